@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X.
+
+A "step" is one ForwardTransformer forward (non-autoregressive TransformerTTS, 80-bin mel) over one batch of
+synthetic LJSpeech-shaped input; at the default workload (BASELINE config 2) that is B=1, N=100 phoneme
+tokens, T=600 mel frames.  Inputs and weights are resident in HBM before the timed region; the whole forward
+is replayed from a hipGraph (captured through torch.cuda.CUDAGraph).  With --gpus N>1 every rank runs an
+independent replica on its own utterances (the path shards by utterance; there is no data-path collective),
+so scaling is "weak".
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline      the kernel with the largest share of the forward's device time, timed in isolation with HIP
+                events on the launch stream, priced against the dense bf16 MFMA peak (or HBM for byte-bound ops)
+  cpu_baseline  the op-for-op PyTorch CPU float32 restatement of the same graph (oracle/tts_torch.py) on this
+                host's cores, on the same utterance (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import estts  # noqa: E402,F401
+from estts import configs, ops, weights  # noqa: E402
+from estts.forward_transformer import ForwardTransformer  # noqa: E402
+
+MFMA_BF16_PEAK = 2.5e15   # dense bf16, FLOP/s (MI355X)
+HBM_PEAK = 8.0e12         # B/s
+
+
+def synthetic_utterance(cfg, B, N, T, seed):
+    rng = np.random.default_rng(seed)
+    tokens = rng.integers(1, cfg['vocab_size'], size=(B, N)).astype(np.int32)
+    d = rng.integers(1, 12, size=(B, N)).astype(np.float64)
+    d = np.floor(d * T / d.sum(axis=1, keepdims=True))
+    d[:, 0] += T - d.sum(axis=1)
+    return tokens, d.astype(np.int32)
+
+
+def algorithmic_flops(N, T):
+    """MACs per utterance of the reference graph (per-token, per-frame and attention terms), times 2."""
+    macs = N * 12_583_424 + T * 6_451_200 + 4 * 2 * N * N * 512 + 4 * 2 * T * T * 256
+    return 2.0 * macs
+
+
+def time_kernels(trace, reps=50):
+    """Time every traced launch in isolation (reps back-to-back launches between two events)."""
+    rows = []
+    for kind, info, fn in trace:
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        rows.append((kind, info, e0.elapsed_time(e1) * 1e-3 / reps))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=1)
+    ap.add_argument('--tokens', type=int, default=100)
+    ap.add_argument('--frames', type=int, default=600)
+    ap.add_argument('--precision', default='bf16x3', choices=['bf16', 'bf16x3'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-attention-weights', action='store_true',
+                    help='skip materialising the attention maps the reference returns')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    cfg = configs.forward_config()
+    w = weights.init_forward_transformer(cfg, seed=1234)
+    B, N, T = args.batch, args.tokens, args.frames
+    tokens, durs = synthetic_utterance(cfg, B, N, T, seed=1234 + rank)
+    model = ForwardTransformer(w, cfg, precision=args.precision)
+    tok_d = torch.from_numpy(tokens).cuda()
+    dur_d = torch.from_numpy(durs.astype(np.float32)).cuda()
+    want_attn = not args.no_attention_weights
+
+    def step():
+        return model.call(tok_d, target_durations=dur_d, max_frames=T, return_attention=want_attn)
+
+    out = step()
+    torch.cuda.synchronize()
+
+    # parity gate on the benchmarked utterance (rank 0): float32 restatement on the CPU
+    cpu = None
+    mel_l1 = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import tts_torch as OT
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        OT.forward_transformer_call(w, cfg, tokens, durs)                 # warm-up
+        runs, t_cpu = 0, 0.0
+        while runs < 3 and t_cpu < 20.0:
+            t0 = time.perf_counter()
+            ref = OT.forward_transformer_call(w, cfg, tokens, durs)
+            t_cpu += time.perf_counter() - t0
+            runs += 1
+        mel_l1 = float(np.abs(out['mel'].cpu().numpy() - ref['mel']).mean())
+        cpu = {'value': B * T * runs / t_cpu, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': f'{runs} forward(s) of the same B={B}, N={N}, T={T} utterance, PyTorch CPU float32'}
+
+    # per-kernel timing for the roofline entry
+    ops.start_trace()
+    step()
+    trace = ops.stop_trace()
+    torch.cuda.synchronize()
+    rows = time_kernels(trace)
+    total_iso = sum(r[2] for r in rows)
+    groups = {}
+    for kind, info, t in rows:
+        key = (kind,) + tuple(sorted((k, v) for k, v in info.items() if k not in ('flops', 'bytes')))
+        g = groups.setdefault(key, {'kind': kind, 'info': info, 'n': 0, 't': 0.0})
+        g['n'] += 1
+        g['t'] += t
+    dom = max(groups.values(), key=lambda g: g['t'])
+    if args.kernel_table and rank == 0:
+        for g in sorted(groups.values(), key=lambda g: -g['t']):
+            shape = {k: v for k, v in g['info'].items() if k not in ('flops', 'bytes')}
+            print(f"{g['kind']:10s} x{g['n']:2d} avg {g['t'] / g['n'] * 1e6:8.2f} us  share {g['t'] / total_iso:5.1%} "
+                  f"{g['info']['flops'] / (g['t'] / g['n']) / 1e12:8.2f} TF/s {g['info']['bytes'] / (g['t'] / g['n']) / 1e9:8.1f} GB/s {shape}",
+                  file=sys.stderr)
+        print(f'launches {len(rows)}, sum of isolated kernel times {total_iso * 1e6:.1f} us', file=sys.stderr)
+    avg = dom['t'] / dom['n']
+    if dom['kind'] in ('gemm', 'attention'):
+        roofline = {'bound': 'mfma', 'achieved': dom['info']['flops'] / avg / 1e12, 'peak': MFMA_BF16_PEAK / 1e12,
+                    'unit': 'TFLOP/s'}
+    else:
+        roofline = {'bound': 'hbm', 'achieved': dom['info']['bytes'] / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s'}
+    roofline['frac'] = roofline['achieved'] / roofline['peak']
+    roofline['traffic'] = None
+    roofline['kernel'] = dom['kind'] + ' ' + json.dumps({k: v for k, v in dom['info'].items() if k not in ('flops', 'bytes')})
+    roofline['avg_us'] = avg * 1e6
+    roofline['launches_per_step'] = dom['n']
+    roofline['share_of_step'] = dom['t'] / total_iso
+
+    # whole-forward timing
+    graph = None
+    if not args.no_graph:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = step()
+        run = graph.replay
+    else:
+        run = step
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt * 1e3 / args.steps
+    value = world * B * T / (dt / args.steps)
+
+    if rank == 0:
+        line = {
+            'metric': 'mel-frames/sec (fwd TransformerTTS)', 'value': value, 'unit': 'mel-frames/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'ForwardTransformer forward (non-AR, 80-mel), batch={B}, N={N} tokens, T={T} frames '
+                                   f'per GPU (BASELINE config 2); {args.precision} MFMA operands, fp32 accumulate',
+                       'global_batch': world * B, 'parallelism': f'replicas x{world}', 'hip_graph': graph is not None,
+                       'attention_weights_materialised': want_attn, 'launches_per_step': len(rows)},
+            'algorithmic_tflops': world * B * algorithmic_flops(N, T) / (dt / args.steps) / 1e12,
+            'mel_l1_vs_cpu_fp32': mel_l1,
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,86 @@
+"""ctypes binding of libestts.so (the C ABI declared in include/estts.h).
+
+There is no fallback: if the shared library is missing or does not export a
+symbol, importing an op raises.  Build it with `make -C <package>/csrc` (or
+`python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libestts.so')
+
+ABI_VERSION = 1
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
+
+_vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('A', _vp), ('lda', _i32), ('seg_len', _i32), ('taps', _i32), ('c_per_tap', _i32), ('tap_lpad', _i32),
+                ('W_hi', _vp), ('W_lo', _vp), ('ldw', _i32), ('M', _i32), ('N', _i32), ('K', _i32),
+                ('s1', _vp), ('b1', _vp), ('act', _i32), ('alpha', _f32),
+                ('R', _vp), ('ldr', _i32), ('r_mod', _i32), ('s2', _vp), ('b2', _vp),
+                ('C', _vp), ('ldc', _i32), ('precision', _i32)]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [('q', _vp), ('ldq', _i32), ('k', _vp), ('ldk', _i32), ('v', _vp), ('ldv', _i32),
+                ('ctx', _vp), ('ldo', _i32), ('attn', _vp), ('key_mask', _vp),
+                ('B', _i32), ('H', _i32), ('Lq', _i32), ('Lk', _i32), ('depth', _i32),
+                ('causal', _i32), ('precision', _i32)]
+
+
+class RownormArgs(C.Structure):
+    _fields_ = [('y', _vp), ('ldy', _i32), ('x', _vp), ('ldx', _i32), ('ga', _vp), ('ba', _vp), ('gb', _vp), ('bb', _vp),
+                ('act', _i32), ('eps', _f32), ('out', _vp), ('ldo', _i32), ('M', _i32), ('D', _i32),
+                ('dot_w', _vp), ('dot_b', _f32), ('dot_scale', _f32), ('dot_mask', _vp), ('dot_out', _vp)]
+
+
+# symbol -> (restype, argtypes); every symbol declared in include/estts.h must be listed here
+SIGNATURES = {
+    'estts_abi_version': (_i32, []),
+    'estts_last_error': (C.c_char_p, []),
+    'estts_gemm': (_i32, [C.POINTER(GemmArgs), _vp]),
+    'estts_attention': (_i32, [C.POINTER(AttentionArgs), _vp]),
+    'estts_rownorm': (_i32, [C.POINTER(RownormArgs), _vp]),
+    'estts_embed_posenc': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    'estts_durations_cumsum': (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    'estts_expand': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class EsttsError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libestts.so once; raise if it is missing, stale or lacks a declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EsttsError(f'{LIB_PATH} not found: the HIP extension is not built (make -C {_PKG}/csrc). '
+                         'There is no CPU fallback for the hot path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EsttsError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.estts_abi_version()
+    if v != ABI_VERSION:
+        raise EsttsError(f'libestts.so ABI version {v}, host code expects {ABI_VERSION}: rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().estts_last_error()
+        raise EsttsError(f'{what} failed (rc={rc}): {msg.decode() if msg else "?"}')

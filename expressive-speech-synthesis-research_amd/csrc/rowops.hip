@@ -1,0 +1,225 @@
+// HBM-bound row kernels: embedding + positional encoding, LayerNorm combos, length regulator.
+// All of them move float4 per lane, one wave per row where a row reduction is needed.
+#include "common.h"
+
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void estts_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* estts_last_error(void) { return g_err; }
+extern "C" int estts_abi_version(void) { return ESTTS_ABI_VERSION; }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_posenc_kernel(const int32_t* tokens, const float* emb, const float* pe,
+                                                           const float* pos_scalar, float* out, int ldo,
+                                                           float* key_mask, int rows, int N, int D, float scale,
+                                                           int pe_stride) {
+    const int dq = D >> 2;
+    const long total = (long)rows * dq;
+    const float ps = pos_scalar ? pos_scalar[0] : 1.0f;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / dq);
+        const int c = (int)(idx - (long)row * dq) * 4;
+        const int n = row % N;
+        const int tok = tokens[row];
+        const float4 e = *reinterpret_cast<const float4*>(emb + (long)tok * D + c);
+        const float4 q = *reinterpret_cast<const float4*>(pe + (long)n * pe_stride * D + c);
+        float4 r;
+        r.x = e.x * scale + ps * q.x;
+        r.y = e.y * scale + ps * q.y;
+        r.z = e.z * scale + ps * q.z;
+        r.w = e.w * scale + ps * q.w;
+        *reinterpret_cast<float4*>(out + (long)row * ldo + c) = r;
+        if (key_mask && c == 0) key_mask[row] = tok == 0 ? 1.0f : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// out = LNb(act(LNa(y)) + x), one wave per row, up to 4 float4 per lane (D <= 1024)
+__device__ __forceinline__ void ln_inplace(float4 (&v)[4], int nch, int lane, int dq, int D, const float* gamma,
+                                           const float* beta, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    const float inv = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) {
+            const int c = (lane + 64 * i) * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 be = *reinterpret_cast<const float4*>(beta + c);
+            v[i].x = (v[i].x - mean) * inv * ga.x + be.x;
+            v[i].y = (v[i].y - mean) * inv * ga.y + be.y;
+            v[i].z = (v[i].z - mean) * inv * ga.z + be.z;
+            v[i].w = (v[i].w - mean) * inv * ga.w + be.w;
+        }
+}
+
+__global__ __launch_bounds__(256) void rownorm_kernel(const estts_rownorm_args p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int dq = p.D >> 2;
+    const int nch = (dq + 63) >> 6;
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq)
+            v[i] = *reinterpret_cast<const float4*>(p.y + (long)row * p.ldy + (lane + 64 * i) * 4);
+    if (p.ga) ln_inplace(v, nch, lane, dq, p.D, p.ga, p.ba, p.eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) {
+            v[i].x = apply_act(v[i].x, p.act);
+            v[i].y = apply_act(v[i].y, p.act);
+            v[i].z = apply_act(v[i].z, p.act);
+            v[i].w = apply_act(v[i].w, p.act);
+            if (p.x) {
+                const float4 r = *reinterpret_cast<const float4*>(p.x + (long)row * p.ldx + (lane + 64 * i) * 4);
+                v[i].x += r.x;
+                v[i].y += r.y;
+                v[i].z += r.z;
+                v[i].w += r.w;
+            }
+        }
+    if (p.gb) ln_inplace(v, nch, lane, dq, p.D, p.gb, p.bb, p.eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) {
+            const int c = (lane + 64 * i) * 4;
+            if (p.out) *reinterpret_cast<float4*>(p.out + (long)row * p.ldo + c) = v[i];
+            if (p.dot_w) {
+                const float4 w = *reinterpret_cast<const float4*>(p.dot_w + c);
+                dot += v[i].x * w.x + v[i].y * w.y + v[i].z * w.z + v[i].w * w.w;
+            }
+        }
+    if (p.dot_w) {
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            float d = fmaxf(dot + p.dot_b, 0.0f) * p.dot_scale;
+            if (p.dot_mask) d *= (1.0f - p.dot_mask[row]);
+            p.dot_out[row] = d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// inclusive prefix sum of max(rint(dur), 0) along N, one 256-thread workgroup per batch row
+__global__ __launch_bounds__(256) void durations_cumsum_kernel(const float* dur, int32_t* cum, int32_t* totals, int N) {
+    __shared__ int part[256];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int per = (N + 255) / 256;
+    const int lo = tid * per;
+    const int hi = min(lo + per, N);
+    int s = 0;
+    for (int n = lo; n < hi; ++n) s += max((int)rintf(dur[(long)b * N + n]), 0);
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;  // exclusive prefix of this thread's span
+    for (int n = lo; n < hi; ++n) {
+        run += max((int)rintf(dur[(long)b * N + n]), 0);
+        cum[(long)b * N + n] = run;
+    }
+    if (tid == 255) totals[b] = part[255];
+}
+
+// one wave per output frame
+__global__ __launch_bounds__(256) void expand_kernel(const float* x, int ldx, const int32_t* cum, float* out, int ldo,
+                                                     float* frame_mask, int B, int N, int T, int D) {
+    const int lane = threadIdx.x & 63;
+    const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= (long)B * T) return;
+    const int b = (int)(frame / T);
+    const int t = (int)(frame - (long)b * T);
+    const int32_t* c = cum + (long)b * N;
+    const int total = c[N - 1];
+    float* o = out + frame * ldo;
+    const int dq = D >> 2;
+    if (t >= total) {
+        for (int ch = lane; ch < dq; ch += 64) *reinterpret_cast<float4*>(o + ch * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (frame_mask && lane == 0) frame_mask[frame] = 1.0f;
+        return;
+    }
+    int lo = 0, hi = N - 1;  // smallest n with cum[n] > t
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    const float* src = x + ((long)b * N + lo) * ldx;
+    for (int ch = lane; ch < dq; ch += 64)
+        *reinterpret_cast<float4*>(o + ch * 4) = *reinterpret_cast<const float4*>(src + ch * 4);
+    if (frame_mask && lane == 0) frame_mask[frame] = 0.0f;
+}
+
+}  // namespace
+
+extern "C" int estts_embed_posenc(const int32_t* tokens, const float* emb, const float* pe, const float* pos_scalar,
+                                  float* out, int32_t ldo, float* key_mask, int32_t B, int32_t N, int32_t D,
+                                  float scale, int32_t pe_stride, void* stream) {
+    ESTTS_CHECK_ARG(tokens && emb && pe && out, "estts_embed_posenc: null pointer");
+    ESTTS_CHECK_ARG(B > 0 && N > 0 && D > 0 && (D & 3) == 0 && (ldo & 3) == 0 && ldo >= D, "estts_embed_posenc: bad shape");
+    const long total = (long)B * N * (D >> 2);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tokens, emb, pe, pos_scalar,
+                       out, ldo, key_mask, B * N, N, D, scale, pe_stride);
+    ESTTS_CHECK_LAUNCH("estts_embed_posenc");
+    return 0;
+}
+
+extern "C" int estts_rownorm(const estts_rownorm_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_rownorm: null args");
+    const estts_rownorm_args& a = *args;
+    ESTTS_CHECK_ARG(a.y && (a.out || a.dot_w), "estts_rownorm: null y/out");
+    ESTTS_CHECK_ARG(a.M > 0 && a.D > 0 && a.D <= 1024 && (a.D & 3) == 0, "estts_rownorm: D=%d must be <=1024, multiple of 4", a.D);
+    ESTTS_CHECK_ARG((a.ldy & 3) == 0 && (!a.x || (a.ldx & 3) == 0) && (!a.out || (a.ldo & 3) == 0), "estts_rownorm: ld not multiple of 4");
+    ESTTS_CHECK_ARG(!a.ga || a.ba, "estts_rownorm: ga without ba");
+    ESTTS_CHECK_ARG(!a.gb || a.bb, "estts_rownorm: gb without bb");
+    ESTTS_CHECK_ARG(!a.dot_w || a.dot_out, "estts_rownorm: dot_w without dot_out");
+    hipLaunchKernelGGL(rownorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_CHECK_LAUNCH("estts_rownorm");
+    return 0;
+}
+
+extern "C" int estts_durations_cumsum(const float* dur, int32_t* cum, int32_t* totals, int32_t B, int32_t N, void* stream) {
+    ESTTS_CHECK_ARG(dur && cum && totals && B > 0 && N > 0, "estts_durations_cumsum: bad arguments");
+    hipLaunchKernelGGL(durations_cumsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dur, cum, totals, N);
+    ESTTS_CHECK_LAUNCH("estts_durations_cumsum");
+    return 0;
+}
+
+extern "C" int estts_expand(const float* x, int32_t ldx, const int32_t* cum, float* out, int32_t ldo, float* frame_mask,
+                            int32_t B, int32_t N, int32_t T, int32_t D, void* stream) {
+    ESTTS_CHECK_ARG(x && cum && out && B > 0 && N > 0 && T > 0 && D > 0, "estts_expand: bad arguments");
+    ESTTS_CHECK_ARG((D & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= D && ldo >= D, "estts_expand: D / ld must be multiples of 4");
+    const long frames = (long)B * T;
+    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, cum,
+                       out, ldo, frame_mask, B, N, T, D);
+    ESTTS_CHECK_LAUNCH("estts_expand");
+    return 0;
+}

@@ -1,0 +1,172 @@
+"""ForwardTransformer (non-autoregressive TransformerTTS) on MI355X.
+
+Mirrors the surface of the reference class
+(TransformerTTS/pretrained_models/for_text_encoder/models.py:283-477): `call`, `forward`,
+`predict`, `set_constants`, `encode_text`, same argument meaning and the same output dict keys;
+tensors are torch CUDA tensors instead of tf tensors.  All arithmetic runs in libestts.so kernels.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .blocks import ConvBNLayer, SelfAttentionStack, _dev_vec, pack_conv, pack_dense, pack_ln
+from .text import Tokenizer, default_alphabet
+
+
+class ForwardTransformer:
+    def __init__(self, weights, config, device='cuda', precision='bf16x3', fold_ffn=True):
+        """weights: dict name -> ndarray in Keras layouts (see weights.py); config: dict with the keys of
+        config/*/forward_config.yaml."""
+        if not torch.cuda.is_available():
+            raise RuntimeError('ForwardTransformer needs a GPU: the hot path has no CPU implementation')
+        ops._lib.load()
+        self.config = dict(config)
+        self.device = torch.device(device)
+        self.precision = precision
+        self.drop_n_heads = 0
+        self.mel_channels = config['mel_channels']
+        w, dev = weights, self.device
+        de, dd = config['encoder_model_dimension'], config['decoder_model_dimension']
+        self.de, self.dd = de, dd
+        self.tokenizer = Tokenizer(default_alphabet(), add_start_end=False)
+        self.emb = _dev_vec(w['encoder_prenet.embeddings'], dev)
+        self.pe_enc = ops.positional_encoding_table(config['encoder_max_position_encoding'], de, dev) * float(
+            w['encoder.pos_encoding_scalar'])
+        self.pe_dec = ops.positional_encoding_table(config['decoder_max_position_encoding'], dd, dev) * float(
+            w['decoder.pos_encoding_scalar'])
+        self.encoder = SelfAttentionStack(w, 'encoder', 'Encoder', de, config['encoder_num_heads'],
+                                          config['encoder_dense_blocks'], dev, fold_ffn=fold_ffn)
+        self.decoder = SelfAttentionStack(w, 'decoder', 'Decoder', dd, config['decoder_num_heads'],
+                                          config['decoder_dense_blocks'], dev, fold_ffn=fold_ffn)
+        # duration predictor: CNNResNorm with LayerNorm (layers.py:618-642)
+        self.dp_conv0 = pack_conv(w, 'dur_pred.conv_blocks.conv0', 'same', dev)
+        self.dp_conv1 = pack_conv(w, 'dur_pred.conv_blocks.last_conv', 'same', dev)
+        self.dp_ln = [pack_ln(w, f'dur_pred.conv_blocks.norm{i}', dev) for i in range(3)]
+        self.dp_w = _dev_vec(np.asarray(w['dur_pred.linear.kernel'])[:, 0], dev)
+        self.dp_b = float(np.asarray(w['dur_pred.linear.bias'])[0])
+        self.prenet1 = pack_dense(w, 'decoder_prenet.d1', dev, act='relu')
+        self.prenet2 = pack_dense(w, 'decoder_prenet.d2', dev, act='relu')
+        self.out = pack_dense(w, 'out', dev)
+        self.postnet = ConvBNLayer(w, 'decoder_postnet', config['postnet_conv_layers'], 'tanh', 'linear', 'same', dev)
+        self._ws = {}
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B, N, T):
+        key = (B, N, T)
+        ws = self._ws.get(key)
+        if ws is None:
+            dev, f32 = self.device, dict(dtype=torch.float32, device=self.device)
+            Me, Md = B * N, B * T
+            ws = {'enc': self.encoder.alloc(Me, dev), 'dec': self.decoder.alloc(Md, dev),
+                  'key_mask': torch.empty(B, N, **f32), 'dp_a': torch.empty(Me, self.de, **f32),
+                  'dp_b': torch.empty(Me, self.de, **f32), 'dur': torch.empty(B, N, **f32),
+                  'cum': torch.empty(B, N, dtype=torch.int32, device=dev),
+                  'totals': torch.empty(B, dtype=torch.int32, device=dev),
+                  'mels_in': torch.empty(Md, self.de, **f32), 'frame_mask': torch.empty(B, T, **f32),
+                  'p1': torch.empty(Md, self.prenet1.N, **f32), 'mel0': torch.empty(Md, self.mel_channels, **f32),
+                  'pn_a': torch.empty(Md, max(self.postnet.hidden(), 4), **f32),
+                  'pn_b': torch.empty(Md, max(self.postnet.hidden(), 4), **f32)}
+            if len(self._ws) > 8:
+                self._ws.clear()
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ stages
+    def _encode(self, tokens, ws, B, N, durations_scalar, return_attention):
+        de = self.de
+        e = ws['enc']
+        ops.embed_posenc(tokens, self.emb, self.pe_enc, None, e['xc'], ws['key_mask'], math.sqrt(np.float32(de)))
+        attn = self.encoder.run(e, B, N, ws['key_mask'], self.precision, return_attention)
+        x = e['xc'][:, :de]
+        ops.gemm(x, self.dp_conv0, ws['dp_a'], seg_len=N, precision=self.precision)
+        ops.rownorm(ws['dp_a'], ws['dp_b'], ln_a=self.dp_ln[0], act='relu')
+        ops.gemm(ws['dp_b'], self.dp_conv1, ws['dp_a'], seg_len=N, precision=self.precision)
+        ops.rownorm(ws['dp_a'], None, ln_a=self.dp_ln[1], act='relu', residual=x, ln_b=self.dp_ln[2],
+                    dot_w=self.dp_w, dot_b=self.dp_b, dot_scale=float(durations_scalar),
+                    dot_mask=ws['key_mask'].view(-1), dot_out=ws['dur'].view(-1))
+        return attn
+
+    def _decode(self, ws, B, N, T, return_attention):
+        de, dd = self.de, self.dd
+        d = ws['dec']
+        ops.expand(ws['enc']['xc'][:, :de], ws['cum'], ws['mels_in'], ws['frame_mask'], B, N, T, de)
+        ops.gemm(ws['mels_in'], self.prenet1, ws['p1'], precision=self.precision)
+        ops.gemm(ws['p1'], self.prenet2, d['xc'][:, :dd], alpha=math.sqrt(np.float32(dd)), residual=self.pe_dec,
+                 r_mod=T, precision=self.precision)
+        attn = self.decoder.run(d, B, T, ws['frame_mask'], self.precision, return_attention)
+        ops.gemm(d['xc'][:, :dd], self.out, ws['mel0'], precision=self.precision)
+        mel = torch.empty(B * T, self.mel_channels, dtype=torch.float32, device=self.device)
+        self.postnet.run(ws['mel0'], ws['pn_a'], ws['pn_b'], mel, T, self.precision)
+        return mel.view(B, T, self.mel_channels), attn
+
+    # ------------------------------------------------------------------ reference surface
+    def call(self, x, target_durations=None, training=False, durations_scalar=1., return_attention=True,
+             max_frames=None):
+        """models.py:434-456.  x: int32 [B,N] tokens (0 = padding); target_durations: [B,N] or None.
+
+        With target_durations=None the predicted durations decide the number of frames, which costs one
+        device-to-host read of B integers (the reference has the same dependency inside Expand).
+        `max_frames` (optional) fixes T without that read: frames beyond it are dropped, missing ones are padding.
+        """
+        if training:
+            raise NotImplementedError('training=True runs through estts.training (dropout, batch statistics)')
+        tokens = torch.as_tensor(x, device=self.device).to(torch.int32).contiguous()
+        B, N = tokens.shape
+        if N > self.pe_enc.shape[0]:
+            raise ValueError(f'{N} tokens exceed encoder_max_position_encoding={self.pe_enc.shape[0]}')
+        T_known = max_frames
+        td = None
+        if target_durations is not None:
+            if not torch.is_tensor(target_durations) or not target_durations.is_cuda:
+                tdn = np.rint(np.asarray(target_durations, dtype=np.float64))
+                if T_known is None:
+                    T_known = int(np.maximum(tdn, 0).sum(axis=1).max())
+                td = torch.from_numpy(tdn.astype(np.float32)).to(self.device)
+            else:
+                td = target_durations.to(torch.float32)
+            td = td.reshape(B, N).contiguous()
+        ws = self._workspace(B, N, T_known or 0)
+        enc_attn = self._encode(tokens, ws, B, N, durations_scalar, return_attention)
+        ops.durations_cumsum(td if td is not None else ws['dur'], ws['cum'], ws['totals'])
+        T = T_known
+        if T is None:
+            T = int(ws['totals'].max().item())
+            ws2 = self._workspace(B, N, T)
+            for k in ('enc', 'key_mask', 'dur', 'cum', 'totals'):
+                ws2[k] = ws[k]
+            ws = ws2
+        if T > self.pe_dec.shape[0]:
+            raise ValueError(f'{T} frames exceed decoder_max_position_encoding={self.pe_dec.shape[0]}')
+        duration = ws['dur'].clone().view(B, N, 1)
+        if T == 0:
+            mel = torch.zeros(B, 0, self.mel_channels, device=self.device)
+            return {'mel': mel, 'duration': duration, 'expanded_mask': torch.zeros(B, 1, 1, 0, device=self.device),
+                    'encoder_attention': enc_attn, 'decoder_attention': {}}
+        mel, dec_attn = self._decode(ws, B, N, T, return_attention)
+        return {'mel': mel, 'duration': duration, 'expanded_mask': ws['frame_mask'].clone().view(B, 1, 1, T),
+                'encoder_attention': enc_attn, 'decoder_attention': dec_attn}
+
+    __call__ = call
+
+    def forward(self, input_sequence, durations_scalar=1., **kw):
+        """models.py:427-428."""
+        return self.call(input_sequence, target_durations=None, training=False, durations_scalar=durations_scalar, **kw)
+
+    def set_constants(self, decoder_prenet_dropout=None, learning_rate=None, drop_n_heads=None, **kwargs):
+        """models.py:458-465 (inference object: only head drop is recorded; it is inactive outside training)."""
+        if drop_n_heads is not None:
+            self.drop_n_heads = drop_n_heads
+
+    def encode_text(self, text):
+        """models.py:467-468.  The phonemizer (espeak) is an external program; `text` must already be phonemes."""
+        return self.tokenizer(text)
+
+    def predict(self, inp, encode=True, speed_regulator=1.):
+        """models.py:470-477."""
+        if encode:
+            inp = torch.tensor([self.encode_text(inp)], dtype=torch.int32)
+        out = self.forward(inp, durations_scalar=1. / speed_regulator)
+        out['mel'] = out['mel'].squeeze()
+        return out

@@ -1,0 +1,220 @@
+"""Host-side op layer: torch tensors in, HIP kernels (through the C ABI) out.
+
+torch is used for device memory and the current stream only; no torch op
+computes anything on the hot path.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT, AttentionArgs, GemmArgs, RownormArgs, check
+
+PRECISION = {'bf16': 1, 'bf16x3': 3}
+
+# When set to a list, every op appends (kind, info dict, relaunch callable): used by bench.py to time
+# individual kernels with events and to price them against the roofline.
+_trace = None
+
+
+def start_trace():
+    global _trace
+    _trace = []
+    return _trace
+
+
+def stop_trace():
+    global _trace
+    t, _trace = _trace, None
+    return t
+
+
+def _record(kind, info, fn, args, *rest):
+    if _trace is not None:
+        _trace.append((kind, info, lambda: fn(args, *rest)))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+def _check_f32(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f'{name}: expected a float32 CUDA tensor, got {t.dtype} on {t.device}')
+    if t.stride(-1) != 1:
+        raise ValueError(f'{name}: last dimension must be contiguous')
+
+
+class PackedLinear:
+    """A dense / conv1d weight in the kernel's layout: bf16 hi (+ lo) [N_pad][K_pad], K contiguous, plus the
+    float32 epilogue vectors (s1, b1: scale and bias applied before the activation; s2, b2: trailing affine).
+
+    `w_nk` is a float array [N, K] (for a convolution K = taps * c_per_tap, tap-major)."""
+
+    def __init__(self, w_nk, bias=None, scale=None, device='cuda', taps=1, lpad=0, act=None, s2=None, b2=None):
+        w_nk = np.ascontiguousarray(np.asarray(w_nk, dtype=np.float32))
+        self.N, self.K = w_nk.shape
+        if self.K % 4:
+            raise ValueError('K must be a multiple of 4')
+        self.taps, self.lpad = taps, lpad
+        self.c_per_tap = self.K // taps
+        self.act = ACT[act]
+        Np, Kp = _ceil(self.N, 64), _ceil(self.K, 32)
+        wp = torch.zeros(Np, Kp, dtype=torch.float32)
+        wp[:self.N, :self.K] = torch.from_numpy(w_nk)
+        hi = wp.to(torch.bfloat16)
+        lo = (wp - hi.to(torch.float32)).to(torch.bfloat16)
+        self.ldw = Kp
+        self.w_hi = hi.to(device)
+        self.w_lo = lo.to(device)
+
+        def vec(v, fill):
+            out = torch.full((Np,), fill, dtype=torch.float32)
+            if v is not None:
+                out[:self.N] = torch.from_numpy(np.asarray(v, dtype=np.float32))
+            return out.to(device)
+
+        self.s1 = vec(scale, 1.0) if scale is not None else None
+        self.b1 = vec(bias, 0.0) if bias is not None else None
+        self.s2 = vec(s2, 1.0) if s2 is not None else None
+        self.b2 = vec(b2, 0.0) if s2 is not None else None
+
+    @property
+    def nbytes(self):
+        return self.w_hi.numel() * 2
+
+
+def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None):
+    """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary)."""
+    _check_f32(x, 'x'); _check_f32(out, 'out')
+    M = x.shape[0] if M is None else M
+    a = GemmArgs()
+    a.A, a.lda, a.seg_len = x.data_ptr(), x.stride(0), seg_len
+    a.taps, a.c_per_tap, a.tap_lpad = lin.taps, lin.c_per_tap, lin.lpad
+    a.W_hi, a.W_lo, a.ldw = lin.w_hi.data_ptr(), lin.w_lo.data_ptr(), lin.ldw
+    a.M, a.N, a.K = M, lin.N, lin.K
+    a.s1, a.b1 = _ptr(lin.s1), _ptr(lin.b1)
+    a.act = lin.act if act is None else ACT[act]
+    a.alpha = alpha
+    if residual is not None:
+        _check_f32(residual, 'residual')
+        a.R, a.ldr, a.r_mod = residual.data_ptr(), residual.stride(0), r_mod
+    a.s2, a.b2 = _ptr(lin.s2), _ptr(lin.b2)
+    a.C, a.ldc = out.data_ptr(), out.stride(0)
+    a.precision = PRECISION[precision]
+    if lin.taps == 1 and x.shape[1] < lin.K:
+        raise ValueError(f'gemm: x has {x.shape[1]} columns, weight expects K={lin.K}')
+    if out.shape[1] < lin.N:
+        raise ValueError(f'gemm: out has {out.shape[1]} columns, weight produces N={lin.N}')
+    check(_lib.load().estts_gemm(a, _stream()), 'estts_gemm')
+    nsplit = 2 if precision == 'bf16x3' else 1
+    _record('gemm', {'M': M, 'N': lin.N, 'K': lin.K, 'taps': lin.taps, 'flops': 2.0 * M * lin.N * lin.K,
+                     'bytes': 4.0 * M * lin.K / lin.taps + 2.0 * nsplit * lin.N * lin.K + 4.0 * M * lin.N},
+            _lib.load().estts_gemm, a, _stream())
+    return out
+
+
+def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, attn=None, precision='bf16x3'):
+    """q: [B*Lq, >=H*depth] view, k/v: [B*Lk, ...] views, ctx: [B*Lq, ...] view; attn: [B,H,Lq,Lk] or None."""
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v'), (ctx, 'ctx')):
+        _check_f32(t, n)
+    a = AttentionArgs()
+    a.q, a.ldq = q.data_ptr(), q.stride(0)
+    a.k, a.ldk = k.data_ptr(), k.stride(0)
+    a.v, a.ldv = v.data_ptr(), v.stride(0)
+    a.ctx, a.ldo = ctx.data_ptr(), ctx.stride(0)
+    if attn is not None:
+        if tuple(attn.shape) != (B, H, Lq, Lk) or not attn.is_contiguous():
+            raise ValueError('attention: attn must be a contiguous [B,H,Lq,Lk] tensor')
+        a.attn = attn.data_ptr()
+    a.key_mask = _ptr(key_mask)
+    a.B, a.H, a.Lq, a.Lk, a.depth = B, H, Lq, Lk, depth
+    a.causal = int(causal)
+    a.precision = PRECISION[precision]
+    check(_lib.load().estts_attention(a, _stream()), 'estts_attention')
+    _record('attention', {'B': B, 'H': H, 'Lq': Lq, 'Lk': Lk, 'depth': depth, 'weights': attn is not None,
+                          'flops': 4.0 * B * H * Lq * Lk * depth,
+                          'bytes': 4.0 * B * H * depth * (2 * Lq + 2 * Lk) + (4.0 * B * H * Lq * Lk if attn is not None else 0)},
+            _lib.load().estts_attention, a, _stream())
+    return ctx
+
+
+def rownorm(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=None, D=None,
+            dot_w=None, dot_b=0.0, dot_scale=1.0, dot_mask=None, dot_out=None):
+    """out = LNb(act(LNa(y)) + residual); ln_a / ln_b are (gamma, beta) tensor pairs or None."""
+    _check_f32(y, 'y')
+    a = RownormArgs()
+    a.y, a.ldy = y.data_ptr(), y.stride(0)
+    if residual is not None:
+        a.x, a.ldx = residual.data_ptr(), residual.stride(0)
+    if ln_a is not None:
+        a.ga, a.ba = ln_a[0].data_ptr(), ln_a[1].data_ptr()
+    if ln_b is not None:
+        a.gb, a.bb = ln_b[0].data_ptr(), ln_b[1].data_ptr()
+    a.act, a.eps = ACT[act], eps
+    if out is not None:
+        a.out, a.ldo = out.data_ptr(), out.stride(0)
+    a.M = y.shape[0] if M is None else M
+    a.D = y.shape[1] if D is None else D
+    if dot_w is not None:
+        a.dot_w, a.dot_b, a.dot_scale = dot_w.data_ptr(), dot_b, dot_scale
+        a.dot_mask, a.dot_out = _ptr(dot_mask), dot_out.data_ptr()
+    check(_lib.load().estts_rownorm(a, _stream()), 'estts_rownorm')
+    _record('rownorm', {'M': a.M, 'D': a.D, 'flops': 0.0,
+                        'bytes': 4.0 * a.M * a.D * (1 + (residual is not None) + (out is not None))},
+            _lib.load().estts_rownorm, a, _stream())
+    return out
+
+
+def embed_posenc(tokens, emb, pe, pos_scalar, out, key_mask, scale, pe_stride=1):
+    """tokens int32 [B,N]; emb [V,D]; pe [P,D]; out [B*N, >=D] view; key_mask [B,N] or None."""
+    if tokens.dtype != torch.int32:
+        raise TypeError('tokens must be int32')
+    B, N = tokens.shape
+    D = emb.shape[1]
+    if N * pe_stride > pe.shape[0] + pe_stride - 1:
+        raise ValueError(f'sequence length {N} exceeds the positional table ({pe.shape[0]})')
+    check(_lib.load().estts_embed_posenc(tokens.data_ptr(), emb.data_ptr(), pe.data_ptr(), _ptr(pos_scalar),
+                                         out.data_ptr(), out.stride(0), _ptr(key_mask), B, N, D, scale, pe_stride,
+                                         _stream()), 'estts_embed_posenc')
+    return out
+
+
+def durations_cumsum(dur, cum, totals):
+    """dur float32 [B,N] -> cum int32 [B,N] (inclusive prefix sums of round-half-even), totals int32 [B]."""
+    B, N = dur.shape
+    check(_lib.load().estts_durations_cumsum(dur.data_ptr(), cum.data_ptr(), totals.data_ptr(), B, N, _stream()),
+          'estts_durations_cumsum')
+
+
+def expand(x, cum, out, frame_mask, B, N, T, D):
+    check(_lib.load().estts_expand(x.data_ptr(), x.stride(0), cum.data_ptr(), out.data_ptr(), out.stride(0),
+                                   _ptr(frame_mask), B, N, T, D, _stream()), 'estts_expand')
+    return out
+
+
+def positional_encoding_table(position, model_dim, device):
+    """Sinusoidal table, float64 angles rounded to float32 (TransformerTTS/model/transformer_utils.py:5-21)."""
+    pos = np.arange(position, dtype=np.float64)[:, None]
+    i = np.arange(model_dim)[None, :]
+    rates = 1.0 / np.power(10000.0, (2 * (i // 2)) / np.float32(model_dim))
+    ang = pos * rates
+    ang[:, 0::2] = np.sin(ang[:, 0::2])
+    ang[:, 1::2] = np.cos(ang[:, 1::2])
+    return torch.from_numpy(ang.astype(np.float32)).to(device)
+
+
+def fold_batchnorm(gamma, beta, mean, var, eps=1e-3):
+    """Inference BatchNormalization as y = x * s + b (Keras epsilon 1e-3)."""
+    s = np.asarray(gamma, np.float64) / np.sqrt(np.asarray(var, np.float64) + eps)
+    b = np.asarray(beta, np.float64) - np.asarray(mean, np.float64) * s
+    return s.astype(np.float32), b.astype(np.float32)

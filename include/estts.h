@@ -1,0 +1,168 @@
+/*
+ * estts.h -- C ABI of libestts.so, the MI355X (gfx950) kernel library behind the
+ * expressive-TTS acoustic + vocoder hot path.
+ *
+ * The reference (sankar-mukherjee/Expressive-Speech-Synthesis-Research) has no
+ * FFI / plugin interface: its hot path is reached through Python objects that
+ * call TensorFlow-Keras / PyTorch layers.  Each entry point below therefore
+ * replaces one (or one fused group) of those framework-layer calls; the comment
+ * on every declaration names the reference call sites it stands in for
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (allocated by
+ *     PyTorch-ROCm or hipMalloc); nothing here allocates, frees or synchronises,
+ *     so every call may be captured into a hipGraph
+ *   - `stream` is a hipStream_t passed as void*; work is asynchronous on it
+ *   - return value 0 = launched; negative = argument / launch error, text via
+ *     estts_last_error() (thread-local)
+ *   - activations are float32 row-major [rows, ld]; rows = batch * seq_len with
+ *     row m = b * seq_len + t; weights are bf16 (hi [+ lo] split), laid out
+ *     [N_padded][K_padded] with K contiguous
+ */
+#ifndef ESTTS_H
+#define ESTTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESTTS_ABI_VERSION 1
+
+/* activation codes for estts_gemm / estts_rownorm */
+#define ESTTS_ACT_NONE 0
+#define ESTTS_ACT_RELU 1
+#define ESTTS_ACT_TANH 2
+
+int estts_abi_version(void);
+const char* estts_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused dense / 1-D convolution on the matrix cores.
+ *
+ *   acc[m, n] = sum_{tap, c} A[row(m) + tap - tap_lpad, c] * W[n, tap * c_per_tap + c]
+ *               (rows outside [0, seg_len) of m's own segment contribute zero)
+ *   v = acc * s1[n] + b1[n];  v = act(v);  v = v * alpha;
+ *   if (R)  v += R[(r_mod ? m % r_mod : m), n];
+ *   if (s2) v = v * s2[n] + b2[n];
+ *   C[m, n] = v
+ *
+ * Replaces: tf.keras.layers.Dense / Conv1D (+ folded inference BatchNormalization, activation,
+ * residual add, trailing BatchNormalization) at TransformerTTS/model/layers.py:19-47 (CNNResNorm),
+ * :58-67 (FFNResNorm d1/d2), :112-116,129-131,145 (MultiHeadAttention wq/wk/wv/dense),
+ * :387-401 (DecoderPrenet), :636 (DurationPredictor.linear),
+ * pretrained_models/for_text_encoder/models.py:350 (out);
+ * nn.Linear / nn.Conv1d at WaveRNN/models/fatchord_version.py:13-25,32-45,109-114.
+ *
+ * precision: 1 = bf16 operands (one MFMA per product); 3 = split-bf16 (hi*hi + lo*hi + hi*lo,
+ * fp32 accumulate; needs W_lo).  K, c_per_tap and lda must be multiples of 4; W rows are padded
+ * with zeros to ldw (multiple of 32) and W has at least ceil(N/64)*64 rows.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct estts_gemm_args {
+    const float* A;
+    int32_t lda;
+    int32_t seg_len;     /* rows per sequence (conv boundary); 0 = one segment of M rows */
+    int32_t taps;        /* 1 = dense */
+    int32_t c_per_tap;   /* input channels per tap; K = taps * c_per_tap */
+    int32_t tap_lpad;    /* left padding in rows: (k-1)/2 for 'same', k-1 for 'causal' */
+    const uint16_t* W_hi;
+    const uint16_t* W_lo; /* may be NULL when precision == 1 */
+    int32_t ldw;
+    int32_t M, N, K;
+    const float* s1;     /* NULL = 1 */
+    const float* b1;     /* NULL = 0 */
+    int32_t act;
+    float alpha;
+    const float* R;      /* NULL = none */
+    int32_t ldr;
+    int32_t r_mod;
+    const float* s2;     /* NULL = none (then b2 ignored) */
+    const float* b2;
+    float* C;
+    int32_t ldc;
+    int32_t precision;
+} estts_gemm_args;
+
+int estts_gemm(const estts_gemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-head scaled-dot-product attention over already-projected q / k / v.
+ *
+ *   S = q k^T / sqrt(depth) + mask * (-1e9);  P = softmax(S);  ctx = P v
+ *   mask[b, i, j] = max(key_mask[b, j], causal ? (j > i) : 0)
+ *
+ * q rows: [B*Lq, ldq] (head h at columns h*depth .. ), k / v rows: [B*Lk, ldk / ldv];
+ * ctx is written to [B*Lq, ldo] at column h*depth; attn (optional) is [B, H, Lq, Lk] float32.
+ * depth must be 32, 64 or 128.
+ *
+ * Replaces: scaled_dot_product_attention + split_heads / merge at
+ * TransformerTTS/model/transformer_utils.py:24-58 and model/layers.py:118-143; the masks of
+ * transformer_utils.py:61-74 enter as key_mask (float 0/1 per key) and the causal flag.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct estts_attention_args {
+    const float* q; int32_t ldq;
+    const float* k; int32_t ldk;
+    const float* v; int32_t ldv;
+    float* ctx; int32_t ldo;
+    float* attn;             /* NULL = do not materialise the attention weights */
+    const float* key_mask;   /* [B, Lk] 1.0 = masked; NULL = none */
+    int32_t B, H, Lq, Lk, depth;
+    int32_t causal;
+    int32_t precision;       /* 1 or 3, as in estts_gemm */
+} estts_attention_args;
+
+int estts_attention(const estts_attention_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-wise normalisation combos:   out = LNb( act( LNa(y) ) + x )
+ * each stage optional; LayerNorm over the last axis (biased variance, eps inside the sqrt).
+ * Optionally also emits dot[m] = relu(out[m,:] . dot_w + dot_b) * dot_scale * (dot_mask ? 1 - dot_mask[m] : 1).
+ *
+ * Replaces: LayerNormalization chains at TransformerTTS/model/layers.py:65-71 (FFNResNorm),
+ * :163-168 (SelfAttentionResNorm), :270-274 (CrossAttentionResnorm), :35-47 with
+ * normalization='layer' (DurationPredictor), and the Dense(1, relu) + padding zeroing at
+ * layers.py:636-642 / pretrained_models/for_text_encoder/models.py:439-440.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct estts_rownorm_args {
+    const float* y; int32_t ldy;
+    const float* x; int32_t ldx;        /* residual, NULL = none */
+    const float* ga; const float* ba;   /* LNa gamma/beta, NULL = skip LNa */
+    const float* gb; const float* bb;   /* LNb gamma/beta, NULL = skip LNb */
+    int32_t act;
+    float eps;
+    float* out; int32_t ldo;
+    int32_t M, D;                       /* D <= 1024, multiple of 4 */
+    const float* dot_w;                 /* NULL = no dot output */
+    float dot_b; float dot_scale;
+    const float* dot_mask;              /* [M] 1.0 = padded row */
+    float* dot_out;                     /* [M] */
+} estts_rownorm_args;
+
+int estts_rownorm(const estts_rownorm_args* args, void* stream);
+
+/* out[b, n, :] = emb[tokens[b, n], :] * scale + pos_scalar[0] * pe[n * pe_stride, :];
+ * also writes key_mask[b, n] = (tokens[b, n] == 0) when key_mask != NULL.
+ * Replaces: Embedding + the positional add at TransformerTTS/model/layers.py:242-246 and
+ * create_encoder_padding_mask (model/transformer_utils.py:61-63). */
+int estts_embed_posenc(const int32_t* tokens, const float* emb, const float* pe, const float* pos_scalar,
+                       float* out, int32_t ldo, float* key_mask, int32_t B, int32_t N, int32_t D,
+                       float scale, int32_t pe_stride, void* stream);
+
+/* Length regulator, step 1: reps = max(round_half_even(dur), 0) per token, inclusive prefix sums
+ * per batch row into cum[b, 0..N-1] and the row total into totals[b].  One workgroup per batch row.
+ * Replaces: tf.math.round + the row-length bookkeeping of Expand.call, model/layers.py:667-677. */
+int estts_durations_cumsum(const float* dur, int32_t* cum, int32_t* totals, int32_t B, int32_t N, void* stream);
+
+/* Length regulator, step 2: out[b, t, :] = x[b, n(t), :] where n(t) is the token whose span covers
+ * frame t (binary search in cum); frames t >= totals[b] are zero and get frame_mask[b, t] = 1.
+ * Replaces: the tile / mask / ragged-to-dense of Expand.call (model/layers.py:679-683) and
+ * create_mel_padding_mask on its output (pretrained_models/for_text_encoder/models.py:445). */
+int estts_expand(const float* x, int32_t ldx, const int32_t* cum, float* out, int32_t ldo, float* frame_mask,
+                 int32_t B, int32_t N, int32_t T, int32_t D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESTTS_H */

@@ -1,0 +1,201 @@
+"""Per-kernel parity tests (GPU): each HIP kernel, called through the C ABI, against a float64/float32
+restatement of the same op on identical inputs.  Tolerances are stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import estts
+from estts import ops
+from estts.ops import PackedLinear
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize('M,N,K', [(600, 512, 768), (100, 1536, 512), (37, 80, 256), (1, 64, 4), (130, 1, 512)])
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 2e-5), ('bf16', 2e-2)])
+def test_gemm_dense(M, N, K, precision, tol):
+    x = _rand(M, K, seed=1)
+    w = _rand(N, K, seed=2, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=3)
+    lin = PackedLinear(w.numpy(), bias=b.numpy(), device=DEV)
+    out = torch.full((M, N), float('nan'), device=DEV)
+    ops.gemm(x.to(DEV), lin, out, precision=precision)
+    ref = x.double() @ w.double().t() + b.double()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < tol, err
+
+
+def test_gemm_asymmetric_layout():
+    # A = identity picks out W^T exactly; catches transposed / permuted fragment maps (values exact in bf16)
+    K = N = 64
+    x = torch.eye(K)
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125
+    lin = PackedLinear(w.numpy(), device=DEV)
+    out = torch.empty(K, N, device=DEV)
+    ops.gemm(x.to(DEV), lin, out, precision='bf16')
+    assert torch.equal(out.cpu(), w.t())
+
+
+@pytest.mark.parametrize('taps,lpad,cin,cout,T,B', [(3, 1, 256, 512, 50, 2), (5, 2, 80, 256, 33, 3), (5, 4, 80, 80, 20, 1)])
+def test_gemm_conv_epilogue(taps, lpad, cin, cout, T, B):
+    # conv1d ('same' or causal) + scale/bias + tanh + residual + trailing affine, strided input/output views
+    x_full = _rand(B * T, cin + 8, seed=4)
+    x = x_full[:, :cin]
+    kern = _rand(taps, cin, cout, seed=5, scale=1 / math.sqrt(taps * cin))
+    s1, b1 = _rand(cout, seed=6).abs() + 0.5, _rand(cout, seed=7)
+    s2, b2 = _rand(cout, seed=8).abs() + 0.5, _rand(cout, seed=9)
+    res = _rand(B * T, cout, seed=10)
+    lin = PackedLinear(kern.reshape(taps * cin, cout).t().numpy(), bias=b1.numpy(), scale=s1.numpy(), device=DEV,
+                       taps=taps, lpad=lpad, act='tanh', s2=s2.numpy(), b2=b2.numpy())
+    out_full = torch.zeros(B * T, cout + 4, device=DEV)
+    ops.gemm(x_full.to(DEV)[:, :cin], lin, out_full[:, :cout], seg_len=T, residual=res.to(DEV), precision='bf16x3')
+    xp = torch.nn.functional.pad(x.double().view(B, T, cin), (0, 0, lpad, taps - 1 - lpad))
+    acc = sum(xp[:, j:j + T] @ kern[j].double() for j in range(taps)).reshape(B * T, cout)
+    ref = (torch.tanh(acc * s1.double() + b1.double()) + res.double()) * s2.double() + b2.double()
+    err = (out_full[:, :cout].cpu().double() - ref).abs().max().item()
+    assert err < 5e-5, err
+    assert (out_full[:, cout:] == 0).all()
+
+
+def test_gemm_posenc_residual_shared_rows():
+    B, T, K, N = 3, 17, 64, 32
+    x, w, pe = _rand(B * T, K, seed=1), _rand(N, K, seed=2, scale=0.1), _rand(40, N, seed=3)
+    lin = PackedLinear(w.numpy(), device=DEV, act='relu')
+    out = torch.empty(B * T, N, device=DEV)
+    ops.gemm(x.to(DEV), lin, out, alpha=4.0, residual=pe.to(DEV), r_mod=T, precision='bf16x3')
+    ref = torch.relu(x.double() @ w.double().t()) * 4.0 + pe[:T].double().repeat(B, 1)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+def test_gemm_rejects_bad_arguments():
+    lin = PackedLinear(np.zeros((8, 16), np.float32), device=DEV)
+    with pytest.raises(ValueError):
+        ops.gemm(torch.zeros(4, 8, device=DEV), lin, torch.zeros(4, 8, device=DEV))
+    with pytest.raises(TypeError):
+        ops.gemm(torch.zeros(4, 16, device=DEV, dtype=torch.float16), lin, torch.zeros(4, 8, device=DEV))
+
+
+def _attention_ref(q, k, v, mask, causal):
+    B, H, Lq, dh = q.shape
+    s = q @ k.transpose(-1, -2) / math.sqrt(dh)
+    m = torch.zeros(B, 1, Lq, k.shape[2], dtype=q.dtype)
+    if mask is not None:
+        m = torch.maximum(m, mask[:, None, None, :].to(q.dtype))
+    if causal:
+        m = torch.maximum(m, torch.triu(torch.ones(Lq, k.shape[2], dtype=q.dtype), diagonal=1))
+    p = torch.softmax(s + m * -1e9, dim=-1)
+    return p @ v, p
+
+
+@pytest.mark.parametrize('B,H,Lq,Lk,dh,causal,masked', [
+    (1, 4, 600, 600, 64, False, False), (2, 4, 100, 100, 128, False, True), (3, 2, 37, 37, 32, True, True),
+    (2, 4, 1, 10, 64, False, False), (2, 4, 50, 75, 64, False, True)])
+@pytest.mark.parametrize('precision,tol', [('bf16x3', 3e-5), ('bf16', 3e-2)])
+def test_attention(B, H, Lq, Lk, dh, causal, masked, precision, tol):
+    d = H * dh
+    q, k, v = _rand(B * Lq, d, seed=1), _rand(B * Lk, d, seed=2), _rand(B * Lk, d, seed=3)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk)
+        for b in range(B):
+            mask[b, Lk - 1 - 3 * b:] = 1.0
+    ctx = torch.full((B * Lq, d + 4), float('nan'), device=DEV)
+    attn = torch.full((B, H, Lq, Lk), float('nan'), device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), ctx[:, :d], B, H, Lq, Lk, dh,
+                  key_mask=None if mask is None else mask.to(DEV), causal=causal, attn=attn, precision=precision)
+    split = lambda t, L: t.double().view(B, L, H, dh).permute(0, 2, 1, 3)
+    ref, pref = _attention_ref(split(q, Lq), split(k, Lk), split(v, Lk), mask, causal)
+    ref = ref.permute(0, 2, 1, 3).reshape(B * Lq, d)
+    assert (ctx[:, :d].cpu().double() - ref).abs().max().item() < tol
+    assert (attn.cpu().double() - pref).abs().max().item() < tol
+    assert torch.isnan(ctx[:, d:]).all()          # columns outside the view untouched
+    # without the weights output the context must be identical
+    ctx2 = torch.empty(B * Lq, d, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), ctx2, B, H, Lq, Lk, dh,
+                  key_mask=None if mask is None else mask.to(DEV), causal=causal, attn=None, precision=precision)
+    assert torch.equal(ctx2, ctx[:, :d])
+
+
+def test_attention_online_softmax_rescale_branch():
+    # one key far above the rest, late in the sequence: forces the running-max rescale at a chosen tile
+    B, H, L, dh = 1, 1, 96, 32
+    q = torch.zeros(L, dh); k = torch.zeros(L, dh); v = _rand(L, dh, seed=5)
+    q[:, 0] = 8.0
+    k[:, 0] = torch.linspace(-1, 1, L)
+    k[70, 0] = 6.0
+    ctx = torch.empty(L, dh, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), ctx, B, H, L, L, dh, precision='bf16x3')
+    ref, _ = _attention_ref(q.double().view(1, 1, L, dh), k.double().view(1, 1, L, dh), v.double().view(1, 1, L, dh), None, False)
+    assert (ctx.cpu().double() - ref[0, 0]).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize('D', [256, 512, 80, 1024])
+def test_rownorm_variants(D):
+    M = 77
+    y, x = _rand(M, D, seed=1), _rand(M, D, seed=2)
+    ga, ba, gb, bb = (_rand(D, seed=s) for s in (3, 4, 5, 6))
+    dev = lambda t: t.to(DEV)
+    F = torch.nn.functional
+    out = torch.empty(M, D, device=DEV)
+    ops.rownorm(dev(y), out, ln_a=(dev(ga), dev(ba)), act='relu', residual=dev(x), ln_b=(dev(gb), dev(bb)))
+    ref = F.layer_norm(torch.relu(F.layer_norm(y.double(), (D,), ga.double(), ba.double(), 1e-6)) + x.double(), (D,),
+                       gb.double(), bb.double(), 1e-6)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    ops.rownorm(dev(y), out, ln_a=(dev(ga), dev(ba)), act='relu')
+    ref = torch.relu(F.layer_norm(y.double(), (D,), ga.double(), ba.double(), 1e-6))
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    # dot output (duration head): relu(out . w + b) * scale * (1 - mask)
+    w = _rand(D, seed=7, scale=0.1)
+    mask = (torch.arange(M) % 5 == 0).float()
+    dot = torch.empty(M, device=DEV)
+    ops.rownorm(dev(y), None, ln_a=(dev(ga), dev(ba)), act='relu', residual=dev(x), ln_b=(dev(gb), dev(bb)),
+                dot_w=dev(w), dot_b=1.0, dot_scale=0.5, dot_mask=dev(mask), dot_out=dot)
+    full = F.layer_norm(torch.relu(F.layer_norm(y.double(), (D,), ga.double(), ba.double(), 1e-6)) + x.double(), (D,),
+                        gb.double(), bb.double(), 1e-6)
+    ref = torch.relu(full @ w.double() + 1.0) * 0.5 * (1 - mask.double())
+    assert (dot.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+def test_embed_posenc_and_mask():
+    B, N, D, V = 3, 19, 64, 30
+    tok = torch.randint(1, V, (B, N), generator=torch.Generator().manual_seed(0), dtype=torch.int32)
+    tok[1, 12:] = 0
+    emb, pe = _rand(V, D, seed=1), _rand(40, D, seed=2)
+    out = torch.empty(B * N, 2 * D, device=DEV)
+    km = torch.empty(B, N, device=DEV)
+    ops.embed_posenc(tok.to(DEV), emb.to(DEV), pe.to(DEV), None, out, km, 8.0)
+    ref = emb[tok.long()] * 8.0 + pe[:N][None]
+    assert torch.allclose(out[:, :D].cpu().view(B, N, D), ref, atol=1e-6)
+    assert torch.equal(km.cpu(), (tok == 0).float())
+
+
+def test_length_regulator_bit_exact():
+    B, N, D = 3, 11, 32
+    dur = torch.tensor(np.random.default_rng(0).uniform(0, 4, size=(B, N)).astype(np.float32))
+    dur[0, :3] = torch.tensor([0.5, 1.5, 2.5])      # half-to-even: 0, 2, 2
+    dur[2, 5:] = 0
+    x = _rand(B * N, D, seed=1)
+    cum = torch.empty(B, N, dtype=torch.int32, device=DEV)
+    tot = torch.empty(B, dtype=torch.int32, device=DEV)
+    ops.durations_cumsum(dur.to(DEV), cum, tot)
+    reps = np.rint(dur.numpy()).astype(np.int64)
+    assert np.array_equal(cum.cpu().numpy(), np.cumsum(reps, axis=1))
+    assert np.array_equal(tot.cpu().numpy(), reps.sum(axis=1))
+    T = int(reps.sum(axis=1).max())
+    out = torch.empty(B * T, D, device=DEV)
+    fm = torch.empty(B, T, device=DEV)
+    ops.expand(x.to(DEV), cum, out, fm, B, N, T, D)
+    ref = np.zeros((B, T, D), np.float32)
+    for b in range(B):
+        rows = np.repeat(np.arange(N), reps[b])
+        ref[b, :len(rows)] = x.view(B, N, D)[b].numpy()[rows]
+    assert np.array_equal(out.cpu().numpy().reshape(B, T, D), ref)
+    assert np.array_equal(fm.cpu().numpy(), (np.arange(T)[None] >= reps.sum(axis=1)[:, None]).astype(np.float32))

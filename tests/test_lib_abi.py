@@ -1,0 +1,44 @@
+"""CPU-side checks of the C ABI boundary: the shared library loads and exports every symbol that
+include/estts.h declares (no compute is launched here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import estts
+from estts import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'estts.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(estts_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_are_bound_and_exported():
+    declared = _declared_symbols()
+    assert declared, 'no declarations parsed from estts.h'
+    assert set(declared) == set(_lib.SIGNATURES), (declared, sorted(_lib.SIGNATURES))
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail(f'{_lib.LIB_PATH} missing: run __graft_entry__.build() first')
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_abi_version_and_error_channel():
+    lib = _lib.load()
+    assert lib.estts_abi_version() == _lib.ABI_VERSION
+    # argument validation happens before any HIP call, so it is safe without a GPU
+    rc = lib.estts_gemm(None, None)
+    assert rc != 0 and b'null args' in lib.estts_last_error()
+
+
+def test_struct_sizes_match_header_layout():
+    # pointer/int packing of the ctypes mirrors: 64-bit pointers, 4-byte ints, natural alignment
+    assert ctypes.sizeof(_lib.GemmArgs) == 136
+    assert ctypes.sizeof(_lib.AttentionArgs) == 112
+    assert ctypes.sizeof(_lib.RownormArgs) == 128
