@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -22,7 +22,8 @@ class GemmArgs(C.Structure):
                 ('W_hi', _vp), ('W_lo', _vp), ('ldw', _i32), ('M', _i32), ('N', _i32), ('K', _i32),
                 ('s1', _vp), ('b1', _vp), ('act', _i32), ('alpha', _f32),
                 ('R', _vp), ('ldr', _i32), ('r_mod', _i32), ('s2', _vp), ('b2', _vp),
-                ('C', _vp), ('ldc', _i32), ('precision', _i32)]
+                ('C', _vp), ('ldc', _i32), ('precision', _i32),
+                ('ws', _vp), ('ws_bytes', C.c_int64), ('counters', _vp), ('n_counters', _i32), ('tune', _i32)]
 
 
 class AttentionArgs(C.Structure):

@@ -1,32 +1,283 @@
-// Fused dense / 1-D-convolution kernel on the gfx950 matrix cores (see estts_gemm in include/estts.h).
+// Fused dense / 1-D-convolution kernels on the gfx950 matrix cores (see estts_gemm in include/estts.h).
 //
-// Tiling: one 256-thread workgroup (4 waves) owns a BM x BN tile of C and walks K in steps of 32.
-// A (float32 activations) is read with 16-byte loads, split into bf16 hi (+ lo) in registers and
-// staged in LDS; W (bf16, [N][K], K contiguous) is staged as is.  Both LDS images use 80-byte rows
-// (32 bf16 + 8 pad) so that the 16 rows one ds_read_b128 lane group touches fall on disjoint banks.
-// The next K-step's global loads are issued before the current step's MFMAs (register prefetch,
-// two LDS buffers, one barrier per step).  v_mfma_f32_16x16x32_bf16: lane l holds
-// A[row l&15][k 8(l>>4)..+7], B[k 8(l>>4)..+7][col l&15]; D[row 4(l>>4)+j][col l&15].
-// A convolution is the same loop with K = taps * c_per_tap: K-chunk -> (tap, channel), the A row is
-// shifted by tap - tap_lpad and rows that leave the sequence read as zero.
+// Operands.  A = float32 activations, row-major; every kernel splits them into bf16 hi (+ lo) on the fly.
+// W = bf16 weights, pre-packed by the host in FRAGMENT-MAJOR order: for each 16-row block nt of W[N][K]
+// and each 32-wide K-step ks there is one contiguous 1 KiB block holding, for lane l = 0..63, the 8 values
+// W[16 nt + (l & 15)][32 ks + 8 (l >> 4) .. + 7]  -- exactly the B operand of v_mfma_f32_16x16x32_bf16
+// (lane l holds B[k 8(l>>4)..+7][col l&15]; A[row l&15][k 8(l>>4)..+7]; D[row 4(l>>4)+j][col l&15]).
+// A wave therefore fetches a weight fragment with one fully coalesced 16-byte-per-lane load, and an LDS
+// image of it is lane-linear (conflict-free).  Loading fragments row-wise instead (16 rows x 64 B per
+// instruction) costs about 4x the L1 cycles, which is what bounds these kernels.
+//
+// A convolution is the same product with K = taps * c_per_tap: a K-chunk maps to (tap, channel), the A row
+// is shifted by tap - tap_lpad, and rows that leave the sequence read as zero.
+//
+// Two kernels:
+//  * gemm_small_kernel (tile id 4; batch-1 synthesis, M up to ~1k rows).  No barrier in the K loop: a
+//    workgroup owns a 32 x 32 tile of C and its NW waves take interleaved K-steps.  Each wave loads its
+//    A slice (32 rows x 32 k) with coalesced float4 loads, converts, and turns it into MFMA fragments
+//    through a wave-private LDS image (80-byte rows: bank-conflict-free for ds_read_b128); the loads of the
+//    next K-step are in flight during the MFMAs.  Partial tiles are summed through LDS at the end.
+//  * gemm_kernel (tile ids 1-3; large M).  Classic LDS-staged BM x BN tile, K stages of 64, register
+//    prefetch of the next stage, two LDS buffers, one barrier per stage.
+// Both support split-K over gridDim.z: every workgroup writes its float32 partial to a slab, takes a ticket
+// from a per-tile counter, and the last arriver sums the slabs and runs the epilogue.  Hand-off: every wave
+// drains its stores, workgroup barrier, one lane issues an agent-scope release fence and then the relaxed
+// agent-scope ticket add; the last arriver issues an agent-scope acquire fence before any wave reads the
+// slabs.  The counter is reset by the last arriver, so it must be zero only before the first ever launch.
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_LD = 40;  // bf16 elements per LDS row
+constexpr int BK = 64;
+
+__device__ __forceinline__ float epilogue_value(const estts_gemm_args& p, float acc, int row, int col, float s1,
+                                                float b1, float s2, float b2) {
+    float v = acc * s1 + b1;
+    v = apply_act(v, p.act) * p.alpha;
+    if (p.R) {
+        const int rr = p.r_mod > 0 ? row % p.r_mod : row;
+        v += p.R[(long)rr * p.ldr + col];
+    }
+    if (p.s2) v = v * s2 + b2;
+    return v;
+}
+
+// split-K hand-off; returns true in the workgroup that must finish the tile (all threads must call)
+__device__ __forceinline__ bool splitk_last_arriver(const estts_gemm_args& p, int tile, int splitk, int* s_ticket) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_ticket = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*s_ticket != splitk - 1) return false;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return true;
+}
+
+// ======================================================================================================
+// small-M kernel
+// ======================================================================================================
+constexpr int SM_LD = 40;                      // bf16 per staged A row (32 + 8 pad = 80 B)
+constexpr int SM_WAVE_ELEMS = 2 * 32 * SM_LD;  // hi + lo image per wave
+
+template <int NS>
+struct SmallStage {
+    float4 a[4];
+    uint4 w[NS][2];
+};
+
+template <int NSPLIT, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_args p, const int splitk) {
+    constexpr int NS = (NSPLIT > 1) ? 2 : 1;
+    constexpr int STAGE_BYTES = NW * SM_WAVE_ELEMS * 2;
+    constexpr int RED_BYTES = NW * 16 * 64 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
+    __shared__ int s_ticket;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i16 = lane & 15;
+    const int g = lane >> 4;
+    const int r8 = lane >> 3;
+    const int c8 = lane & 7;
+    const int m0 = blockIdx.y * 32;
+    const int n0 = blockIdx.x * 32;
+    const int seg = p.seg_len > 0 ? p.seg_len : p.M;
+    const int KS = p.ldw >> 5;  // K-steps per packed row block
+
+    int a_row[4], a_t[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + r8 + 8 * j;
+        a_row[j] = m;
+        a_ok[j] = m < p.M;
+        a_t[j] = m % seg;
+    }
+    const uint16_t* whp[2];
+    const uint16_t* wlp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long off = (long)((n0 >> 4) + i) * KS * 512 + lane * 8;
+        whp[i] = p.W_hi + off;
+        wlp[i] = p.W_lo + off;
+    }
+
+    const int nks_all = (p.K + 31) / 32;
+    const int per = (nks_all + splitk - 1) / splitk;
+    const int ks_end = min((int)(blockIdx.z + 1) * per, nks_all);
+    int ks = blockIdx.z * per + wave;
+
+    auto load = [&](int k, SmallStage<NS>& st) {
+        const int kk = k * 32 + c8 * 4;
+        int tap = 0, c = kk;
+        if (p.taps > 1) {
+            tap = kk / p.c_per_tap;
+            c = kk - tap * p.c_per_tap;
+        }
+        const int shift = tap - p.tap_lpad;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = a_t[j] + shift;
+            const bool ok = a_ok[j] && kk < p.K && t >= 0 && t < seg;
+            const float* ap = p.A + (long)(a_row[j] + shift) * p.lda + c;
+            st.a[j] = ok ? *reinterpret_cast<const float4*>(ap) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            st.w[0][i] = *reinterpret_cast<const uint4*>(whp[i] + (long)k * 512);
+            if (NS == 2) st.w[NS - 1][i] = *reinterpret_cast<const uint4*>(wlp[i] + (long)k * 512);
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    __bf16* stage = reinterpret_cast<__bf16*>(smem) + wave * SM_WAVE_ELEMS;  // [hi | lo][32][SM_LD]
+
+    auto compute = [&](const SmallStage<NS>& st) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v[4] = {st.a[j].x, st.a[j].y, st.a[j].z, st.a[j].w};
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 h, l;
+                split_bf16(v[e], h, l);
+                hi[e] = h;
+                lo[e] = l;
+            }
+            const int o = (r8 + 8 * j) * SM_LD + c8 * 4;
+            *reinterpret_cast<bf16x4*>(stage + o) = hi;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(stage + 32 * SM_LD + o) = lo;
+        }
+        bf16x8 af[NS][2], wf[NS][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = (i * 16 + i16) * SM_LD + g * 8;
+            af[0][i] = *reinterpret_cast<const bf16x8*>(stage + o);
+            if (NS == 2) af[NS - 1][i] = *reinterpret_cast<const bf16x8*>(stage + 32 * SM_LD + o);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) wf[s][i] = __builtin_bit_cast(bf16x8, st.w[s][i]);
+        }
+        // small terms first; consecutive MFMAs go to different accumulators
+        if (NS == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NS - 1][i], wf[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], wf[NS - 1][j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], wf[0][j], acc[i][j], 0, 0, 0);
+    };
+
+    SmallStage<NS> sa, sb;
+    if (ks < ks_end) {
+        load(ks, sa);
+        while (true) {
+            if (ks + NW < ks_end) load(ks + NW, sb);
+            compute(sa);
+            ks += NW;
+            if (ks >= ks_end) break;
+            if (ks + NW < ks_end) load(ks + NW, sa);
+            compute(sb);
+            ks += NW;
+            if (ks >= ks_end) break;
+        }
+    }
+
+    // sum the waves' partial tiles (the staging images are dead after the barrier); wave w < 4 finishes
+    // sub-tile (w >> 1, w & 1), the other waves only keep the barriers company
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [NW][16][64]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 16 + (i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+    const bool fin = wave < 4;
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    if (fin) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[r] += red[(w * 16 + wave * 4 + r) * 64 + lane];
+    }
+
+    if (splitk > 1) {
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        const long ntiles = (long)gridDim.x * gridDim.y;
+        float* slab = p.ws + ((long)blockIdx.z * ntiles + tile) * 1024;
+        if (fin) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[r * 256 + tid] = out[r];
+        }
+        if (!splitk_last_arriver(p, tile, splitk, &s_ticket)) return;
+        out = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (fin) {
+            for (int z = 0; z < splitk; ++z) {
+                const float* sl = p.ws + ((long)z * ntiles + tile) * 1024;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] += sl[r * 256 + tid];
+            }
+        }
+    }
+    if (!fin) return;
+
+    const int col = n0 + (wave & 1) * 16 + i16;
+    if (col >= p.N) return;
+    const float s1 = p.s1 ? p.s1[col] : 1.0f;
+    const float b1 = p.b1 ? p.b1[col] : 0.0f;
+    const float s2 = p.s2 ? p.s2[col] : 1.0f;
+    const float b2 = p.s2 ? p.b2[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + (wave >> 1) * 16 + g * 4 + r;
+        if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value(p, out[r], row, col, s1, b1, s2, b2);
+    }
+}
+
+// ======================================================================================================
+// large-M kernel
+// ======================================================================================================
+constexpr int A_LD = 72;  // bf16 per staged A row (64 + 8 pad = 144 B)
 
 template <int BM, int BN, int WM, int WN, int NSPLIT>
-__global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p) {
+__global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p, const int splitk) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
-    constexpr int A_ITERS = BM * 8 / 256;
-    constexpr int W_ITERS = BN * 4 / 256;
+    constexpr int A_ITERS = BM * 16 / 256;
+    constexpr int W_ITERS = BN * 8 / 256;
     constexpr int MI = BM / WM / 16;
     constexpr int NI = BN / WN / 16;
-    static_assert(A_ITERS >= 1 && W_ITERS >= 1 && MI >= 1 && NI >= 1, "tile too small");
+    static_assert(WM * WN == 4 && A_ITERS >= 1 && W_ITERS >= 1 && MI >= 1 && NI >= 1, "bad tile");
 
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][NS][BN * LDS_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][BM * A_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][NS][BN * BK];  // (BN/16) x 2 fragment blocks of 512
+    __shared__ int s_ticket;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -36,25 +287,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p) {
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
     const int seg = p.seg_len > 0 ? p.seg_len : p.M;
+    const int KS = p.ldw >> 5;
 
-    // per-thread A load slots
     int a_row[A_ITERS], a_t[A_ITERS];
     bool a_ok[A_ITERS];
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-        const int idx = tid + i * 256;
-        const int m = m0 + (idx >> 3);
+        const int m = m0 + ((tid + i * 256) >> 4);
         a_row[i] = m;
         a_ok[i] = m < p.M;
         a_t[i] = m % seg;
     }
-    const int a_ch = tid & 7;  // (tid + i*256) & 7 is the same for every i
+    const int a_ch = tid & 15;  // same 16-byte column chunk for every i
 
     float4 a_reg[A_ITERS];
     uint4 w_reg[NS][W_ITERS];
 
-    auto load_tiles = [&](int k0) {
-        const int kk = k0 + a_ch * 4;
+    auto load_tiles = [&](int kt) {
+        const int kk = kt * BK + a_ch * 4;
         int tap = 0, c = kk;
         if (p.taps > 1) {
             tap = kk / p.c_per_tap;
@@ -65,13 +315,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p) {
         for (int i = 0; i < A_ITERS; ++i) {
             const int t = a_t[i] + shift;
             const bool ok = a_ok[i] && kk < p.K && t >= 0 && t < seg;
-            a_reg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) a_reg[i] = *reinterpret_cast<const float4*>(p.A + (long)(a_row[i] + shift) * p.lda + c);
+            const float* ap = p.A + (long)(a_row[i] + shift) * p.lda + c;
+            a_reg[i] = ok ? *reinterpret_cast<const float4*>(ap) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i) {
             const int idx = tid + i * 256;
-            const long off = (long)(n0 + (idx >> 2)) * p.ldw + k0 + (idx & 3) * 8;
+            const int blk = idx >> 6;  // (n16 block j, k-step s) = (blk >> 1, blk & 1)
+            const long off = ((long)((n0 >> 4) + (blk >> 1)) * KS + kt * 2 + (blk & 1)) * 512 + (idx & 63) * 8;
             w_reg[0][i] = *reinterpret_cast<const uint4*>(p.W_hi + off);
             if (NS == 2) w_reg[NS - 1][i] = *reinterpret_cast<const uint4*>(p.W_lo + off);
         }
@@ -80,8 +331,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p) {
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_ITERS; ++i) {
-            const int idx = tid + i * 256;
-            const int o = (idx >> 3) * LDS_LD + a_ch * 4;
+            const int o = ((tid + i * 256) >> 4) * A_LD + a_ch * 4;
             const float v[4] = {a_reg[i].x, a_reg[i].y, a_reg[i].z, a_reg[i].w};
             bf16x4 hi, lo;
 #pragma unroll
@@ -96,8 +346,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p) {
         }
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i) {
-            const int idx = tid + i * 256;
-            const int o = (idx >> 2) * LDS_LD + (idx & 3) * 8;
+            const int o = (tid + i * 256) * 8;
             *reinterpret_cast<uint4*>(&Ws[buf][0][o]) = w_reg[0][i];
             if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][o]) = w_reg[NS - 1][i];
         }
@@ -109,42 +358,79 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
-    const int frag_off = (lane & 15) * LDS_LD + (lane >> 4) * 8;
-    const int a_base = wm * (BM / WM) * LDS_LD + frag_off;
-    const int w_base = wn * (BN / WN) * LDS_LD + frag_off;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int per = (nk_all + splitk - 1) / splitk;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = min(kt0 + per, nk_all);
 
-    load_tiles(0);
+    const int a_base = (wm * (BM / WM) + (lane & 15)) * A_LD + (lane >> 4) * 8;
+    const int w_base = wn * NI * 2 * 512 + lane * 8;
+
+    if (kt0 < kt1) load_tiles(kt0);
     int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < kt1; ++kt) {
         store_tiles(buf);
         __syncthreads();
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-
-        bf16x8 af[NS][MI], wf[NS][NI];
+        if (kt + 1 < kt1) load_tiles(kt + 1);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 af[NS][MI], wf[NS][NI];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    af[s][i] = *reinterpret_cast<const bf16x8*>(&As[buf][s][a_base + i * 16 * A_LD + ks * 32]);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    wf[s][j] = *reinterpret_cast<const bf16x8*>(&Ws[buf][s][w_base + (j * 2 + ks) * 512]);
+            }
+            if (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NS - 1][i], wf[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], wf[NS - 1][j], acc[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                af[s][i] = *reinterpret_cast<const bf16x8*>(&As[buf][s][a_base + i * 16 * LDS_LD]);
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
-                wf[s][j] = *reinterpret_cast<const bf16x8*>(&Ws[buf][s][w_base + j * 16 * LDS_LD]);
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], wf[0][j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                if (NS == 2) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NS - 1][i], wf[0][j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], wf[NS - 1][j], acc[i][j], 0, 0, 0);
-                }
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], wf[0][j], acc[i][j], 0, 0, 0);
-            }
         buf ^= 1;
     }
 
-    // epilogue
+    if (splitk > 1) {
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        const long ntiles = (long)gridDim.x * gridDim.y;
+        float* slab = p.ws + ((long)blockIdx.z * ntiles + tile) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[((i * NI + j) * 4 + r) * 256 + tid] = acc[i][j][r];
+        if (!splitk_last_arriver(p, tile, splitk, &s_ticket)) return;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < splitk; ++z) {
+            const float* sl = p.ws + ((long)z * ntiles + tile) * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += sl[((i * NI + j) * 4 + r) * 256 + tid];
+        }
+    }
+
     const int col_l = lane & 15;
     const int row_l = (lane >> 4) * 4;
 #pragma unroll
@@ -160,27 +446,55 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (BM / WM) + i * 16 + row_l + r;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * s1 + b1;
-                v = apply_act(v, p.act) * p.alpha;
-                if (p.R) {
-                    const int rr = p.r_mod > 0 ? row % p.r_mod : row;
-                    v += p.R[(long)rr * p.ldr + col];
-                }
-                if (p.s2) v = v * s2 + b2;
-                p.C[(long)row * p.ldc + col] = v;
+                if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value(p, acc[i][j][r], row, col, s1, b1, s2, b2);
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch(const estts_gemm_args& a, hipStream_t st) {
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
+// ------------------------------------------------------------------------------------------------------
+bool splitk_fits(const estts_gemm_args& a, dim3 grid, long tile_elems) {
+    const long need = (long)grid.z * grid.x * grid.y * tile_elems * sizeof(float);
+    if (!a.ws || !a.counters || need > a.ws_bytes || (long)grid.x * grid.y > a.n_counters) {
+        estts_set_error("estts_gemm: split-K needs %ld workspace bytes and %ld counters", need, (long)grid.x * grid.y);
+        return false;
+    }
+    return true;
+}
+
+template <int NW>
+int launch_small_nw(const estts_gemm_args& a, dim3 grid, hipStream_t st) {
     if (a.precision == 3)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_small_kernel<3, NW>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
     else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_small_kernel<1, NW>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
+    ESTTS_CHECK_LAUNCH("estts_gemm");
+    return 0;
+}
+
+int launch_small(const estts_gemm_args& a, int splitk, int nw, hipStream_t st) {
+    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, splitk);
+    if (splitk > 1 && !splitk_fits(a, grid, 1024)) return -1;
+    if (nw == 0) {  // measured on MI355X: 8 waves from 16 K-steps up, 16 waves never (register spills at 128 VGPRs)
+        const int nks = ((a.K + 31) / 32 + splitk - 1) / splitk;
+        nw = nks >= 16 ? 8 : 4;
+    }
+    switch (nw) {
+        case 4: return launch_small_nw<4>(a, grid, st);
+        case 8: return launch_small_nw<8>(a, grid, st);
+        case 16: return launch_small_nw<16>(a, grid, st);
+        default: estts_set_error("estts_gemm: waves per workgroup must be 4, 8 or 16"); return -1;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const estts_gemm_args& a, int splitk, hipStream_t st) {
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splitk);
+    if (splitk > 1 && !splitk_fits(a, grid, BM * BN)) return -1;
+    if (a.precision == 3)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, a, splitk);
+    else
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, st, a, splitk);
     ESTTS_CHECK_LAUNCH("estts_gemm");
     return 0;
 }
@@ -200,13 +514,42 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
                     "estts_gemm: K, c_per_tap and lda must be multiples of 4");
     ESTTS_CHECK_ARG(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W_hi & 15) == 0 && ((uintptr_t)a.W_lo & 15) == 0,
                     "estts_gemm: A / W must be 16-byte aligned");
-    ESTTS_CHECK_ARG(a.ldw >= ((a.K + 31) / 32) * 32 && (a.ldw & 7) == 0, "estts_gemm: ldw too small / unaligned");
+    ESTTS_CHECK_ARG(a.ldw >= ((a.K + 63) / 64) * 64 && (a.ldw & 63) == 0, "estts_gemm: ldw must be K rounded up to 64");
     ESTTS_CHECK_ARG(a.seg_len == 0 || a.M % a.seg_len == 0, "estts_gemm: M not a multiple of seg_len");
     ESTTS_CHECK_ARG(a.taps == 1 || a.lda >= a.c_per_tap, "estts_gemm: lda < c_per_tap");
     ESTTS_CHECK_ARG(!a.R || a.ldr >= a.N, "estts_gemm: ldr < N");
     ESTTS_CHECK_ARG(a.ldc >= a.N, "estts_gemm: ldc < N");
     hipStream_t st = (hipStream_t)stream;
-    const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-    if (tiles64 >= 256) return launch<64, 64, 2, 2>(a, st);
-    return launch<32, 64, 1, 4>(a, st);
+
+    int tile = a.tune & 0xff;
+    int splitk = (a.tune >> 8) & 0xff;
+    if (tile == 0) {
+        const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        tile = t64 < 512 ? 4 : 1;
+    }
+    long tiles;
+    int nk;  // K units that one split must keep at least two of
+    switch (tile) {
+        case 1: tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64); nk = (a.K + BK - 1) / BK; break;
+        case 2: tiles = (long)((a.M + 31) / 32) * ((a.N + 63) / 64); nk = (a.K + BK - 1) / BK; break;
+        case 3: tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32); nk = (a.K + BK - 1) / BK; break;
+        case 4: tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32); nk = (a.K + 31) / 32 / 8; break;
+        default: estts_set_error("estts_gemm: unknown tile id %d", tile); return -1;
+    }
+    if (nk < 1) nk = 1;
+    if (splitk == 0) {
+        // the release / acquire fences of the hand-off cost more than the extra parallelism returns until a launch
+        // has only a handful of tiles, so split automatically only then
+        splitk = 1;
+        if (a.ws && a.counters) {
+            while (splitk < 8 && tiles * splitk * 2 <= 32 && nk / (splitk * 2) >= 2) splitk *= 2;
+        }
+    }
+    if (splitk > nk) splitk = nk;
+    switch (tile) {
+        case 1: return launch<64, 64, 2, 2>(a, splitk, st);
+        case 2: return launch<32, 64, 1, 4>(a, splitk, st);
+        case 3: return launch<32, 32, 2, 2>(a, splitk, st);
+        default: return launch_small(a, splitk, (a.tune >> 16) & 0xff, st);
+    }
 }

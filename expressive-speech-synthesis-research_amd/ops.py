@@ -58,7 +58,8 @@ class PackedLinear:
     """A dense / conv1d weight in the kernel's layout: bf16 hi (+ lo) [N_pad][K_pad], K contiguous, plus the
     float32 epilogue vectors (s1, b1: scale and bias applied before the activation; s2, b2: trailing affine).
 
-    `w_nk` is a float array [N, K] (for a convolution K = taps * c_per_tap, tap-major)."""
+    `w_nk` is a float array [N, K] (for a convolution K = taps * c_per_tap, tap-major).  N is padded to a multiple
+    of 64 and K to a multiple of 64 with zeros; storage order is fragment-major (see _fragment_major)."""
 
     def __init__(self, w_nk, bias=None, scale=None, device='cuda', taps=1, lpad=0, act=None, s2=None, b2=None):
         w_nk = np.ascontiguousarray(np.asarray(w_nk, dtype=np.float32))
@@ -68,14 +69,14 @@ class PackedLinear:
         self.taps, self.lpad = taps, lpad
         self.c_per_tap = self.K // taps
         self.act = ACT[act]
-        Np, Kp = _ceil(self.N, 64), _ceil(self.K, 32)
+        Np, Kp = _ceil(self.N, 64), _ceil(self.K, 64)
         wp = torch.zeros(Np, Kp, dtype=torch.float32)
         wp[:self.N, :self.K] = torch.from_numpy(w_nk)
         hi = wp.to(torch.bfloat16)
         lo = (wp - hi.to(torch.float32)).to(torch.bfloat16)
         self.ldw = Kp
-        self.w_hi = hi.to(device)
-        self.w_lo = lo.to(device)
+        self.w_hi = self._fragment_major(hi).to(device)
+        self.w_lo = self._fragment_major(lo).to(device)
 
         def vec(v, fill):
             out = torch.full((Np,), fill, dtype=torch.float32)
@@ -88,12 +89,39 @@ class PackedLinear:
         self.s2 = vec(s2, 1.0) if s2 is not None else None
         self.b2 = vec(b2, 0.0) if s2 is not None else None
 
+    @staticmethod
+    def _fragment_major(w):
+        """[Np][Kp] -> blocks of 64 lanes x 8 values: block (n // 16, k // 32), lane (n % 16) + 16 * ((k % 32) // 8),
+        i.e. the B-operand register image of v_mfma_f32_16x16x32_bf16, so that one wave reads a fragment as 1 KiB
+        of contiguous memory."""
+        Np, Kp = w.shape
+        return w.view(Np // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
     @property
     def nbytes(self):
         return self.w_hi.numel() * 2
 
 
-def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None):
+_WS_BYTES = 64 << 20
+_N_COUNTERS = 4096
+_workspaces = {}
+
+
+def gemm_workspace(device):
+    """Per-device split-K scratch (float32 slabs + zeroed tickets) shared by every gemm() call on the
+    current stream.  Launches that may run concurrently on different streams must not share it."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _workspaces.get(key)
+    if ws is None:
+        dev = torch.device('cuda', key)
+        ws = (torch.empty(_WS_BYTES // 4, dtype=torch.float32, device=dev),
+              torch.zeros(_N_COUNTERS, dtype=torch.int32, device=dev))
+        _workspaces[key] = ws
+    return ws
+
+
+def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
+         split=True):
     """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary)."""
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
@@ -111,6 +139,10 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     a.s2, a.b2 = _ptr(lin.s2), _ptr(lin.b2)
     a.C, a.ldc = out.data_ptr(), out.stride(0)
     a.precision = PRECISION[precision]
+    a.tune = tune
+    if split:
+        ws, cnt = gemm_workspace(x.device)
+        a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
     if lin.taps == 1 and x.shape[1] < lin.K:
         raise ValueError(f'gemm: x has {x.shape[1]} columns, weight expects K={lin.K}')
     if out.shape[1] < lin.N:

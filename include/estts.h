@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 1
+#define ESTTS_ABI_VERSION 2
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -58,7 +58,16 @@ const char* estts_last_error(void);
  *
  * precision: 1 = bf16 operands (one MFMA per product); 3 = split-bf16 (hi*hi + lo*hi + hi*lo,
  * fp32 accumulate; needs W_lo).  K, c_per_tap and lda must be multiples of 4; W rows are padded
- * with zeros to ldw (multiple of 32) and W has at least ceil(N/64)*64 rows.
+ * with zeros to ldw = K rounded up to 64, W has ceil(N/64)*64 rows, and its storage order is
+ * fragment-major: 1 KiB blocks indexed (n / 16, k / 32), each holding for lane l = 0..63 the eight
+ * values W[16 (n/16) + (l & 15)][32 (k/32) + 8 (l >> 4) .. + 7].
+ *
+ * Split-K: when ws / counters are given and the tile count is small, several workgroups share one
+ * output tile through float32 slabs in ws (ws_bytes >= splitk * tiles * tile_elems * 4) and one
+ * int32 ticket per tile in counters (n_counters of them, zero before the first launch; the kernel
+ * leaves them zero).  Calls that may overlap on the GPU must not share ws / counters.
+ * tune: 0 = choose tile and split automatically; else (tile id 1..4) | (splitk << 8) | (waves << 16,
+ * tile 4 only: 4, 8 or 16 waves per workgroup, 0 = by K).
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_gemm_args {
     const float* A;
@@ -83,6 +92,11 @@ typedef struct estts_gemm_args {
     float* C;
     int32_t ldc;
     int32_t precision;
+    float* ws;           /* split-K slabs, may be NULL (then no split) */
+    int64_t ws_bytes;
+    int32_t* counters;   /* split-K tickets, may be NULL */
+    int32_t n_counters;
+    int32_t tune;
 } estts_gemm_args;
 
 int estts_gemm(const estts_gemm_args* args, void* stream);

@@ -33,6 +33,26 @@ def test_gemm_dense(M, N, K, precision, tol):
     assert err < tol, err
 
 
+@pytest.mark.parametrize('tile', [1, 2, 3, 4])
+@pytest.mark.parametrize('splitk', [1, 2, 8])
+def test_gemm_tiles_and_split_k(tile, splitk):
+    # every tile shape x split-K factor against float64, several back-to-back launches sharing the workspace
+    M, N, K = 200, 192, 1152
+    x = _rand(M, K // 3, seed=1)
+    w = _rand(N, K, seed=2, scale=1 / math.sqrt(K))
+    b = _rand(N, seed=3)
+    lin = PackedLinear(w.numpy(), bias=b.numpy(), device=DEV, taps=3, lpad=1, act='relu')
+    xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1))
+    ref = torch.relu(sum(xp[j:j + M] @ w.double()[:, j * (K // 3):(j + 1) * (K // 3)].t() for j in range(3)) + b.double())
+    xd = x.to(DEV)
+    for rep in range(3):
+        out = torch.full((M, N), float('nan'), device=DEV)
+        ops.gemm(xd, lin, out, seg_len=M, precision='bf16x3', tune=tile | (splitk << 8))
+        assert (out.cpu().double() - ref).abs().max().item() < 5e-5
+    _, counters = ops.gemm_workspace(DEV)
+    assert int(counters.abs().sum().item()) == 0      # tickets are left at zero
+
+
 def test_gemm_asymmetric_layout():
     # A = identity picks out W^T exactly; catches transposed / permuted fragment maps (values exact in bf16)
     K = N = 64
