@@ -49,19 +49,32 @@ def algorithmic_flops(N, T):
     return 2.0 * macs
 
 
-def time_kernels(trace, reps=50):
-    """Time every traced launch in isolation (reps back-to-back launches between two events)."""
+def time_kernels(trace, reps=20, rounds=3):
+    """Device time of every traced launch in isolation: `reps` launches of the same kernel captured into one hipGraph
+    (so that the host's launch cost is not what is measured), replayed between two HIP events on the launch stream;
+    best of `rounds`.  The figure includes the ~1-2 us dependent-launch boundary between consecutive replays."""
     rows = []
-    for kind, info, fn in trace:
-        for _ in range(3):
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for kind, info, fn in trace:
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        e1.synchronize()
-        rows.append((kind, info, e0.elapsed_time(e1) * 1e-3 / reps))
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                for _ in range(reps):
+                    fn()
+            g.replay()
+            best = float('inf')
+            for _ in range(rounds):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                g.replay()
+                e1.record(stream)
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e-3 / reps)
+            rows.append((kind, info, best))
+            del g
+    torch.cuda.synchronize()
     return rows
 
 
@@ -123,11 +136,14 @@ def main():
                'sample': f'{runs} forward(s) of the same B={B}, N={N}, T={T} utterance, PyTorch CPU float32'}
 
     # per-kernel timing for the roofline entry
+    # (the traced step's outputs must stay referenced while its launches are replayed: torch.cuda.graph() empties
+    # the allocator cache on entry, which would unmap any buffer that has been freed in the meantime)
     ops.start_trace()
-    step()
+    traced_out = step()
     trace = ops.stop_trace()
     torch.cuda.synchronize()
     rows = time_kernels(trace)
+    del traced_out
     total_iso = sum(r[2] for r in rows)
     groups = {}
     for kind, info, t in rows:

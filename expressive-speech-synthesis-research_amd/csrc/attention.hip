@@ -1,18 +1,24 @@
 // Multi-head scaled-dot-product attention (see estts_attention in include/estts.h).
 //
-// One wave owns 16 query rows of one (batch, head); a 256-thread workgroup is four such waves.
-// Both products are issued "swapped" so that a query stays on one lane column throughout:
-//   S^T (16 keys x 16 queries) = K_tile . Q^T     A = K rows (key on lane&15), B = Q^T
-//   O^T (16 feats x 16 queries) = V^T . P^T       A = V^T (feature on lane&15), B = P^T
-// With v_mfma_f32_16x16x32_bf16 the D layout is D[row 4(l>>4)+j][col l&15], so after S^T every lane
-// holds, for its query (l&15), the scores of keys 4g+j (g = l>>4) of each 16-key sub-tile; two
-// sub-tiles give the 8 k-slots (8g+j') of the P^T operand without any data movement:
-// slot j' <-> key 16*(j'>>2) + 4g + (j'&3).  V^T fragments are gathered with that same key map.
-// Softmax is online (running max / sum per query, replicated over the 4 lane groups by two
-// xor-shuffles); the optional attention-weight output is a second sweep that recomputes S.
+// A 256-thread workgroup owns 16 query rows of one (batch, head); its four waves take interleaved 32-key
+// tiles and keep private online-softmax state (running max m, sum l, unnormalised output), which is merged
+// through LDS at the end.  Both products are issued "swapped" so that a query stays on one lane column:
+//   S^T (16 keys x 16 queries) = K_tile . Q^T     A = K rows (key on lane & 15),      B = Q^T
+//   O^T (16 feats x 16 queries) = V^T . P^T       A = V^T (feature on lane & 15),     B = P^T
+// With v_mfma_f32_16x16x32_bf16 the D layout is D[row 4(l>>4)+j][col l&15], so after S^T every lane holds,
+// for its query (l & 15), the scores of keys 4g+j (g = l>>4) of each 16-key sub-tile; two sub-tiles give the
+// 8 k-slots (8g+j') of the P^T operand without data movement: slot j' <-> key 16 (j'>>2) + 4g + (j'&3).
+// K and V tiles are read from global memory with coalesced float4 loads (one tile ahead of their use), split
+// into bf16 hi (+ lo) and staged in a wave-private LDS image [32 keys][depth + 8]: K fragments come back with
+// ds_read_b128, V^T fragments with the transposing ds_read_b64_tr_b16 (4 keys x 16 features per 16-lane group,
+// delivered feature-per-lane), in the key order of the P^T slots above.
+// The optional attention-weight output is a second sweep that recomputes S against the merged (m, l).
 #include "common.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 template <int NS>
 struct Frag {
@@ -41,19 +47,35 @@ __device__ __forceinline__ f32x4 mfma_split(const Frag<NS>& a, const Frag<NS>& b
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[0], b.v[0], c, 0, 0, 0);
 }
 
+__device__ __forceinline__ bf16x8 tr_read_pair(const __bf16* p0, const __bf16* p1) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p1);
+    const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
 template <int DH, int NS>
 __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_args p) {
-    constexpr int KS = DH / 32;  // k-steps of the score product
-    constexpr int NT = DH / 16;  // 16-feature tiles of the output
+    constexpr int KS = DH / 32;        // k-steps of the score product
+    constexpr int NT = DH / 16;        // 16-feature tiles of the output
+    constexpr int LD = DH + 8;         // staged row length in bf16 (row stride = 2 DH + 16 bytes)
+    constexpr int LPR = DH / 4;        // lanes per tile row (one float4 each)
+    constexpr int RPI = 64 / LPR;      // tile rows per load instruction
+    constexpr int NLD = 32 / RPI;      // load instructions per 32-key tile
+    constexpr int IMG = 32 * LD;       // one staged image (hi or lo)
+    constexpr int STAGE_BYTES = 4 * NS * IMG * 2;
+    constexpr int MERGE_FLOATS = NT * 256 + 128;  // per wave: O^T fragments + m + l
+    constexpr int MERGE_BYTES = 4 * MERGE_FLOATS * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES];
+
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int i = lane & 15;
     const int g = lane >> 4;
     const int h = blockIdx.y;
     const int b = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * 16;
-    if (q0 >= p.Lq) return;  // whole wave out of range (no barriers in this kernel)
-
+    const int q0 = blockIdx.x * 16;
     const int qi = q0 + i;
     const int qrow = min(qi, p.Lq - 1);
     const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * DH + 8 * g;
@@ -61,6 +83,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     const float* vbase = p.v + (long)b * p.Lk * p.ldv + h * DH;
     const float* mask = p.key_mask ? p.key_mask + (long)b * p.Lk : nullptr;
     const float scale = 1.0f / sqrtf((float)DH);
+    __bf16* stage = reinterpret_cast<__bf16*>(smem) + wave * (NS * IMG);
 
     Frag<NS> qf[KS];
 #pragma unroll
@@ -71,19 +94,46 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
         qf[ks] = make_frag<NS>(t);
     }
 
-    // scores of one 32-key tile for this lane's query: s[sub][j] <-> key kt*32 + sub*16 + 4g + j
+    const int ld_row = lane / LPR;
+    const int ld_col = (lane % LPR) * 4;
+
+    auto load_tile = [&](const float* base, int ld, int kt, float4 (&x)[NLD]) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int key = min(kt * 32 + j * RPI + ld_row, p.Lk - 1);
+            x[j] = *reinterpret_cast<const float4*>(base + (long)key * ld + ld_col);
+        }
+    };
+
+    auto stage_tile = [&](const float4 (&x)[NLD]) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const float v[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 hh, ll;
+                split_bf16(v[e], hh, ll);
+                hi[e] = hh;
+                lo[e] = ll;
+            }
+            const int o = (j * RPI + ld_row) * LD + ld_col;
+            *reinterpret_cast<bf16x4*>(stage + o) = hi;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(stage + IMG + o) = lo;
+        }
+    };
+
+    // scores of the staged K tile for this lane's query: s[sub][j] <-> key kt*32 + sub*16 + 4g + j
     auto scores = [&](int kt, float (&s)[2][4]) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
-            const int krow = min(kt * 32 + sub * 16 + i, p.Lk - 1);
-            const float* kp = kbase + (long)krow * p.ldk + 8 * g;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                float t[8];
-                *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(kp + ks * 32);
-                *reinterpret_cast<float4*>(t + 4) = *reinterpret_cast<const float4*>(kp + ks * 32 + 4);
-                const Frag<NS> kf = make_frag<NS>(t);
+                Frag<NS> kf;
+                const int o = (sub * 16 + i) * LD + ks * 32 + g * 8;
+                kf.v[0] = *reinterpret_cast<const bf16x8*>(stage + o);
+                if (NS == 2) kf.v[NS - 1] = *reinterpret_cast<const bf16x8*>(stage + IMG + o);
                 acc = mfma_split<NS>(kf, qf[ks], acc);
             }
 #pragma unroll
@@ -108,7 +158,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     float m_run = -INFINITY, l_run = 0.0f;
     const int nkt = (p.Lk + 31) / 32;
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    float4 kx[NLD], vx[NLD];
+    if (wave < nkt) {
+        load_tile(kbase, p.ldk, wave, kx);
+        load_tile(vbase, p.ldv, wave, vx);
+    }
+    for (int kt = wave; kt < nkt; kt += 4) {
+        stage_tile(kx);
+        if (kt + 4 < nkt) load_tile(kbase, p.ldk, kt + 4, kx);
         float s[2][4];
         scores(kt, s);
         float tmax = -INFINITY;
@@ -134,43 +191,83 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
         l_run = l_run * alpha + psum;
         m_run = m_new;
         const Frag<NS> pf = make_frag<NS>(pv);
+
+        stage_tile(vx);  // same image: this wave's K fragment reads were issued before these writes (in-order LDS)
+        if (kt + 4 < nkt) load_tile(vbase, p.ldv, kt + 4, vx);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float t[8];
-#pragma unroll
-            for (int jp = 0; jp < 8; ++jp) {
-                const int key = min(kt * 32 + (jp >> 2) * 16 + 4 * g + (jp & 3), p.Lk - 1);
-                t[jp] = vbase[(long)key * p.ldv + nt * 16 + i];
-            }
-            const Frag<NS> vf = make_frag<NS>(t);
+            Frag<NS> vf;
+            const int o0 = (4 * g + (i >> 2)) * LD + nt * 16 + 4 * (i & 3);
+            vf.v[0] = tr_read_pair(stage + o0, stage + o0 + 16 * LD);
+            if (NS == 2) vf.v[NS - 1] = tr_read_pair(stage + IMG + o0, stage + IMG + o0 + 16 * LD);
             o[nt] = o[nt] * alpha;
             o[nt] = mfma_split<NS>(vf, pf, o[nt]);
         }
     }
 
-    const float inv_l = 1.0f / l_run;
+    // merge the four waves' states
+    __syncthreads();  // every staging image is dead
+    float* mg = reinterpret_cast<float*>(smem);
+    {
+        float* mine = mg + wave * MERGE_FLOATS;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine[(nt * 4 + r) * 64 + lane] = o[nt][r];
+        mine[NT * 256 + lane] = m_run;
+        mine[NT * 256 + 64 + lane] = l_run;
+    }
+    __syncthreads();
+    float m_all = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) m_all = fmaxf(m_all, mg[w * MERGE_FLOATS + NT * 256 + lane]);
+    float sc[4], l_all = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        sc[w] = expf(mg[w * MERGE_FLOATS + NT * 256 + lane] - m_all);
+        l_all += mg[w * MERGE_FLOATS + NT * 256 + 64 + lane] * sc[w];
+    }
+    const float inv_l = 1.0f / l_all;
     if (qi < p.Lq) {
         float* op = p.ctx + ((long)b * p.Lq + qi) * p.ldo + h * DH + 4 * g;
+        for (int nt = wave; nt < NT; nt += 4) {
+            float r4[4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float4 r = make_float4(o[nt][0] * inv_l, o[nt][1] * inv_l, o[nt][2] * inv_l, o[nt][3] * inv_l);
-            *reinterpret_cast<float4*>(op + nt * 16) = r;
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) acc += mg[w * MERGE_FLOATS + (nt * 4 + r) * 64 + lane] * sc[w];
+                r4[r] = acc * inv_l;
+            }
+            *reinterpret_cast<float4*>(op + nt * 16) = make_float4(r4[0], r4[1], r4[2], r4[3]);
         }
     }
 
     if (p.attn) {
+        __syncthreads();  // merge buffer is dead; the staging images are reused
         float* ap = p.attn + (((long)b * p.H + h) * p.Lq + qrow) * p.Lk;
-        for (int kt = 0; kt < nkt; ++kt) {
+        const bool vec = (p.Lk & 3) == 0;
+        if (wave < nkt) load_tile(kbase, p.ldk, wave, kx);
+        for (int kt = wave; kt < nkt; kt += 4) {
+            stage_tile(kx);
+            if (kt + 4 < nkt) load_tile(kbase, p.ldk, kt + 4, kx);
             float s[2][4];
             scores(kt, s);
             if (qi < p.Lq) {
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int key0 = kt * 32 + sub * 16 + 4 * g;
+                    float w4[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int key = kt * 32 + sub * 16 + 4 * g + j;
-                        if (key < p.Lk) ap[key] = expf(s[sub][j] - m_run) * inv_l;
+                    for (int j = 0; j < 4; ++j) w4[j] = expf(s[sub][j] - m_all) * inv_l;
+                    if (vec && key0 + 3 < p.Lk) {
+                        *reinterpret_cast<float4*>(ap + key0) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (key0 + j < p.Lk) ap[key0 + j] = w4[j];
                     }
+                }
             }
         }
     }
@@ -178,7 +275,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
 
 template <int DH>
 int launch(const estts_attention_args& a, hipStream_t st) {
-    dim3 grid((a.Lq + 63) / 64, a.H, a.B);
+    dim3 grid((a.Lq + 15) / 16, a.H, a.B);
     if (a.precision == 3)
         hipLaunchKernelGGL((attention_kernel<DH, 2>), grid, dim3(256), 0, st, a);
     else
@@ -196,10 +293,12 @@ extern "C" int estts_attention(const estts_attention_args* args, void* stream) {
     ESTTS_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "estts_attention: bad shape");
     ESTTS_CHECK_ARG(a.B <= 65535 && a.H <= 65535, "estts_attention: B / H exceed grid limits");
     ESTTS_CHECK_ARG(a.precision == 1 || a.precision == 3, "estts_attention: precision must be 1 or 3");
-    ESTTS_CHECK_ARG((a.ldq & 3) == 0 && (a.ldk & 3) == 0 && (a.ldo & 3) == 0, "estts_attention: ld not multiple of 4");
+    ESTTS_CHECK_ARG((a.ldq & 3) == 0 && (a.ldk & 3) == 0 && (a.ldv & 3) == 0 && (a.ldo & 3) == 0,
+                    "estts_attention: ld not multiple of 4");
     ESTTS_CHECK_ARG(a.ldq >= a.H * a.depth && a.ldk >= a.H * a.depth && a.ldv >= a.H * a.depth && a.ldo >= a.H * a.depth,
                     "estts_attention: ld smaller than H*depth");
-    ESTTS_CHECK_ARG((((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.ctx) & 15) == 0, "estts_attention: q/k/ctx not 16-byte aligned");
+    ESTTS_CHECK_ARG((((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.ctx | (uintptr_t)a.attn) & 15) == 0,
+                    "estts_attention: q/k/v/ctx/attn not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     switch (a.depth) {
         case 32: return launch<32>(a, st);

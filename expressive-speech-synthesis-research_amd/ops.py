@@ -30,9 +30,10 @@ def stop_trace():
     return t
 
 
-def _record(kind, info, fn, args, *rest):
+def _record(kind, info, fn, *args):
+    """Remember a launch; the relaunch callable passes whatever stream is current when it is called."""
     if _trace is not None:
-        _trace.append((kind, info, lambda: fn(args, *rest)))
+        _trace.append((kind, info, lambda: fn(*args, _stream())))
 
 
 def _stream():
@@ -151,7 +152,7 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     nsplit = 2 if precision == 'bf16x3' else 1
     _record('gemm', {'M': M, 'N': lin.N, 'K': lin.K, 'taps': lin.taps, 'flops': 2.0 * M * lin.N * lin.K,
                      'bytes': 4.0 * M * lin.K / lin.taps + 2.0 * nsplit * lin.N * lin.K + 4.0 * M * lin.N},
-            _lib.load().estts_gemm, a, _stream())
+            _lib.load().estts_gemm, a)
     return out
 
 
@@ -176,7 +177,7 @@ def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, at
     _record('attention', {'B': B, 'H': H, 'Lq': Lq, 'Lk': Lk, 'depth': depth, 'weights': attn is not None,
                           'flops': 4.0 * B * H * Lq * Lk * depth,
                           'bytes': 4.0 * B * H * depth * (2 * Lq + 2 * Lk) + (4.0 * B * H * Lq * Lk if attn is not None else 0)},
-            _lib.load().estts_attention, a, _stream())
+            _lib.load().estts_attention, a)
     return ctx
 
 
@@ -203,7 +204,7 @@ def rownorm(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=N
     check(_lib.load().estts_rownorm(a, _stream()), 'estts_rownorm')
     _record('rownorm', {'M': a.M, 'D': a.D, 'flops': 0.0,
                         'bytes': 4.0 * a.M * a.D * (1 + (residual is not None) + (out is not None))},
-            _lib.load().estts_rownorm, a, _stream())
+            _lib.load().estts_rownorm, a)
     return out
 
 
@@ -218,6 +219,9 @@ def embed_posenc(tokens, emb, pe, pos_scalar, out, key_mask, scale, pe_stride=1)
     check(_lib.load().estts_embed_posenc(tokens.data_ptr(), emb.data_ptr(), pe.data_ptr(), _ptr(pos_scalar),
                                          out.data_ptr(), out.stride(0), _ptr(key_mask), B, N, D, scale, pe_stride,
                                          _stream()), 'estts_embed_posenc')
+    _record('embed_posenc', {'B': B, 'N': N, 'D': D, 'flops': 0.0, 'bytes': 12.0 * B * N * D},
+            _lib.load().estts_embed_posenc, tokens.data_ptr(), emb.data_ptr(), pe.data_ptr(), _ptr(pos_scalar),
+            out.data_ptr(), out.stride(0), _ptr(key_mask), B, N, D, scale, pe_stride)
     return out
 
 
@@ -226,11 +230,16 @@ def durations_cumsum(dur, cum, totals):
     B, N = dur.shape
     check(_lib.load().estts_durations_cumsum(dur.data_ptr(), cum.data_ptr(), totals.data_ptr(), B, N, _stream()),
           'estts_durations_cumsum')
+    _record('durations_cumsum', {'B': B, 'N': N, 'flops': 0.0, 'bytes': 8.0 * B * N},
+            _lib.load().estts_durations_cumsum, dur.data_ptr(), cum.data_ptr(), totals.data_ptr(), B, N)
 
 
 def expand(x, cum, out, frame_mask, B, N, T, D):
     check(_lib.load().estts_expand(x.data_ptr(), x.stride(0), cum.data_ptr(), out.data_ptr(), out.stride(0),
                                    _ptr(frame_mask), B, N, T, D, _stream()), 'estts_expand')
+    _record('expand', {'B': B, 'N': N, 'T': T, 'D': D, 'flops': 0.0, 'bytes': 8.0 * B * T * D},
+            _lib.load().estts_expand, x.data_ptr(), x.stride(0), cum.data_ptr(), out.data_ptr(), out.stride(0),
+            _ptr(frame_mask), B, N, T, D)
     return out
 
 
