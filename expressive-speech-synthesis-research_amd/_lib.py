@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -39,6 +39,19 @@ class RownormArgs(C.Structure):
                 ('dot_w', _vp), ('dot_b', _f32), ('dot_scale', _f32), ('dot_mask', _vp), ('dot_out', _vp)]
 
 
+class WavernnPrepArgs(C.Structure):
+    _fields_ = [('mel', _vp), ('mel_off', _vp), ('aux', _vp), ('aux_off', _vp), ('fir', _vp), ('ntaps', _i32),
+                ('fir_kmin', _i32), ('seq_utt', _vp), ('seq_start', _vp), ('utt_samples', _vp), ('x_prev', _vp),
+                ('step', _vp), ('xin', _vp), ('ld_xin', _i32), ('a2', _vp), ('ld_a2', _i32), ('a3', _vp), ('ld_a3', _i32),
+                ('a4', _vp), ('ld_a4', _i32), ('n_seq', _i32), ('feat', _i32), ('d', _i32), ('hop', _i32), ('pad', _i32)]
+
+
+class WavernnSampleArgs(C.Structure):
+    _fields_ = [('logits', _vp), ('ld_logits', _i32), ('n_classes', _i32), ('mode', _i32), ('u', _vp), ('u_mix', _vp),
+                ('forced', _vp), ('seed', C.c_uint32), ('wave', _vp), ('ld_wave', _i32), ('x_prev', _vp), ('step', _vp),
+                ('done', _vp), ('n_seq', _i32)]
+
+
 # symbol -> (restype, argtypes); every symbol declared in include/estts.h must be listed here
 SIGNATURES = {
     'estts_abi_version': (_i32, []),
@@ -49,6 +62,9 @@ SIGNATURES = {
     'estts_embed_posenc': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     'estts_durations_cumsum': (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     'estts_expand': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'estts_wavernn_prep': (_i32, [C.POINTER(WavernnPrepArgs), _vp]),
+    'estts_gru_gates': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    'estts_wavernn_sample': (_i32, [C.POINTER(WavernnSampleArgs), _vp]),
 }
 
 _lib = None

@@ -1,0 +1,215 @@
+// WaveRNN per-sample step kernels (see the estts_wavernn_* / estts_gru_gates entries of include/estts.h).
+// The dense layers of a step run through estts_gemm; these kernels are the HBM/latency-bound glue around
+// them: conditioning assembly (upsampling filter applied on the fly), GRU gate math, sampling.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// one 256-thread workgroup per sequence: thread c < 1 + feat + d fills xin, the next 3 d threads the aux slices
+__global__ __launch_bounds__(256) void wavernn_prep_kernel(const estts_wavernn_prep_args p) {
+    const int b = blockIdx.x;
+    const int c = threadIdx.x;
+    const int step = p.step[0];
+    const int u = p.seq_utt[b];
+    const int s = p.seq_start[b] + step;
+    const bool live = s < p.utt_samples[u];
+    const int frame = s / p.hop;
+    const int phase = s - frame * p.hop;
+    const int n_in = 1 + p.feat + p.d;
+    for (int col = c; col < n_in + 3 * p.d; col += 256) {
+        float v = 0.0f;
+        if (col == 0) {
+            v = p.x_prev[b];
+        } else if (live) {
+            if (col <= p.feat) {
+                const float* m = p.mel + (long)(p.mel_off[u] + frame + p.pad - p.fir_kmin) * p.feat + (col - 1);
+                const float* f = p.fir + phase * p.ntaps;
+                for (int j = 0; j < p.ntaps; ++j) v += f[j] * m[-(long)j * p.feat];
+            } else {
+                v = p.aux[(long)(p.aux_off[u] + frame) * (4 * p.d) + (col - 1 - p.feat)];
+            }
+        }
+        if (col < n_in) {
+            p.xin[(long)b * p.ld_xin + col] = v;
+        } else {
+            const int k = col - n_in;  // 0 .. 3d-1 -> slices a2, a3, a4
+            const int which = k / p.d;
+            const int e = k - which * p.d;
+            float* dst = which == 0 ? p.a2 + (long)b * p.ld_a2 : (which == 1 ? p.a3 + (long)b * p.ld_a3 : p.a4 + (long)b * p.ld_a4);
+            dst[e] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gru_gates_kernel(const float* gi, int ldgi, const float* gh, int ldgh, float* h,
+                                                        int ldh, const float* x_res, int ldx, float* out, int ldo, int M,
+                                                        int H) {
+    const int hq = H >> 2;
+    const long total = (long)M * hq;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / hq);
+        const int c = (int)(idx - (long)m * hq) * 4;
+        const float* gim = gi + (long)m * ldgi + c;
+        const float* ghm = gh + (long)m * ldgh + c;
+        const float4 ir = *reinterpret_cast<const float4*>(gim);
+        const float4 iz = *reinterpret_cast<const float4*>(gim + H);
+        const float4 in = *reinterpret_cast<const float4*>(gim + 2 * H);
+        const float4 hr = *reinterpret_cast<const float4*>(ghm);
+        const float4 hz = *reinterpret_cast<const float4*>(ghm + H);
+        const float4 hn = *reinterpret_cast<const float4*>(ghm + 2 * H);
+        float4 hv = *reinterpret_cast<const float4*>(h + (long)m * ldh + c);
+        float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x_res) xr = *reinterpret_cast<const float4*>(x_res + (long)m * ldx + c);
+        auto cell = [](float ir_, float iz_, float in_, float hr_, float hz_, float hn_, float h_) {
+            const float r = sigmoidf_(ir_ + hr_);
+            const float z = sigmoidf_(iz_ + hz_);
+            const float n = tanhf(in_ + r * hn_);
+            return (1.0f - z) * n + z * h_;
+        };
+        hv.x = cell(ir.x, iz.x, in.x, hr.x, hz.x, hn.x, hv.x);
+        hv.y = cell(ir.y, iz.y, in.y, hr.y, hz.y, hn.y, hv.y);
+        hv.z = cell(ir.z, iz.z, in.z, hr.z, hz.z, hn.z, hv.z);
+        hv.w = cell(ir.w, iz.w, in.w, hr.w, hz.w, hn.w, hv.w);
+        *reinterpret_cast<float4*>(h + (long)m * ldh + c) = hv;
+        *reinterpret_cast<float4*>(out + (long)m * ldo + c) = make_float4(xr.x + hv.x, xr.y + hv.y, xr.z + hv.z, xr.w + hv.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// counter-based uniform in (0, 1): 32-bit finaliser of (seed, step, sequence, stream)
+__device__ __forceinline__ float uniform01(uint32_t seed, uint32_t step, uint32_t seq, uint32_t stream) {
+    uint32_t x = seed ^ (step * 0x9E3779B9u) ^ (seq * 0x85EBCA6Bu) ^ (stream * 0xC2B2AE35u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    x += step * 0x27D4EB2Fu + seq;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// one wave per sequence, four sequences per workgroup
+__global__ __launch_bounds__(256) void wavernn_sample_kernel(const estts_wavernn_sample_args p) {
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int step = p.step[0];
+    if (b < p.n_seq) {
+        const float* lg = p.logits + (long)b * p.ld_logits;
+        float value;
+        if (p.mode == 0) {
+            // lane owns classes [lane * per, lane * per + per)
+            const int per = (p.n_classes + 63) / 64;
+            const int c0 = lane * per;
+            float mx = -INFINITY;
+            for (int k = 0; k < per; ++k)
+                if (c0 + k < p.n_classes) mx = fmaxf(mx, lg[c0 + k]);
+            mx = wave_max(mx);
+            float mine = 0.0f;
+            for (int k = 0; k < per; ++k)
+                if (c0 + k < p.n_classes) mine += expf(lg[c0 + k] - mx);
+            const float total = wave_sum(mine);
+            float incl = mine;  // inclusive prefix over lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            const float u = (p.u ? p.u[(long)step * p.n_seq + b] : uniform01(p.seed, step, b, 0)) * total;
+            float run = incl - mine;
+            int cnt = 0;
+            for (int k = 0; k < per; ++k)
+                if (c0 + k < p.n_classes) {
+                    run += expf(lg[c0 + k] - mx);
+                    cnt += (run <= u) ? 1 : 0;
+                }
+            cnt = (int)wave_sum((float)cnt);
+            cnt = min(cnt, p.n_classes - 1);
+            value = 2.0f * (float)cnt / ((float)p.n_classes - 1.0f) - 1.0f;
+        } else {
+            const int nr = p.n_classes / 3;
+            float best = -INFINITY;
+            int arg = 0;
+            if (lane < nr) {
+                float um = p.u_mix ? p.u_mix[((long)step * p.n_seq + b) * nr + lane] : uniform01(p.seed, step, b, 1 + lane);
+                um = fminf(fmaxf(um, 1e-5f), 1.0f - 1e-5f);
+                best = lg[lane] - logf(-logf(um));
+                arg = lane;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {  // arg-max, lowest index wins ties (as torch.max)
+                const float ob = __shfl_xor(best, o, 64);
+                const int oa = __shfl_xor(arg, o, 64);
+                if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+            }
+            const float mean = lg[nr + arg];
+            const float log_scale = fmaxf(lg[2 * nr + arg], -32.23619130191664f);  // log(1e-14)
+            float ul = p.u ? p.u[(long)step * p.n_seq + b] : uniform01(p.seed, step, b, 0);
+            ul = fminf(fmaxf(ul, 1e-5f), 1.0f - 1e-5f);
+            value = mean + expf(log_scale) * (logf(ul) - logf(1.0f - ul));
+            value = fminf(fmaxf(value, -1.0f), 1.0f);
+        }
+        if (lane == 0) {
+            p.wave[(long)b * p.ld_wave + step] = value;
+            p.x_prev[b] = p.forced ? p.forced[(long)step * p.n_seq + b] : value;
+        }
+    }
+    // the last workgroup to finish has seen every workgroup read step[0]; it advances the counter
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(p.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (int)gridDim.x - 1);
+        if (s_last) {
+            __hip_atomic_store(p.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.step, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int estts_wavernn_prep(const estts_wavernn_prep_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_wavernn_prep: null args");
+    const estts_wavernn_prep_args& a = *args;
+    ESTTS_CHECK_ARG(a.mel && a.mel_off && a.aux && a.aux_off && a.fir && a.seq_utt && a.seq_start && a.utt_samples &&
+                    a.x_prev && a.step && a.xin && a.a2 && a.a3 && a.a4, "estts_wavernn_prep: null pointer");
+    ESTTS_CHECK_ARG(a.n_seq > 0 && a.feat > 0 && a.d > 0 && a.hop > 0 && a.pad >= 0 && a.ntaps > 0,
+                    "estts_wavernn_prep: bad sizes");
+    ESTTS_CHECK_ARG(a.ld_xin >= 1 + a.feat + a.d && a.ld_a2 >= a.d && a.ld_a3 >= a.d && a.ld_a4 >= a.d,
+                    "estts_wavernn_prep: leading dimension too small");
+    ESTTS_CHECK_ARG(a.pad - a.fir_kmin - (a.ntaps - 1) >= 0 && a.pad + a.fir_kmin >= 0,
+                    "estts_wavernn_prep: filter reaches outside the padded mel");
+    hipLaunchKernelGGL(wavernn_prep_kernel, dim3(a.n_seq), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_CHECK_LAUNCH("estts_wavernn_prep");
+    return 0;
+}
+
+extern "C" int estts_gru_gates(const float* gi, int32_t ldgi, const float* gh, int32_t ldgh, float* h, int32_t ldh,
+                               const float* x_res, int32_t ldx, float* out, int32_t ldo, int32_t M, int32_t H,
+                               void* stream) {
+    ESTTS_CHECK_ARG(gi && gh && h && out, "estts_gru_gates: null pointer");
+    ESTTS_CHECK_ARG(M > 0 && H > 0 && (H & 3) == 0, "estts_gru_gates: H must be a positive multiple of 4");
+    ESTTS_CHECK_ARG(ldgi >= 3 * H && ldgh >= 3 * H && ldh >= H && ldo >= H && (!x_res || ldx >= H), "estts_gru_gates: ld too small");
+    ESTTS_CHECK_ARG(((ldgi | ldgh | ldh | ldo | (x_res ? ldx : 0)) & 3) == 0, "estts_gru_gates: ld not multiple of 4");
+    const long total = (long)M * (H >> 2);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gru_gates_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gi, ldgi, gh, ldgh, h, ldh, x_res,
+                       ldx, out, ldo, M, H);
+    ESTTS_CHECK_LAUNCH("estts_gru_gates");
+    return 0;
+}
+
+extern "C" int estts_wavernn_sample(const estts_wavernn_sample_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_wavernn_sample: null args");
+    const estts_wavernn_sample_args& a = *args;
+    ESTTS_CHECK_ARG(a.logits && a.wave && a.x_prev && a.step && a.done, "estts_wavernn_sample: null pointer");
+    ESTTS_CHECK_ARG(a.n_seq > 0 && a.n_classes > 0 && a.ld_logits >= a.n_classes, "estts_wavernn_sample: bad sizes");
+    ESTTS_CHECK_ARG(a.mode == 0 || (a.mode == 1 && a.n_classes % 3 == 0 && a.n_classes / 3 <= 64),
+                    "estts_wavernn_sample: mode must be 0 (RAW) or 1 (MOL with <= 64 components)");
+    ESTTS_CHECK_ARG(a.mode == 1 || a.n_classes <= 65536, "estts_wavernn_sample: too many classes");
+    ESTTS_CHECK_ARG(a.mode == 0 || !a.u_mix == !a.u, "estts_wavernn_sample: MOL needs both u and u_mix or neither");
+    hipLaunchKernelGGL(wavernn_sample_kernel, dim3((a.n_seq + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_CHECK_LAUNCH("estts_wavernn_sample");
+    return 0;
+}

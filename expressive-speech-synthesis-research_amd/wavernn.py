@@ -1,0 +1,461 @@
+"""WaveRNN vocoder on MI355X.
+
+Mirrors the surface of the reference class (WaveRNN/models/fatchord_version.py:89-415): constructor
+arguments, state_dict key names (so existing `.pyt` checkpoints load), `forward`, `generate`,
+`restore / load / save / checkpoint / get_step`.  Differences that the hardware path needs:
+`generate` also accepts several utterances at once (`generate_batch`), takes an explicit `seed` (the
+reference uses torch's global RNG) and optional injected uniform numbers / forced samples for replaying a
+recorded trajectory.  All arithmetic on the device runs in libestts.so kernels; the cross-fade, mu-law
+expansion and fade-out run on the host in float64 NumPy exactly as the reference does
+(fatchord_version.py:222-237).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import WavernnPrepArgs, WavernnSampleArgs, check
+from .ops import PackedLinear
+
+
+def composite_upsample_filter(up_weights, scales):
+    """Collapse the reference's [repeat x s, Conv2d(1, 1, (1, 2 s + 1))] x 3 chain (fatchord_version.py:70-85) into
+    one periodic FIR over mel frames:  up[s] = sum_j fir[s % hop, j] * mel_padded[s // hop + pad - (kmin + j)].
+
+    Away from the sequence ends (which the reference trims by `indent`) the chain is linear and invariant to shifts
+    by whole frames, so its response to a unit impulse at one frame determines it.  Returns (fir [hop, ntaps], kmin).
+    """
+    hop = int(np.prod(scales))
+    c = 6                                     # impulse frame; margin of 6 frames on both sides
+    x = np.zeros(2 * c + 1, dtype=np.float64)
+    x[c] = 1.0
+    for s, k in zip(scales, up_weights):
+        k = np.asarray(k, dtype=np.float64).reshape(-1)
+        x = np.repeat(x, s)
+        xp = np.pad(x, (s, s))
+        x = sum(k[t] * xp[t:t + x.shape[0]] for t in range(2 * s + 1))
+    # R[delta] = response at output index c*hop + delta
+    nz = np.nonzero(np.abs(x) > 0)[0]
+    lo, hi = int(nz.min()) - c * hop, int(nz.max()) - c * hop
+    kmin = math.ceil((lo - hop + 1) / hop)
+    kmax = math.floor(hi / hop)
+    ntaps = kmax - kmin + 1
+    fir = np.zeros((hop, ntaps), dtype=np.float64)
+    for phase in range(hop):
+        for j in range(ntaps):
+            d = phase + (kmin + j) * hop
+            idx = c * hop + d
+            if 0 <= idx < x.shape[0]:
+                fir[phase, j] = x[idx]
+    return fir.astype(np.float32), kmin
+
+
+def fold_starts(total_len, target, overlap):
+    """Start offsets of the folds fold_with_overlap (fatchord_version.py:298-317) produces for `total_len` samples."""
+    num_folds = (total_len - overlap) // (target + overlap)
+    extended_len = num_folds * (overlap + target) + overlap
+    if total_len - extended_len != 0:
+        num_folds += 1
+    return [i * (target + overlap) for i in range(num_folds)]
+
+
+def xfade_and_unfold(y, target, overlap):
+    """fatchord_version.py:321-383 (host, float64)."""
+    y = np.array(y, dtype=np.float64)
+    num_folds, length = y.shape
+    target = length - 2 * overlap
+    total_len = num_folds * (target + overlap) + overlap
+    silence_len = overlap // 2
+    fade_len = overlap - silence_len
+    t = np.linspace(-1, 1, fade_len, dtype=np.float64)
+    fade_in = np.concatenate([np.zeros(silence_len), np.sqrt(0.5 * (1 + t))])
+    fade_out = np.concatenate([np.sqrt(0.5 * (1 - t)), np.zeros(silence_len)])
+    y[:, :overlap] *= fade_in
+    y[:, -overlap:] *= fade_out
+    unfolded = np.zeros(total_len, dtype=np.float64)
+    for i in range(num_folds):
+        start = i * (target + overlap)
+        unfolded[start:start + target + 2 * overlap] += y[i]
+    return unfolded
+
+
+def decode_mu_law(y, mu, from_labels=True):
+    """WaveRNN/utility/dsp.py:100-105."""
+    if from_labels:
+        y = 2 * y / (2 ** math.log2(mu) - 1.) - 1.
+    mu = mu - 1
+    return np.sign(y) / mu * ((1 + mu) ** np.abs(y) - 1)
+
+
+def _fold_bn(w, p, eps=1e-5):
+    s = np.asarray(w[p + '.weight'], np.float64) / np.sqrt(np.asarray(w[p + '.running_var'], np.float64) + eps)
+    b = np.asarray(w[p + '.bias'], np.float64) - np.asarray(w[p + '.running_mean'], np.float64) * s
+    return s.astype(np.float32), b.astype(np.float32)
+
+
+class WaveRNN:
+    def __init__(self, rnn_dims, fc_dims, bits, pad, upsample_factors, feat_dims, compute_dims, res_out_dims, res_blocks,
+                 hop_length, sample_rate, mode='RAW', device='cuda', precision='bf16x3'):
+        if mode == 'RAW':
+            self.n_classes = 2 ** bits
+        elif mode == 'MOL':
+            self.n_classes = 30
+        else:
+            raise RuntimeError(f'Unknown model mode value - {mode}')
+        if int(np.prod(upsample_factors)) != hop_length:
+            raise ValueError('upsample_factors must multiply to hop_length')
+        if not torch.cuda.is_available():
+            raise RuntimeError('WaveRNN needs a GPU: the hot path has no CPU implementation')
+        _lib.load()
+        self.mode, self.pad = mode, pad
+        self.rnn_dims, self.fc_dims = rnn_dims, fc_dims
+        self.aux_dims = res_out_dims // 4
+        self.feat_dims, self.compute_dims, self.res_out_dims, self.res_blocks = feat_dims, compute_dims, res_out_dims, res_blocks
+        self.upsample_factors = tuple(upsample_factors)
+        self.hop_length, self.sample_rate = hop_length, sample_rate
+        self.device = torch.device(device)
+        self.precision = precision
+        self.step = 0
+        self._sd = None
+        self.steps_per_graph = 50
+        ops.gemm_workspace(self.device)
+
+    @classmethod
+    def from_hparams(cls, hp, **kw):
+        return cls(rnn_dims=hp['voc_rnn_dims'], fc_dims=hp['voc_fc_dims'], bits=hp['bits'], pad=hp['voc_pad'],
+                   upsample_factors=hp['voc_upsample_factors'], feat_dims=hp['num_mels'],
+                   compute_dims=hp['voc_compute_dims'], res_out_dims=hp['voc_res_out_dims'],
+                   res_blocks=hp['voc_res_blocks'], hop_length=hp['hop_length'], sample_rate=hp['sample_rate'],
+                   mode=hp['voc_mode'], **kw)
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, strict=False):
+        w = {}
+        for k, v in sd.items():
+            w[k] = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        if 'step' in w:
+            self.step = int(np.asarray(w['step']).reshape(-1)[0])
+        dev = self.device
+        p = 'upsample.resnet'
+        s, b = _fold_bn(w, p + '.batch_norm')
+        wi = np.asarray(w[p + '.conv_in.weight'])                          # (C, feat, k)
+        k = wi.shape[2]
+        if k != 2 * self.pad + 1:
+            raise ValueError('conv_in kernel size does not match pad')
+        self.conv_in = PackedLinear(wi.transpose(0, 2, 1).reshape(wi.shape[0], -1), bias=b, scale=s, device=dev, taps=k,
+                                    lpad=0, act='relu')
+        self.res = []
+        for i in range(self.res_blocks):
+            q = f'{p}.layers.{i}'
+            s1, b1 = _fold_bn(w, q + '.batch_norm1')
+            s2, b2 = _fold_bn(w, q + '.batch_norm2')
+            self.res.append((PackedLinear(np.asarray(w[q + '.conv1.weight'])[:, :, 0], bias=b1, scale=s1, device=dev, act='relu'),
+                             PackedLinear(np.asarray(w[q + '.conv2.weight'])[:, :, 0], bias=b2, scale=s2, device=dev)))
+        self.conv_out = PackedLinear(np.asarray(w[p + '.conv_out.weight'])[:, :, 0], bias=w[p + '.conv_out.bias'], device=dev)
+        ups = [w[f'upsample.up_layers.{2 * j + 1}.weight'] for j in range(len(self.upsample_factors))]
+        fir, kmin = composite_upsample_filter(ups, self.upsample_factors)
+        if self.pad - kmin - (fir.shape[1] - 1) < 0 or self.pad + kmin < 0:
+            raise ValueError('pad is too small for the upsampling filters')
+        self.fir = torch.from_numpy(fir).to(dev)
+        self.fir_kmin = kmin
+        n_in = 1 + self.feat_dims + self.aux_dims
+        self.k_in = (n_in + 3) // 4 * 4
+        wI = np.zeros((self.rnn_dims, self.k_in), np.float32)
+        wI[:, :n_in] = w['I.weight']
+        self.I = PackedLinear(wI, bias=w['I.bias'], device=dev)
+        self.ih1 = PackedLinear(w['rnn1.weight_ih_l0'], bias=w['rnn1.bias_ih_l0'], device=dev)
+        self.hh1 = PackedLinear(w['rnn1.weight_hh_l0'], bias=w['rnn1.bias_hh_l0'], device=dev)
+        self.ih2 = PackedLinear(w['rnn2.weight_ih_l0'], bias=w['rnn2.bias_ih_l0'], device=dev)
+        self.hh2 = PackedLinear(w['rnn2.weight_hh_l0'], bias=w['rnn2.bias_hh_l0'], device=dev)
+        self.fc1 = PackedLinear(w['fc1.weight'], bias=w['fc1.bias'], device=dev, act='relu')
+        self.fc2 = PackedLinear(w['fc2.weight'], bias=w['fc2.bias'], device=dev, act='relu')
+        self.fc3 = PackedLinear(w['fc3.weight'], bias=w['fc3.bias'], device=dev)
+        if self.fc3.N != self.n_classes:
+            raise ValueError(f'fc3 has {self.fc3.N} outputs, mode {self.mode} expects {self.n_classes}')
+        self._sd = {k: np.array(v) for k, v in w.items()}
+        return self
+
+    def state_dict(self):
+        sd = {k: torch.from_numpy(np.array(v)) for k, v in self._sd.items()}
+        sd['step'] = torch.tensor([self.step], dtype=torch.long)
+        return sd
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location='cpu', weights_only=True), strict=False)
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def restore(self, path):
+        if not os.path.exists(path):
+            print('\nNew WaveRNN Training Session...\n')
+            self.save(path)
+        else:
+            print(f'\nLoading Weights: "{path}"\n')
+            self.load(path)
+
+    def checkpoint(self, path):
+        self.save(f'{path}/checkpoint_{self.get_step() // 1000}k_steps.pyt')
+
+    def get_step(self):
+        return self.step
+
+    def num_params(self, print_out=True):
+        n = sum(v.size for k, v in self._sd.items() if 'running' not in k and k != 'step' and 'num_batches' not in k) / 1e6
+        if print_out:
+            print('Trainable Parameters: %.3fM' % n)
+        return n
+
+    # ------------------------------------------------------------------ conditioning network
+    def _aux_frames(self, mel_padded):
+        """mel_padded: [T + 2 pad, feat] float32 device tensor -> MelResNet output [T, res_out] (fatchord_version.py:39-45)."""
+        Tp = mel_padded.shape[0]
+        T = Tp - 2 * self.pad
+        f32 = dict(dtype=torch.float32, device=self.device)
+        x = torch.empty(Tp, self.compute_dims, **f32)
+        h = torch.empty(Tp, self.compute_dims, **f32)
+        y = torch.empty(Tp, self.compute_dims, **f32)
+        ops.gemm(mel_padded, self.conv_in, x, seg_len=Tp, precision=self.precision)   # rows >= T are partial sums, unused
+        for c1, c2 in self.res:
+            ops.gemm(x, c1, h, precision=self.precision)
+            ops.gemm(h, c2, y, residual=x, precision=self.precision)
+            x, y = y, x
+        out = torch.empty(Tp, self.res_out_dims, **f32)
+        ops.gemm(x, self.conv_out, out, precision=self.precision)
+        return out[:T]
+
+    def _prepare(self, mel_list):
+        """mel_list: list of [feat, T] arrays/tensors (values as the reference expects).  Returns the packed padded mel
+        frames, aux frames and per-utterance offsets on the device."""
+        mels_p, auxs, mel_off, aux_off, frames = [], [], [], [], []
+        mo = ao = 0
+        for m in mel_list:
+            m = torch.as_tensor(m, dtype=torch.float32)
+            if m.dim() != 2 or m.shape[0] != self.feat_dims:
+                raise ValueError(f'each mel must be [feat={self.feat_dims}, T], got {tuple(m.shape)}')
+            T = m.shape[1]
+            mp = torch.zeros(T + 2 * self.pad, self.feat_dims, dtype=torch.float32)
+            mp[self.pad:self.pad + T] = m.t()
+            mp = mp.to(self.device)
+            mels_p.append(mp)
+            auxs.append(self._aux_frames(mp))
+            mel_off.append(mo)
+            aux_off.append(ao)
+            frames.append(T)
+            mo += T + 2 * self.pad
+            ao += T
+        i32 = dict(dtype=torch.int32, device=self.device)
+        return {'mel': torch.cat(mels_p).contiguous(), 'aux': torch.cat(auxs).contiguous(),
+                'mel_off': torch.tensor(mel_off, **i32), 'aux_off': torch.tensor(aux_off, **i32), 'frames': frames,
+                'utt_samples': torch.tensor([t * self.hop_length for t in frames], **i32)}
+
+    # ------------------------------------------------------------------ step machinery
+    def _alloc_state(self, n_seq, L):
+        f32 = dict(dtype=torch.float32, device=self.device)
+        R, d = self.rnn_dims, self.aux_dims
+        return {'xin': torch.zeros(n_seq, self.k_in, **f32), 'xI': torch.empty(n_seq, R, **f32),
+                'gi': torch.empty(n_seq, 3 * R, **f32), 'gh': torch.empty(n_seq, 3 * R, **f32),
+                'h1': torch.zeros(n_seq, R, **f32), 'h2': torch.zeros(n_seq, R, **f32),
+                'x1cat': torch.zeros(n_seq, R + d, **f32), 'x2cat': torch.zeros(n_seq, R + d, **f32),
+                'f1cat': torch.zeros(n_seq, self.fc_dims + d, **f32), 'f2': torch.empty(n_seq, self.fc_dims, **f32),
+                'logits': torch.empty(n_seq, self.n_classes, **f32), 'x_prev': torch.zeros(n_seq, **f32),
+                'wave': torch.zeros(n_seq, L, **f32), 'step': torch.zeros(1, dtype=torch.int32, device=self.device),
+                'done': torch.zeros(1, dtype=torch.int32, device=self.device)}
+
+    def _prep_args(self, cond, st, seq_utt, seq_start, n_seq):
+        a = WavernnPrepArgs()
+        a.mel, a.mel_off, a.aux, a.aux_off = cond['mel'].data_ptr(), cond['mel_off'].data_ptr(), cond['aux'].data_ptr(), cond['aux_off'].data_ptr()
+        a.fir, a.ntaps, a.fir_kmin = self.fir.data_ptr(), self.fir.shape[1], self.fir_kmin
+        a.seq_utt, a.seq_start, a.utt_samples = seq_utt.data_ptr(), seq_start.data_ptr(), cond['utt_samples'].data_ptr()
+        a.x_prev, a.step = st['x_prev'].data_ptr(), st['step'].data_ptr()
+        a.xin, a.ld_xin = st['xin'].data_ptr(), st['xin'].stride(0)
+        R, F = self.rnn_dims, self.fc_dims
+        a.a2, a.ld_a2 = st['x1cat'][:, R:].data_ptr(), st['x1cat'].stride(0)
+        a.a3, a.ld_a3 = st['x2cat'][:, R:].data_ptr(), st['x2cat'].stride(0)
+        a.a4, a.ld_a4 = st['f1cat'][:, F:].data_ptr(), st['f1cat'].stride(0)
+        a.n_seq, a.feat, a.d, a.hop, a.pad = n_seq, self.feat_dims, self.aux_dims, self.hop_length, self.pad
+        return a
+
+    def _sample_args(self, st, n_seq, seed, u, u_mix, forced, logits=None):
+        a = WavernnSampleArgs()
+        lg = st['logits'] if logits is None else logits
+        a.logits, a.ld_logits, a.n_classes = lg.data_ptr(), lg.stride(0), self.n_classes
+        a.mode = 0 if self.mode == 'RAW' else 1
+        a.u, a.u_mix, a.forced = ops._ptr(u), ops._ptr(u_mix), ops._ptr(forced)
+        a.seed = seed & 0xFFFFFFFF
+        a.wave, a.ld_wave, a.x_prev = st['wave'].data_ptr(), st['wave'].stride(0), st['x_prev'].data_ptr()
+        a.step, a.done, a.n_seq = st['step'].data_ptr(), st['done'].data_ptr(), n_seq
+        return a
+
+    def _one_step(self, st, prep_args, sample_args, logits_out=None):
+        """fatchord_version.py:180-216 for every sequence at once."""
+        lib, stream, R, F, pr = _lib.load(), ops._stream(), self.rnn_dims, self.fc_dims, self.precision
+        check(lib.estts_wavernn_prep(prep_args, stream), 'estts_wavernn_prep')
+        ops.gemm(st['xin'], self.I, st['xI'], precision=pr)
+        ops.gemm(st['xI'], self.ih1, st['gi'], precision=pr)
+        ops.gemm(st['h1'], self.hh1, st['gh'], precision=pr)
+        self._gates(st['gi'], st['gh'], st['h1'], st['xI'], st['x1cat'][:, :R])
+        ops.gemm(st['x1cat'], self.ih2, st['gi'], precision=pr)
+        ops.gemm(st['h2'], self.hh2, st['gh'], precision=pr)
+        self._gates(st['gi'], st['gh'], st['h2'], st['x1cat'][:, :R], st['x2cat'][:, :R])
+        ops.gemm(st['x2cat'], self.fc1, st['f1cat'][:, :F], precision=pr)
+        ops.gemm(st['f1cat'], self.fc2, st['f2'], precision=pr)
+        ops.gemm(st['f2'], self.fc3, st['logits'] if logits_out is None else logits_out, precision=pr)
+        check(lib.estts_wavernn_sample(sample_args, stream), 'estts_wavernn_sample')
+
+    def _gates(self, gi, gh, h, x_res, out):
+        M, H = h.shape
+        check(_lib.load().estts_gru_gates(gi.data_ptr(), gi.stride(0), gh.data_ptr(), gh.stride(0), h.data_ptr(), h.stride(0),
+                                          x_res.data_ptr(), x_res.stride(0), out.data_ptr(), out.stride(0), M, H,
+                                          ops._stream()), 'estts_gru_gates')
+
+    def _run_steps(self, st, prep_args, sample_args, L, use_graph):
+        n = self.steps_per_graph
+        done = 0
+        if use_graph and L >= 2 * n:
+            self._one_step(st, prep_args, sample_args)          # warm-up outside capture (also step 0)
+            done = 1
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(n):
+                    self._one_step(st, prep_args, sample_args)
+            # capture does not execute: the step counter still says `done`
+            while L - done >= n:
+                g.replay()
+                done += n
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        for _ in range(L - done):
+            self._one_step(st, prep_args, sample_args)
+
+    # ------------------------------------------------------------------ reference surface
+    def generate_batch(self, mel_list, batched=True, target=11_000, overlap=550, mu_law=True, seed=0, uniforms=None,
+                       forced=None, use_graph=True, return_trace=False):
+        """Vocode several utterances at once: every fold of every utterance is one sequence of the step kernels.
+
+        mel_list: list of [feat, T] mels in the reference's [0, 1] normalisation.  Returns a list of float64 waveforms
+        (as WaveRNN.generate, fatchord_version.py:150-243).  uniforms: optional injected uniform numbers, RAW: [L, n_seq];
+        MOL: {'mix': [L, n_seq, nr_mix], 'logistic': [L, n_seq]}.  forced: optional [L, n_seq] sample values fed back
+        instead of the drawn ones.  With return_trace also returns the raw per-sequence samples [n_seq, L]."""
+        mu_law = mu_law if self.mode == 'RAW' else False
+        cond = self._prepare(mel_list)
+        hop = self.hop_length
+        seq_utt, seq_start, folds = [], [], []
+        for ui, T in enumerate(cond['frames']):
+            starts = fold_starts(T * hop, target, overlap) if batched else [0]
+            folds.append(len(starts))
+            seq_utt += [ui] * len(starts)
+            seq_start += starts
+        n_seq = len(seq_utt)
+        L = target + 2 * overlap if batched else max(cond['frames']) * hop
+        i32 = dict(dtype=torch.int32, device=self.device)
+        seq_utt_d, seq_start_d = torch.tensor(seq_utt, **i32), torch.tensor(seq_start, **i32)
+        st = self._alloc_state(n_seq, L)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        u = u_mix = None
+        if uniforms is not None:
+            if self.mode == 'RAW':
+                u = torch.as_tensor(np.asarray(uniforms), **f32).contiguous()
+            else:
+                u = torch.as_tensor(np.asarray(uniforms['logistic']), **f32).contiguous()
+                u_mix = torch.as_tensor(np.asarray(uniforms['mix']), **f32).contiguous()
+            if u.shape != (L, n_seq):
+                raise ValueError(f'uniforms must have shape {(L, n_seq)}, got {tuple(u.shape)}')
+        forced_d = None if forced is None else torch.as_tensor(np.asarray(forced), **f32).contiguous()
+        prep_args = self._prep_args(cond, st, seq_utt_d, seq_start_d, n_seq)
+        sample_args = self._sample_args(st, n_seq, seed, u, u_mix, forced_d)
+        self._run_steps(st, prep_args, sample_args, L, use_graph)
+        raw = st['wave'].cpu().numpy().astype(np.float64)
+        outs, o = [], 0
+        for ui, T in enumerate(cond['frames']):
+            y = raw[o:o + folds[ui]]
+            o += folds[ui]
+            y = xfade_and_unfold(y, target, overlap) if batched else y[0]
+            if mu_law:
+                y = decode_mu_law(y, self.n_classes, False)
+            wave_len = (T - 1) * hop
+            y = y[:wave_len]
+            y[-20 * hop:] *= np.linspace(1, 0, 20 * hop)
+            outs.append(y)
+        if return_trace:
+            return outs, raw
+        return outs
+
+    def generate(self, mels, batched, target, overlap, mu_law, **kw):
+        """fatchord_version.py:150.  mels: [1, feat, T]."""
+        mels = torch.as_tensor(mels)
+        if mels.dim() != 3 or mels.shape[0] != 1:
+            raise ValueError('generate expects mels of shape [1, feat, T]; use generate_batch for several utterances')
+        out = self.generate_batch([mels[0]], batched, target, overlap, mu_law, **kw)
+        return out if kw.get('return_trace') else out[0]
+
+    def forward(self, x, mels):
+        """Teacher-forced logits, fatchord_version.py:119-148.  x: [B, L] float32 in [-1, 1]; mels: [B, feat, L / hop + 2 pad]
+        (already padded, as the training collate produces them).  Returns [B, L, n_classes] on the device."""
+        x = torch.as_tensor(x, dtype=torch.float32)
+        mels = torch.as_tensor(mels, dtype=torch.float32)
+        B, L = x.shape
+        T = mels.shape[2] - 2 * self.pad
+        if T * self.hop_length < L:
+            raise ValueError('mels are too short for x')
+        # the mels are padded already: feed the inner frames and let _prepare re-create the same padding values
+        cond = self._prepare_padded(mels)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        seq_utt, seq_start = torch.arange(B, **i32), torch.zeros(B, **i32)
+        st = self._alloc_state(B, L)
+        xd = x.to(self.device)
+        st['x_prev'].copy_(xd[:, 0])
+        forced = torch.zeros(L, B, dtype=torch.float32, device=self.device)
+        forced[:L - 1] = xd[:, 1:].t()
+        logits = torch.empty(L, B, self.n_classes, dtype=torch.float32, device=self.device)
+        prep_args = self._prep_args(cond, st, seq_utt, seq_start, B)
+        for t in range(L):
+            sample_args = self._sample_args(st, B, 0, None, None, forced, logits=logits[t])
+            self._one_step(st, prep_args, sample_args, logits_out=logits[t])
+        self.step += 1
+        return logits.permute(1, 0, 2)
+
+    __call__ = forward
+
+    def _prepare_padded(self, mels):
+        """mels [B, feat, T + 2 pad] whose edge frames are real context (training windows), not zero padding."""
+        mels_p, auxs, mel_off, aux_off, frames = [], [], [], [], []
+        mo = ao = 0
+        for m in mels:
+            mp = m.t().contiguous().to(self.device)
+            T = mp.shape[0] - 2 * self.pad
+            mels_p.append(mp)
+            auxs.append(self._aux_frames(mp))
+            mel_off.append(mo)
+            aux_off.append(ao)
+            frames.append(T)
+            mo += T + 2 * self.pad
+            ao += T
+        i32 = dict(dtype=torch.int32, device=self.device)
+        return {'mel': torch.cat(mels_p).contiguous(), 'aux': torch.cat(auxs).contiguous(),
+                'mel_off': torch.tensor(mel_off, **i32), 'aux_off': torch.tensor(aux_off, **i32), 'frames': frames,
+                'utt_samples': torch.tensor([t * self.hop_length for t in frames], **i32)}
+
+    def upsample(self, mels):
+        """UpsampleNetwork.forward (fatchord_version.py:79-86), materialised: mels [B, feat, T + 2 pad] ->
+        (upsampled mels [B, T hop, feat], aux [B, T hop, res_out]).  Generation never materialises these; this entry
+        exists for parity checks and runs the same conditioning kernel with one "sequence" per output sample."""
+        mels = torch.as_tensor(mels, dtype=torch.float32)
+        cond = self._prepare_padded(mels)
+        B = mels.shape[0]
+        T = cond['frames'][0]
+        n = T * self.hop_length
+        i32 = dict(dtype=torch.int32, device=self.device)
+        seq_utt = torch.arange(B, **i32).repeat_interleave(n)
+        seq_start = torch.arange(n, **i32).repeat(B)
+        st = self._alloc_state(B * n, 1)
+        check(_lib.load().estts_wavernn_prep(self._prep_args(cond, st, seq_utt, seq_start, B * n), ops._stream()),
+              'estts_wavernn_prep')
+        f, d, R, F = self.feat_dims, self.aux_dims, self.rnn_dims, self.fc_dims
+        up = st['xin'][:, 1:1 + f].reshape(B, n, f)
+        aux = torch.cat([st['xin'][:, 1 + f:1 + f + d], st['x1cat'][:, R:], st['x2cat'][:, R:], st['f1cat'][:, F:]], dim=1)
+        return up.clone(), aux.reshape(B, n, 4 * d)

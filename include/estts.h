@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 2
+#define ESTTS_ABI_VERSION 3
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -175,6 +175,70 @@ int estts_durations_cumsum(const float* dur, int32_t* cum, int32_t* totals, int3
  * create_mel_padding_mask on its output (pretrained_models/for_text_encoder/models.py:445). */
 int estts_expand(const float* x, int32_t ldx, const int32_t* cum, float* out, int32_t ldo, float* frame_mask,
                  int32_t B, int32_t N, int32_t T, int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * WaveRNN generation, per-sample step kernels.  One "sequence" is one fold of one utterance
+ * (fold_with_overlap, WaveRNN/models/fatchord_version.py:272-319); all sequences advance together.
+ * The step index lives in device memory (step[0]) so that a run of steps can be captured once into
+ * a hipGraph and replayed; estts_wavernn_sample advances it.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Builds the inputs of one step for every sequence, without ever materialising the upsampled
+ * conditioning tensors: for sequence b at global sample s = seq_start[b] + step[0] of utterance
+ * u = seq_utt[b]:
+ *   xin[b, 0]            = x_prev[b]
+ *   xin[b, 1 .. feat]    = sum_j fir[s % hop, j] * mel[u, s / hop + pad - (fir_kmin + j), :]
+ *   xin[b, 1+feat ..+d]  = aux[u, s / hop, 0:d];  a2/a3/a4[b, 0:d] = aux[u, s / hop, d:2d / 2d:3d / 3d:4d]
+ * (all zero when s >= utt_samples[u]: the zero padding fold_with_overlap appends).
+ * mel: [sum frames + 2 pad per utterance][feat] padded frames, utterance u starting at row mel_off[u];
+ * aux: MelResNet output at frame rate [sum frames][4 d], utterance u starting at row aux_off[u];
+ * fir: composite response of the three repeat + box-filter stages, [hop][ntaps].
+ * Replaces: UpsampleNetwork.forward's Stretch2d / Conv2d chain and the aux repeat
+ * (fatchord_version.py:79-86), fold_with_overlap (:272-319) and the per-step slicing and
+ * concatenations of generate (:182-199). */
+typedef struct estts_wavernn_prep_args {
+    const float* mel; const int32_t* mel_off;
+    const float* aux; const int32_t* aux_off;
+    const float* fir; int32_t ntaps; int32_t fir_kmin;
+    const int32_t* seq_utt; const int32_t* seq_start; const int32_t* utt_samples;
+    const float* x_prev; const int32_t* step;
+    float* xin; int32_t ld_xin;
+    float* a2; int32_t ld_a2;
+    float* a3; int32_t ld_a3;
+    float* a4; int32_t ld_a4;
+    int32_t n_seq, feat, d, hop, pad;
+} estts_wavernn_prep_args;
+
+int estts_wavernn_prep(const estts_wavernn_prep_args* args, void* stream);
+
+/* torch-order GRU gates (r, z, n) on precomputed projections gi = W_ih x + b_ih, gh = W_hh h + b_hh:
+ *   r = sigmoid(gi_r + gh_r); z = sigmoid(gi_z + gh_z); n = tanh(gi_n + r * gh_n); h' = (1 - z) n + z h
+ * h is updated in place; out[m, :] = (x_res ? x_res[m, :] : 0) + h'[m, :].
+ * Replaces: nn.GRUCell at fatchord_version.py:189-195 (and nn.GRU, :135-142, one time step at a time). */
+int estts_gru_gates(const float* gi, int32_t ldgi, const float* gh, int32_t ldgh, float* h, int32_t ldh,
+                    const float* x_res, int32_t ldx, float* out, int32_t ldo, int32_t M, int32_t H, void* stream);
+
+/* Draws the next sample of every sequence from its logits and advances step[0].
+ * mode 0 (RAW): softmax, inverse CDF at u (class = number of cdf entries <= u), value 2 c / (n - 1) - 1.
+ * mode 1 (MOL): mixture of logistics with nr_mix = n_classes / 3 components, Gumbel-max component pick from
+ *               u_mix, logistic inverse CDF at u, clamp to [-1, 1].
+ * Uniform numbers: u[step * n_seq + b] (and u_mix[(step * n_seq + b) * nr_mix + k]) when given, else a
+ * counter-based generator keyed by (seed, step, b).  wave[b * ld_wave + step] receives the value;
+ * x_prev[b] receives forced[step * n_seq + b] when forced != NULL, else the value.
+ * `done` is one zero-initialised int32 used to find the last workgroup, which advances step[0].
+ * Replaces: F.softmax + Categorical.sample (fatchord_version.py:210-216) and
+ * sample_from_discretized_mix_logistic (utility/distribution.py:87-123). */
+typedef struct estts_wavernn_sample_args {
+    const float* logits; int32_t ld_logits; int32_t n_classes; int32_t mode;
+    const float* u; const float* u_mix; const float* forced;
+    uint32_t seed;
+    float* wave; int32_t ld_wave;
+    float* x_prev;
+    int32_t* step; int32_t* done;
+    int32_t n_seq;
+} estts_wavernn_sample_args;
+
+int estts_wavernn_sample(const estts_wavernn_sample_args* args, void* stream);
 
 #ifdef __cplusplus
 }

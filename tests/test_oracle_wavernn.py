@@ -1,0 +1,60 @@
+"""The NumPy WaveRNN oracle against golden vectors produced by the reference module itself
+(tests/golden/wavernn_*.npz, see tests/golden/make_wavernn_goldens.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from wavernn_common import small_hp
+from estts import weights
+from oracle import wavernn_numpy as W
+
+
+def _load(golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, f'wavernn_{mode.lower()}_small.npz'))
+    hp = small_hp(mode)
+    return g, hp, weights.init_wavernn(hp, seed=int(g['seed']))
+
+
+@pytest.mark.parametrize('mode', ['RAW', 'MOL'])
+def test_upsample_and_forward_match_reference(golden_dir, mode):
+    g, hp, w = _load(golden_dir, mode)
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    mp = np.pad(g['mel'].astype(np.float64), ((0, 0), (0, 0), (hp['voc_pad'], hp['voc_pad'])))
+    up, aux = W.upsample_network(mp, w64, hp['voc_upsample_factors'], hp['voc_res_blocks'], hp['voc_pad'])
+    np.testing.assert_allclose(up, g['upsampled_mel'], atol=2e-6)
+    np.testing.assert_allclose(aux, g['aux'], atol=2e-5)
+    logits = W.forward(g['fwd_x'], g['fwd_mels'], w, hp)
+    np.testing.assert_allclose(logits, g['fwd_logits'], atol=3e-5)
+
+
+def test_generate_raw_trajectory_matches_reference(golden_dir):
+    g, hp, w = _load(golden_dir, 'RAW')
+    wav, logits, raw = W.generate(g['mel'], w, hp, g['u'], return_trace=True)
+    # free-running: same uniforms -> same classes -> same waveform (float32 vs float64 logits never straddle a
+    # CDF boundary for this seed)
+    np.testing.assert_allclose(logits, g['gen_logits'], atol=5e-5)
+    np.testing.assert_allclose(wav, g['wav'], atol=1e-6)
+
+
+def test_generate_mol_trajectory_matches_reference(golden_dir):
+    g, hp, w = _load(golden_dir, 'MOL')
+    wav, logits, raw = W.generate(g['mel'], w, hp, {'mix': g['u_mix'], 'logistic': g['u_logistic']}, return_trace=True)
+    np.testing.assert_allclose(logits, g['gen_logits'], atol=2e-4)
+    np.testing.assert_allclose(wav, g['wav'], atol=2e-4)
+
+
+def test_fold_unfold_shapes_and_mu_law():
+    x = np.arange(10, dtype=np.float64).reshape(1, 10, 1) + 1
+    f = W.fold_with_overlap(x, 2, 1)          # docstring example of fatchord_version.py:291-295
+    assert f.shape == (3, 4, 1)
+    assert f[:, :, 0].tolist() == [[1, 2, 3, 4], [4, 5, 6, 7], [7, 8, 9, 10]]
+    # ragged tail is zero padded to one more fold
+    f2 = W.fold_with_overlap(np.ones((1, 12, 1)), 2, 1)
+    assert f2.shape == (4, 4, 1) and f2[3, :, 0].tolist() == [1, 1, 1, 0]
+    y = W.xfade_and_unfold(np.ones((3, 8)), 4, 2)
+    assert y.shape == (3 * 6 + 2,)
+    labels = W.encode_mu_law(np.array([-1.0, 0.0, 1.0]), 512)
+    assert labels.tolist() == [0.0, 256.0, 511.0]
+    back = W.decode_mu_law(labels, 512)
+    assert abs(back[0] + 1) < 1e-9 and abs(back[2] - 1) < 1e-9 and abs(back[1]) < 1e-4
