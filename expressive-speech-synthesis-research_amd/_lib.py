@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 5
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -23,14 +23,16 @@ class GemmArgs(C.Structure):
                 ('s1', _vp), ('b1', _vp), ('act', _i32), ('alpha', _f32),
                 ('R', _vp), ('ldr', _i32), ('r_mod', _i32), ('s2', _vp), ('b2', _vp),
                 ('C', _vp), ('ldc', _i32), ('precision', _i32),
-                ('ws', _vp), ('ws_bytes', C.c_int64), ('counters', _vp), ('n_counters', _i32), ('tune', _i32)]
+                ('ws', _vp), ('ws_bytes', C.c_int64), ('counters', _vp), ('n_counters', _i32), ('tune', _i32),
+                ('conv_h', _i32), ('conv_w', _i32), ('conv_wo', _i32), ('conv_howo', _i32), ('conv_kw', _i32),
+                ('conv_stride', _i32), ('conv_pt', _i32), ('conv_pl', _i32)]
 
 
 class AttentionArgs(C.Structure):
     _fields_ = [('q', _vp), ('ldq', _i32), ('k', _vp), ('ldk', _i32), ('v', _vp), ('ldv', _i32),
                 ('ctx', _vp), ('ldo', _i32), ('attn', _vp), ('key_mask', _vp),
                 ('B', _i32), ('H', _i32), ('Lq', _i32), ('Lk', _i32), ('depth', _i32),
-                ('causal', _i32), ('precision', _i32)]
+                ('causal', _i32), ('precision', _i32), ('kv_shared', _i32)]
 
 
 class RownormArgs(C.Structure):
@@ -62,6 +64,9 @@ SIGNATURES = {
     'estts_embed_posenc': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     'estts_durations_cumsum': (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     'estts_expand': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'estts_conv2d_c1': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'estts_row_zero_mask': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
+    'estts_masked_mae': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp]),
     'estts_wavernn_prep': (_i32, [C.POINTER(WavernnPrepArgs), _vp]),
     'estts_gru_gates': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_wavernn_sample': (_i32, [C.POINTER(WavernnSampleArgs), _vp]),

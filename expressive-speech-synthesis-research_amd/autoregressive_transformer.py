@@ -1,0 +1,283 @@
+"""GST / speaker-conditioned autoregressive TransformerTTS on MI355X: reference encoder + style tokens,
+text encoder, teacher-forced decoder.
+
+Mirrors the surface of the reference class (TransformerTTS/model/AutoregressiveTransformer.py:20-327):
+`call(inputs, targets, spk_embed, train_*=False)`, `call_encoder`, `call_decoder`, `set_constants`,
+`encode_text`, `encode_ref`, `input_reshape`, same output dict keys.  Tensors are torch CUDA tensors;
+all arithmetic runs in libestts.so kernels (torch only moves / broadcasts data).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .blocks import (ConvBNLayer, CrossAttentionStack, SelfAttentionStack, _dev_vec, pack_dense)
+from .ops import PackedLinear, fold_batchnorm, same_pad
+from .text import Tokenizer, default_alphabet
+from .weights import encoder_output_dim
+
+
+class ReferenceEncoderGST:
+    """ReferenceEncoderGST (TransformerTTS/model/layers.py:526-585), inference.
+
+    conv stack: first layer (one input channel) by a direct HBM-bound kernel, the other layers as implicit GEMMs over
+    NHWC pixels; GRU: input projection of all steps in one GEMM, then per step one recurrent GEMM + gate kernel
+    (Keras gate order z, r, h is permuted to the kernel's r, z, n at pack time; reset_after=True is exactly that form);
+    style-token attention: keys / values depend on parameters only and are projected once at load time."""
+
+    def __init__(self, w, p, cfg, device):
+        self.device = device
+        self.k = cfg['ref_encoder_kernel_size']
+        self.stride = cfg['ref_encoder_strides']
+        if self.k != 3:
+            raise NotImplementedError('reference encoder kernels other than 3x3')
+        filters = cfg['ref_encoder_filters']
+        self.filters = filters
+        # first layer: kernel (3, 3, 1, C0)
+        k0 = np.asarray(w[f'{p}.conv0.kernel'])
+        s, b = fold_batchnorm(w[f'{p}.norm0.gamma'], w[f'{p}.norm0.beta'], w[f'{p}.norm0.moving_mean'], w[f'{p}.norm0.moving_variance'])
+        self.w0 = _dev_vec(k0.reshape(9, filters[0]), device)
+        self.s0 = _dev_vec(s, device)
+        self.b0 = _dev_vec(np.asarray(w[f'{p}.conv0.bias'], np.float32) * s + b, device)
+        self.convs = []
+        for i in range(1, len(filters)):
+            kern = np.asarray(w[f'{p}.conv{i}.kernel'])                 # (3, 3, cin, cout)
+            s, b = fold_batchnorm(w[f'{p}.norm{i}.gamma'], w[f'{p}.norm{i}.beta'], w[f'{p}.norm{i}.moving_mean'],
+                                  w[f'{p}.norm{i}.moving_variance'])
+            cin, cout = kern.shape[2], kern.shape[3]
+            self.convs.append(PackedLinear(kern.reshape(9 * cin, cout).T, bias=np.asarray(w[f'{p}.conv{i}.bias'], np.float32) * s + b,
+                                           scale=s, device=device, taps=9, act='relu'))
+        u = cfg['ref_encoder_gru_cell_units']
+        self.u = u
+
+        def reorder(a):          # Keras gates [z | r | h] -> [r | z | n]
+            return np.concatenate([a[..., u:2 * u], a[..., :u], a[..., 2 * u:]], axis=-1)
+
+        bias = np.asarray(w[p + '.gru.bias'])
+        self.gru_ih = PackedLinear(reorder(np.asarray(w[p + '.gru.kernel'])).T, bias=reorder(bias[0]), device=device)
+        self.gru_hh = PackedLinear(reorder(np.asarray(w[p + '.gru.recurrent_kernel'])).T, bias=reorder(bias[1]), device=device)
+        self.rnn_proj = pack_dense(w, p + '.rnn_proj', device, act='tanh')
+        m = p + '.mha'
+        self.heads = cfg['gst_multi_num_heads']
+        self.sd = cfg['gst_style_embed_dim']
+        self.wq = pack_dense(w, m + '.wq', device)
+        self.out = pack_dense(w, m + '.dense', device)
+        tok = np.tanh(np.asarray(w[p + '.gst_tokens'], np.float64))
+        k = tok @ np.asarray(w[m + '.wk.kernel'], np.float64) + np.asarray(w[m + '.wk.bias'], np.float64)
+        v = tok @ np.asarray(w[m + '.wv.kernel'], np.float64) + np.asarray(w[m + '.wv.bias'], np.float64)
+        self.keys, self.values = _dev_vec(k, device), _dev_vec(v, device)
+        self.n_tokens = tok.shape[0]
+        self.gst_tokens = np.asarray(w[p + '.gst_tokens'])
+
+    def run(self, x, precision, return_attention=True):
+        """x: [B, T, mel] float32 device tensor -> (style embedding [B, sd], attention [B, heads, 1, tokens] or None)."""
+        B, H, W = x.shape
+        dev, f32 = self.device, dict(dtype=torch.float32, device=self.device)
+        Ho, pt = same_pad(H, 3, self.stride)
+        Wo, pl = same_pad(W, 3, self.stride)
+        y = torch.empty(B, Ho, Wo, self.filters[0], **f32)
+        ops.conv2d_c1(x.contiguous(), self.w0, self.s0, self.b0, y, self.stride, pt, pl)
+        H, W = Ho, Wo
+        for lin in self.convs:
+            Ho, pt = same_pad(H, 3, self.stride)
+            Wo, pl = same_pad(W, 3, self.stride)
+            out = torch.empty(B * Ho * Wo, lin.N, **f32)
+            ops.gemm(y.view(B * H * W, -1), lin, out, M=B * Ho * Wo, precision=precision,
+                     conv2d=(H, W, Ho, Wo, 3, self.stride, pt, pl))
+            y, H, W = out, Ho, Wo
+        steps, feat = H, W * self.filters[-1]
+        seq = y.view(B * steps, feat)
+        u = self.u
+        gi = torch.empty(B * steps, 3 * u, **f32)
+        ops.gemm(seq, self.gru_ih, gi, precision=precision)
+        gi3 = gi.view(B, steps, 3 * u)
+        h = torch.zeros(B, u, **f32)
+        gh = torch.empty(B, 3 * u, **f32)
+        hout = torch.empty(B, u, **f32)
+        lib = ops._lib.load()
+        for t in range(steps):
+            ops.gemm(h, self.gru_hh, gh, precision=precision)
+            g = gi3[:, t]
+            ops.check(lib.estts_gru_gates(g.data_ptr(), g.stride(0), gh.data_ptr(), gh.stride(0), h.data_ptr(), h.stride(0),
+                                          0, 0, hout.data_ptr(), hout.stride(0), B, u, ops._stream()), 'estts_gru_gates')
+        qcat = torch.empty(B, u + self.sd, **f32)
+        ops.gemm(h, self.rnn_proj, qcat[:, :u], precision=precision)
+        q = torch.empty(B, self.sd, **f32)
+        ops.gemm(qcat[:, :u], self.wq, q, precision=precision)
+        attn = torch.empty(B, self.heads, 1, self.n_tokens, **f32) if return_attention else None
+        ops.attention(q, self.keys, self.values, qcat[:, u:], B, self.heads, 1, self.n_tokens, self.sd // self.heads,
+                      attn=attn, precision=precision, kv_shared=True)
+        out = torch.empty(B, self.sd, **f32)
+        ops.gemm(qcat, self.out, out, precision=precision)
+        return out, attn
+
+
+class AutoregressiveTransformer:
+    def __init__(self, weights, config, device='cuda', precision='bf16x3', fold_ffn=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError('AutoregressiveTransformer needs a GPU: the hot path has no CPU implementation')
+        ops._lib.load()
+        cfg = self.config = dict(config)
+        self.device = torch.device(device)
+        self.precision = precision
+        self.system_type = cfg['system_type']
+        self.mel_channels = cfg['mel_channels']
+        self.max_r = cfg['max_r']
+        self.r = self.max_r
+        self.drop_n_heads = 0
+        self.stop_prob_index = 2
+        self.decoder_prenet_dropout = 0.0
+        w, dev = weights, self.device
+        de, dd = cfg['encoder_model_dimension'], cfg['decoder_model_dimension']
+        self.de, self.dd = de, dd
+        self.start_vec = torch.full((1, self.mel_channels), float(cfg['mel_start_value']), device=dev)
+        self.end_vec = torch.full((1, self.mel_channels), float(cfg['mel_end_value']), device=dev)
+        self.tokenizer = Tokenizer(default_alphabet(), add_start_end=True)
+        self.emb = _dev_vec(w['text_encoder_prenet.embeddings'], dev)
+        if self.emb.shape[1] != de:
+            raise ValueError('encoder_prenet_dimension must equal encoder_model_dimension')
+        self.pe_enc = ops.positional_encoding_table(cfg['encoder_max_position_encoding'], de, dev) * float(
+            w['text_encoder.pos_encoding_scalar'])
+        self.pe_dec = ops.positional_encoding_table(cfg['decoder_max_position_encoding'], dd, dev) * float(
+            w['decoder.pos_encoding_scalar'])
+        self.text_encoder = SelfAttentionStack(w, 'text_encoder', 'TextEncoder', de, cfg['encoder_num_heads'],
+                                               cfg['encoder_dense_blocks'], dev, fold_ffn=fold_ffn)
+        self.style_encoder = None
+        if self.system_type in ('speaker_style_text', 'style_text'):
+            self.style_encoder = ReferenceEncoderGST(w, 'style_encoder', cfg, dev)
+        self.enc_dim = encoder_output_dim(cfg)
+        self.prenet1 = pack_dense(w, 'decoder_prenet.d1', dev, act='relu')
+        self.prenet2 = pack_dense(w, 'decoder_prenet.d2', dev, act='relu')
+        self.decoder = CrossAttentionStack(w, 'decoder', 'Decoder', dd, cfg['decoder_num_heads'], cfg['decoder_dense_blocks'],
+                                           'causal', dev, fold_ffn=fold_ffn)
+        self._final_w = (np.asarray(w['final_proj_mel.kernel']), np.asarray(w['final_proj_mel.bias']))
+        self._final = {}
+        self.stop_linear = pack_dense(w, 'decoder_postnet.stop_linear', dev)
+        self.postnet = ConvBNLayer(w, 'decoder_postnet.conv_blocks', cfg['postnet_conv_layers'], 'tanh', 'linear', 'causal', dev)
+
+    # ------------------------------------------------------------------ helpers
+    def _final_proj(self, r):
+        """FinalProj restricted to the first r * mel_channels outputs (AutoregressiveTransformer.py:173)."""
+        lin = self._final.get(r)
+        if lin is None:
+            n = r * self.mel_channels
+            lin = PackedLinear(self._final_w[0][:, :n].T, bias=self._final_w[1][:n], device=self.device)
+            self._final[r] = lin
+        return lin
+
+    def _set_r(self, r):
+        self.r = r
+
+    def _set_heads(self, heads):
+        self.drop_n_heads = heads
+
+    def set_constants(self, decoder_prenet_dropout=None, learning_rate=None, reduction_factor=None, drop_n_heads=None):
+        """AutoregressiveTransformer.py:298-307."""
+        if decoder_prenet_dropout is not None:
+            self.decoder_prenet_dropout = float(decoder_prenet_dropout)
+        if reduction_factor is not None:
+            self._set_r(int(reduction_factor))
+        if drop_n_heads is not None:
+            self._set_heads(drop_n_heads)
+
+    def encode_text(self, text):
+        return self.tokenizer(text)
+
+    def encode_ref(self, targets):
+        """AutoregressiveTransformer.py:312-316: drop the last frame, keep every r-th."""
+        tar = torch.as_tensor(targets, dtype=torch.float32, device=self.device)[None]
+        return tar[:, :-1][:, 0::self.r, :]
+
+    def input_reshape(self, tar, stop_prob):
+        """AutoregressiveTransformer.py:318-327."""
+        tar_inp, tar_real = tar[:, :-1], tar[:, 1:]
+        return tar_real, tar_inp[:, 0::self.r, :], stop_prob[:, 1:], int(tar_inp.shape[1])
+
+    # ------------------------------------------------------------------ reference surface
+    def call_encoder(self, inputs, targets, spk_embed, training_text_encoder=False, training_style_encoder=False,
+                     return_attention=True):
+        """AutoregressiveTransformer.py:124-159."""
+        if training_text_encoder or training_style_encoder:
+            raise NotImplementedError('training runs through estts.training')
+        tokens = torch.as_tensor(inputs, device=self.device).to(torch.int32).contiguous()
+        B, N = tokens.shape
+        dev, f32, de = self.device, dict(dtype=torch.float32, device=self.device), self.de
+        ws = self.text_encoder.alloc(B * N, dev)
+        key_mask = torch.empty(B, N, **f32)
+        ops.embed_posenc(tokens, self.emb, self.pe_enc, None, ws['xc'], key_mask, math.sqrt(np.float32(de)))
+        text_attn = self.text_encoder.run(ws, B, N, key_mask, self.precision, return_attention)
+        text_out = ws['xc'][:, :de]
+        enc = torch.empty(B * N, self.enc_dim, **f32)
+        enc3 = enc.view(B, N, self.enc_dim)
+        enc3[:, :, :de].copy_(text_out.reshape(B, N, de))
+        col = de
+        gst_out = gst_attn = gst_tokens = None
+        if self.style_encoder is not None:
+            tg = torch.as_tensor(targets, dtype=torch.float32, device=dev)
+            gst_out, gst_attn = self.style_encoder.run(tg, self.precision, return_attention)
+            sd = gst_out.shape[1]
+            enc3[:, :, col:col + sd].copy_(gst_out[:, None, :].expand(B, N, sd))
+            col += sd
+            gst_tokens = {'GST_tokens': self.style_encoder.gst_tokens}
+            gst_attn = {'RefEncoderGST_attention': gst_attn}
+            gst_out = gst_out.view(B, 1, sd)
+        if self.system_type in ('speaker_style_text', 'speaker_text'):
+            spk = torch.as_tensor(spk_embed, dtype=torch.float32, device=dev).reshape(B, 1, -1)
+            enc3[:, :, col:col + spk.shape[2]].copy_(spk.expand(B, N, spk.shape[2]))
+        enc_mask = torch.empty(B, N, **f32)
+        ops.row_zero_mask(enc, enc_mask.view(-1))
+        return (enc3, enc_mask.view(B, 1, 1, N), text_attn, gst_attn, gst_tokens, gst_out,
+                text_out.reshape(B, N, de).clone())
+
+    def call_decoder(self, encoder_output, targets, encoder_padding_mask, training=False, return_attention=True):
+        """AutoregressiveTransformer.py:161-181."""
+        if training:
+            raise NotImplementedError('training runs through estts.training')
+        if self.decoder_prenet_dropout != 0.0:
+            raise NotImplementedError('decoder prenet dropout > 0 (always-on dropout, layers.py:394-402) is not available '
+                                      'in the inference kernels yet')
+        dev, f32, dd, r = self.device, dict(dtype=torch.float32, device=self.device), self.dd, self.r
+        tg = torch.as_tensor(targets, dtype=torch.float32, device=dev).contiguous()
+        B, Tq, C = tg.shape
+        N = encoder_output.shape[1]
+        if Tq * r > self.pe_dec.shape[0] + r - 1:
+            raise ValueError('decoder input exceeds decoder_max_position_encoding')
+        enc = encoder_output.reshape(B * N, -1)
+        enc_mask = encoder_padding_mask.reshape(B, N).contiguous()
+        ws = self.decoder.alloc(B * Tq, B * N, dev)
+        self.decoder.project_kv(ws, enc, self.precision)
+        dec_mask = torch.empty(B, Tq, **f32)
+        ops.row_zero_mask(tg.view(B * Tq, C), dec_mask.view(-1))
+        p1 = torch.empty(B * Tq, self.prenet1.N, **f32)
+        ops.gemm(tg.view(B * Tq, C), self.prenet1, p1, precision=self.precision)
+        pe = self.pe_dec[0:Tq * r:r].contiguous()
+        ops.gemm(p1, self.prenet2, ws['xc'][:, :dd], alpha=math.sqrt(np.float32(dd)), residual=pe, r_mod=Tq,
+                 precision=self.precision)
+        attn = self.decoder.run(ws, B, Tq, N, dec_mask, enc_mask, self.precision, return_attention)
+        dec_out = ws['xc'][:, :dd]
+        lin = self._final_proj(r)
+        proj = torch.empty(B * Tq, r * C, **f32)
+        ops.gemm(dec_out, lin, proj, precision=self.precision)
+        mel = proj.view(B * Tq * r, C)                                    # (b, t, r, c) -> rows (b, t*r + j)
+        T = Tq * r
+        stop = torch.empty(B * T, 3, **f32)
+        ops.gemm(mel, self.stop_linear, stop, precision=self.precision)
+        hid = max(self.postnet.hidden(), 4)
+        final = torch.empty(B * T, C, **f32)
+        self.postnet.run(mel, torch.empty(B * T, hid, **f32), torch.empty(B * T, hid, **f32), final, T, self.precision)
+        mel3 = mel.view(B, T, C)
+        return {'mel_linear': mel3, 'final_output': final.view(B, T, C), 'stop_prob': stop.view(B, T, 3),
+                'decoder_attention': attn, 'decoder_output': dec_out.reshape(B, Tq, dd).clone(), 'linear': mel3}
+
+    def call(self, inputs, targets, spk_embed=None, train_text_encoder=False, train_style_encoder=False, train_decoder=False,
+             return_attention=True):
+        """AutoregressiveTransformer.py:243-263."""
+        enc, mask, text_attn, gst_attn, gst_tokens, gst_out, text_out = self.call_encoder(
+            inputs, targets, spk_embed, train_text_encoder, train_style_encoder, return_attention)
+        out = self.call_decoder(enc, targets, mask, train_decoder, return_attention)
+        out.update({'text_encoder_attention': text_attn, 'gst_encoder_attention': gst_attn, 'gst_tokens': gst_tokens,
+                    'gst_output': gst_out, 'text_enc_output': text_out})
+        return out
+
+    __call__ = call

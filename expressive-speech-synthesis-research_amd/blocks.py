@@ -172,3 +172,79 @@ class SelfAttentionStack:
             else:
                 ff.run(ws['x1'], ws['h'], ws['h'], xc[:, :d], L, precision)
         return attn_out
+
+
+class CrossAttentionLayer:
+    """CrossAttentionResnorm (layers.py:258-274): q from the decoder stream, k / v from the encoder output,
+    output projection over [q_in | ctx], then LN(attn + q)."""
+
+    def __init__(self, w, p, d, heads, device):
+        m = p + '.mha'
+        self.wq = pack_dense(w, m + '.wq', device)
+        wkv = np.concatenate([np.asarray(w[m + '.wk.kernel']).T, np.asarray(w[m + '.wv.kernel']).T], axis=0)
+        self.wkv = PackedLinear(wkv, bias=np.concatenate([w[m + '.wk.bias'], w[m + '.wv.bias']]), device=device)
+        self.out = pack_dense(w, m + '.dense', device)
+        self.ln = pack_ln(w, p + '.layernorm', device)
+        self.d, self.heads = d, heads
+
+    def project_kv(self, enc, kv, precision):
+        """enc [B*N, E] -> kv [B*N, 2d] (keys | values); depends on the encoder output only."""
+        ops.gemm(enc, self.wkv, kv, precision=precision)
+
+    def run(self, xc, q, kv, y, out, B, Lq, Lk, enc_mask, attn, precision):
+        d = self.d
+        ops.gemm(xc[:, :d], self.wq, q, precision=precision)
+        ops.attention(q, kv[:, :d], kv[:, d:], xc[:, d:], B, self.heads, Lq, Lk, d // self.heads, key_mask=enc_mask,
+                      attn=attn, precision=precision)
+        ops.gemm(xc, self.out, y, precision=precision)
+        ops.rownorm(y, out, residual=xc[:, :d], ln_b=self.ln)
+
+
+class CrossAttentionStack:
+    """CrossAttentionBlocks (layers.py:331-376) without its positional front end."""
+
+    def __init__(self, w, p, name, d, heads, dense_blocks, conv_padding, device, fold_ffn=True):
+        self.d, self.name = d, name
+        self.blocks, self.names = [], []
+        for i, h in enumerate(heads):
+            b = f'{p}.block{i}'
+            sa = SelfAttentionLayer(w, b + '.sarn', d, h, device)
+            ca = CrossAttentionLayer(w, b + '.carn', d, h, device)
+            if i < dense_blocks:
+                ff = FFNLayer(w, b + '.ffn', device, fold=fold_ffn)
+                self.names.append(f'{name}_DenseBlock{i + 1}_CrossAttention')
+            else:
+                ff = ConvBNLayer(w, b + '.conv', 2, 'relu', 'relu', conv_padding, device)
+                self.names.append(f'{name}_ConvBlock{i - dense_blocks + 1}_CrossAttention')
+            self.blocks.append((sa, ca, ff))
+        self.hidden = max(ff.hidden() for _, _, ff in self.blocks)
+
+    def alloc(self, rows, enc_rows, device):
+        d = self.d
+        f32 = dict(dtype=torch.float32, device=device)
+        return {'xc': torch.empty(rows, 2 * d, **f32), 'xc2': torch.empty(rows, 2 * d, **f32),
+                'qkv': torch.empty(rows, 3 * d, **f32), 'q': torch.empty(rows, d, **f32), 'y': torch.empty(rows, d, **f32),
+                'x2': torch.empty(rows, d, **f32), 'h': torch.empty(rows, max(self.hidden, 4), **f32),
+                'kv': [torch.empty(enc_rows, 2 * d, **f32) for _ in self.blocks]}
+
+    def project_kv(self, ws, enc, precision):
+        for (_, ca, _), kv in zip(self.blocks, ws['kv']):
+            ca.project_kv(enc, kv, precision)
+
+    def run(self, ws, B, Lq, Lk, dec_key_mask, enc_mask, precision, return_attention):
+        """Input in ws['xc'][:, :d]; output left there.  Self-attention is causal (look-ahead mask) and masks padded
+        decoder frames; returns {name: cross-attention weights}."""
+        d = self.d
+        xc, xc2, attn_out = ws['xc'], ws['xc2'], {}
+        for (sa, ca, ff), kv, name in zip(self.blocks, ws['kv'], self.names):
+            attn = None
+            if return_attention:
+                attn = torch.empty(B, ca.heads, Lq, Lk, dtype=torch.float32, device=xc.device)
+                attn_out[name] = attn
+            sa.run(xc, ws['qkv'], ws['y'], xc2[:, :d], B, Lq, dec_key_mask, True, None, precision)
+            ca.run(xc2, ws['q'], kv, ws['y'], ws['x2'], B, Lq, Lk, enc_mask, attn, precision)
+            if isinstance(ff, FFNLayer):
+                ff.run(ws['x2'], ws['h'], ws['y'], xc[:, :d], precision)
+            else:
+                ff.run(ws['x2'], ws['h'], ws['h'], xc[:, :d], Lq, precision)
+        return attn_out

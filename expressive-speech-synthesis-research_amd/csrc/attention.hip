@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     const int qi = q0 + i;
     const int qrow = min(qi, p.Lq - 1);
     const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * DH + 8 * g;
-    const float* kbase = p.k + (long)b * p.Lk * p.ldk + h * DH;
-    const float* vbase = p.v + (long)b * p.Lk * p.ldv + h * DH;
+    const long kvb = p.kv_shared ? 0 : b;
+    const float* kbase = p.k + kvb * p.Lk * p.ldk + h * DH;
+    const float* vbase = p.v + kvb * p.Lk * p.ldv + h * DH;
     const float* mask = p.key_mask ? p.key_mask + (long)b * p.Lk : nullptr;
     const float scale = 1.0f / sqrtf((float)DH);
     __bf16* stage = reinterpret_cast<__bf16*>(smem) + wave * (NS * IMG);

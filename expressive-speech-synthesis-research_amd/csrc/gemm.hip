@@ -43,6 +43,56 @@ __device__ __forceinline__ float epilogue_value(const estts_gemm_args& p, float 
     return v;
 }
 
+
+// ---- A operand addressing.  Output row m is pixel (img, ho, wo) of a [*, Ho, Wo] output grid; K index kk is
+// (tap, channel) with tap = (kh, kw); the source pixel is (ho * stride + kh - pad_top, wo * stride + kw - pad_left) of a
+// [*, H, W] input grid with lda floats per pixel; pixels outside the grid read as zero.  A dense layer is the 1 x 1 case
+// (H = Ho = 1, W = Wo = M), a 1-D convolution over rows has H = 1, W = seg_len, kw = taps.
+struct ARow {
+    int pix0;   // img * H * W
+    int h0, w0; // ho * stride - pad_top, wo * stride - pad_left
+    bool ok;
+};
+struct ATap {
+    int dh, dw, c;
+    bool ok;
+};
+
+__device__ __forceinline__ ARow make_arow(const estts_gemm_args& p, int m) {
+    ARow r;
+    r.ok = m < p.M;
+    const int img = m / p.conv_howo;
+    const int rem = m - img * p.conv_howo;
+    const int ho = rem / p.conv_wo;
+    const int wo = rem - ho * p.conv_wo;
+    r.pix0 = img * p.conv_h * p.conv_w;
+    r.h0 = ho * p.conv_stride - p.conv_pt;
+    r.w0 = wo * p.conv_stride - p.conv_pl;
+    return r;
+}
+
+__device__ __forceinline__ ATap make_atap(const estts_gemm_args& p, int kk) {
+    ATap t;
+    t.ok = kk < p.K;
+    int tap = 0;
+    t.c = kk;
+    if (p.taps > 1) {
+        tap = kk / p.c_per_tap;
+        t.c = kk - tap * p.c_per_tap;
+    }
+    t.dh = tap / p.conv_kw;
+    t.dw = tap - t.dh * p.conv_kw;
+    return t;
+}
+
+__device__ __forceinline__ float4 load_a(const estts_gemm_args& p, const ARow& r, const ATap& t) {
+    const int hi = r.h0 + t.dh;
+    const int wi = r.w0 + t.dw;
+    const bool ok = r.ok && t.ok && hi >= 0 && hi < p.conv_h && wi >= 0 && wi < p.conv_w;
+    const float* ap = p.A + (long)(r.pix0 + hi * p.conv_w + wi) * p.lda + t.c;
+    return ok ? *reinterpret_cast<const float4*>(ap) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // split-K hand-off; returns true in the workgroup that must finish the tile (all threads must call)
 __device__ __forceinline__ bool splitk_last_arriver(const estts_gemm_args& p, int tile, int splitk, int* s_ticket) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -92,18 +142,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     const int c8 = lane & 7;
     const int m0 = blockIdx.y * 32;
     const int n0 = blockIdx.x * 32;
-    const int seg = p.seg_len > 0 ? p.seg_len : p.M;
     const int KS = p.ldw >> 5;  // K-steps per packed row block
 
-    int a_row[4], a_t[4];
-    bool a_ok[4];
+    ARow a_row[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + r8 + 8 * j;
-        a_row[j] = m;
-        a_ok[j] = m < p.M;
-        a_t[j] = m % seg;
-    }
+    for (int j = 0; j < 4; ++j) a_row[j] = make_arow(p, m0 + r8 + 8 * j);
     const uint16_t* whp[2];
     const uint16_t* wlp[2];
 #pragma unroll
@@ -119,20 +162,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     int ks = blockIdx.z * per + wave;
 
     auto load = [&](int k, SmallStage<NS>& st) {
-        const int kk = k * 32 + c8 * 4;
-        int tap = 0, c = kk;
-        if (p.taps > 1) {
-            tap = kk / p.c_per_tap;
-            c = kk - tap * p.c_per_tap;
-        }
-        const int shift = tap - p.tap_lpad;
+        const ATap tp = make_atap(p, k * 32 + c8 * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = a_t[j] + shift;
-            const bool ok = a_ok[j] && kk < p.K && t >= 0 && t < seg;
-            const float* ap = p.A + (long)(a_row[j] + shift) * p.lda + c;
-            st.a[j] = ok ? *reinterpret_cast<const float4*>(ap) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int j = 0; j < 4; ++j) st.a[j] = load_a(p, a_row[j], tp);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             st.w[0][i] = *reinterpret_cast<const uint4*>(whp[i] + (long)k * 512);
@@ -286,38 +318,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p, cons
     const int wn = wave % WN;
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
-    const int seg = p.seg_len > 0 ? p.seg_len : p.M;
     const int KS = p.ldw >> 5;
 
-    int a_row[A_ITERS], a_t[A_ITERS];
-    bool a_ok[A_ITERS];
+    ARow a_row[A_ITERS];
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-        const int m = m0 + ((tid + i * 256) >> 4);
-        a_row[i] = m;
-        a_ok[i] = m < p.M;
-        a_t[i] = m % seg;
-    }
+    for (int i = 0; i < A_ITERS; ++i) a_row[i] = make_arow(p, m0 + ((tid + i * 256) >> 4));
     const int a_ch = tid & 15;  // same 16-byte column chunk for every i
 
     float4 a_reg[A_ITERS];
     uint4 w_reg[NS][W_ITERS];
 
     auto load_tiles = [&](int kt) {
-        const int kk = kt * BK + a_ch * 4;
-        int tap = 0, c = kk;
-        if (p.taps > 1) {
-            tap = kk / p.c_per_tap;
-            c = kk - tap * p.c_per_tap;
-        }
-        const int shift = tap - p.tap_lpad;
+        const ATap tp = make_atap(p, kt * BK + a_ch * 4);
 #pragma unroll
-        for (int i = 0; i < A_ITERS; ++i) {
-            const int t = a_t[i] + shift;
-            const bool ok = a_ok[i] && kk < p.K && t >= 0 && t < seg;
-            const float* ap = p.A + (long)(a_row[i] + shift) * p.lda + c;
-            a_reg[i] = ok ? *reinterpret_cast<const float4*>(ap) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < A_ITERS; ++i) a_reg[i] = load_a(p, a_row[i], tp);
 #pragma unroll
         for (int i = 0; i < W_ITERS; ++i) {
             const int idx = tid + i * 256;
@@ -503,7 +517,22 @@ int launch(const estts_gemm_args& a, int splitk, hipStream_t st) {
 
 extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
     ESTTS_CHECK_ARG(args != nullptr, "estts_gemm: null args");
-    const estts_gemm_args& a = *args;
+    estts_gemm_args a = *args;
+    if (a.conv_kw <= 0) {  // dense layer or 1-D convolution over rows: one image row of seg_len pixels per sequence
+        ESTTS_CHECK_ARG(a.seg_len == 0 || a.M % a.seg_len == 0, "estts_gemm: M not a multiple of seg_len");
+        a.conv_h = 1;
+        a.conv_w = a.seg_len > 0 ? a.seg_len : a.M;
+        a.conv_wo = a.conv_w;
+        a.conv_howo = a.conv_w;
+        a.conv_kw = a.taps;
+        a.conv_stride = 1;
+        a.conv_pt = 0;
+        a.conv_pl = a.tap_lpad;
+    } else {
+        ESTTS_CHECK_ARG(a.conv_h > 0 && a.conv_w > 0 && a.conv_wo > 0 && a.conv_howo > 0 && a.conv_stride > 0 &&
+                        a.taps % a.conv_kw == 0 && a.M % a.conv_howo == 0 && a.conv_howo % a.conv_wo == 0,
+                        "estts_gemm: inconsistent 2-D convolution geometry");
+    }
     ESTTS_CHECK_ARG(a.A && a.W_hi && a.C, "estts_gemm: null A/W/C");
     ESTTS_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "estts_gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     ESTTS_CHECK_ARG(a.precision == 1 || a.precision == 3, "estts_gemm: precision must be 1 or 3");
@@ -515,7 +544,6 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
     ESTTS_CHECK_ARG(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W_hi & 15) == 0 && ((uintptr_t)a.W_lo & 15) == 0,
                     "estts_gemm: A / W must be 16-byte aligned");
     ESTTS_CHECK_ARG(a.ldw >= ((a.K + 63) / 64) * 64 && (a.ldw & 63) == 0, "estts_gemm: ldw must be K rounded up to 64");
-    ESTTS_CHECK_ARG(a.seg_len == 0 || a.M % a.seg_len == 0, "estts_gemm: M not a multiple of seg_len");
     ESTTS_CHECK_ARG(a.taps == 1 || a.lda >= a.c_per_tap, "estts_gemm: lda < c_per_tap");
     ESTTS_CHECK_ARG(!a.R || a.ldr >= a.N, "estts_gemm: ldr < N");
     ESTTS_CHECK_ARG(a.ldc >= a.N, "estts_gemm: ldc < N");

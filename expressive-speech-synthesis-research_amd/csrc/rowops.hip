@@ -177,6 +177,78 @@ __global__ __launch_bounds__(256) void expand_kernel(const float* x, int ldx, co
     if (frame_mask && lane == 0) frame_mask[frame] = 0.0f;
 }
 
+// ------------------------------------------------------------------------------------------
+// 3 x 3, one input channel: one thread per (output pixel, 4 output channels)
+__global__ __launch_bounds__(256) void conv2d_c1_kernel(const float* x, const float* w, const float* scale, const float* bias,
+                                                        float* out, int B, int H, int W, int Ho, int Wo, int Cout, int stride,
+                                                        int pad_t, int pad_l) {
+    const int cq = Cout >> 2;
+    const long total = (long)B * Ho * Wo * cq;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cq) * 4;
+        long pix = idx / cq;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * stride + kh - pad_t;
+            if (hi < 0 || hi >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * stride + kw - pad_l;
+                if (wi < 0 || wi >= W) continue;
+                const float v = x[((long)b * H + hi) * W + wi];
+                const float4 wv = *reinterpret_cast<const float4*>(w + (kh * 3 + kw) * Cout + c);
+                acc.x += v * wv.x; acc.y += v * wv.y; acc.z += v * wv.z; acc.w += v * wv.w;
+            }
+        }
+        const float4 s = *reinterpret_cast<const float4*>(scale + c);
+        const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+        float4 r;
+        r.x = fmaxf(acc.x * s.x + bb.x, 0.f); r.y = fmaxf(acc.y * s.y + bb.y, 0.f);
+        r.z = fmaxf(acc.z * s.z + bb.z, 0.f); r.w = fmaxf(acc.w * s.w + bb.w, 0.f);
+        *reinterpret_cast<float4*>(out + (((long)b * Ho + ho) * Wo + wo) * Cout + c) = r;
+    }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void row_zero_mask_kernel(const float* x, int ldx, float* mask, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += fabsf(x[(long)row * ldx + c]);
+    s = wave_sum(s);
+    if (lane == 0) mask[row] = s == 0.0f ? 1.0f : 0.0f;
+}
+
+// one wave per row; one atomic per workgroup
+__global__ __launch_bounds__(256) void masked_mae_kernel(const float* target, int ldt, const float* pred, int ldp, float* out,
+                                                         int M, int C) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    float v = 0.f;
+    if (row < M) {
+        float s = 0.f, nz = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float t = target[(long)row * ldt + c];
+            s += fabsf(t - pred[(long)row * ldp + c]);
+            nz += t != 0.0f ? 1.0f : 0.0f;
+        }
+        s = wave_sum(s);
+        nz = wave_sum(nz);
+        v = nz > 0.f ? s / (float)C : 0.f;
+    }
+    if (lane == 0) part[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1] + part[2] + part[3]) / (float)M);
+}
+
 }  // namespace
 
 extern "C" int estts_embed_posenc(const int32_t* tokens, const float* emb, const float* pe, const float* pos_scalar,
@@ -221,5 +293,35 @@ extern "C" int estts_expand(const float* x, int32_t ldx, const int32_t* cum, flo
     hipLaunchKernelGGL(expand_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, cum,
                        out, ldo, frame_mask, B, N, T, D);
     ESTTS_CHECK_LAUNCH("estts_expand");
+    return 0;
+}
+
+extern "C" int estts_conv2d_c1(const float* x, const float* w, const float* scale, const float* bias, float* out, int32_t B,
+                               int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t Cout, int32_t stride, int32_t pad_t,
+                               int32_t pad_l, void* stream) {
+    ESTTS_CHECK_ARG(x && w && scale && bias && out, "estts_conv2d_c1: null pointer");
+    ESTTS_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && Cout > 0 && (Cout & 3) == 0 && stride > 0,
+                    "estts_conv2d_c1: bad shape (Cout must be a multiple of 4)");
+    ESTTS_CHECK_ARG((Ho - 1) * stride - pad_t < H && (Wo - 1) * stride - pad_l < W, "estts_conv2d_c1: output grid leaves the image");
+    const long total = (long)B * Ho * Wo * (Cout >> 2);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv2d_c1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, scale, bias, out, B, H, W, Ho,
+                       Wo, Cout, stride, pad_t, pad_l);
+    ESTTS_CHECK_LAUNCH("estts_conv2d_c1");
+    return 0;
+}
+
+extern "C" int estts_row_zero_mask(const float* x, int32_t ldx, float* mask, int32_t M, int32_t D, void* stream) {
+    ESTTS_CHECK_ARG(x && mask && M > 0 && D > 0 && ldx >= D, "estts_row_zero_mask: bad arguments");
+    hipLaunchKernelGGL(row_zero_mask_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, mask, M, D);
+    ESTTS_CHECK_LAUNCH("estts_row_zero_mask");
+    return 0;
+}
+
+extern "C" int estts_masked_mae(const float* target, int32_t ldt, const float* pred, int32_t ldp, float* out, int32_t M,
+                                int32_t C, void* stream) {
+    ESTTS_CHECK_ARG(target && pred && out && M > 0 && C > 0 && ldt >= C && ldp >= C, "estts_masked_mae: bad arguments");
+    hipLaunchKernelGGL(masked_mae_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, target, ldt, pred, ldp, out, M, C);
+    ESTTS_CHECK_LAUNCH("estts_masked_mae");
     return 0;
 }

@@ -122,7 +122,7 @@ def gemm_workspace(device):
 
 
 def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
-         split=True):
+         split=True, conv2d=None):
     """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary)."""
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
@@ -141,6 +141,10 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     a.C, a.ldc = out.data_ptr(), out.stride(0)
     a.precision = PRECISION[precision]
     a.tune = tune
+    if conv2d is not None:   # (H, W, Ho, Wo, kw, stride, pad_top, pad_left); x rows are NHWC pixels
+        H, W, Ho, Wo, kw, stride, pt, pl = conv2d
+        a.conv_h, a.conv_w, a.conv_wo, a.conv_howo = H, W, Wo, Ho * Wo
+        a.conv_kw, a.conv_stride, a.conv_pt, a.conv_pl = kw, stride, pt, pl
     if split:
         ws, cnt = gemm_workspace(x.device)
         a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
@@ -156,7 +160,8 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     return out
 
 
-def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, attn=None, precision='bf16x3'):
+def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, attn=None, precision='bf16x3',
+              kv_shared=False):
     """q: [B*Lq, >=H*depth] view, k/v: [B*Lk, ...] views, ctx: [B*Lq, ...] view; attn: [B,H,Lq,Lk] or None."""
     for t, n in ((q, 'q'), (k, 'k'), (v, 'v'), (ctx, 'ctx')):
         _check_f32(t, n)
@@ -173,6 +178,7 @@ def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, at
     a.B, a.H, a.Lq, a.Lk, a.depth = B, H, Lq, Lk, depth
     a.causal = int(causal)
     a.precision = PRECISION[precision]
+    a.kv_shared = int(kv_shared)
     check(_lib.load().estts_attention(a, _stream()), 'estts_attention')
     _record('attention', {'B': B, 'H': H, 'Lq': Lq, 'Lk': Lk, 'depth': depth, 'weights': attn is not None,
                           'flops': 4.0 * B * H * Lq * Lk * depth,
@@ -241,6 +247,37 @@ def expand(x, cum, out, frame_mask, B, N, T, D):
             _lib.load().estts_expand, x.data_ptr(), x.stride(0), cum.data_ptr(), out.data_ptr(), out.stride(0),
             _ptr(frame_mask), B, N, T, D)
     return out
+
+
+def conv2d_c1(x, w9, scale, bias, out, stride, pad_t, pad_l):
+    """x [B,H,W] (one input channel), w9 [9, Cout], out [B,Ho,Wo,Cout] NHWC: conv + folded BN + ReLU."""
+    B, H, W = x.shape
+    _, Ho, Wo, Cout = out.shape
+    check(_lib.load().estts_conv2d_c1(x.data_ptr(), w9.data_ptr(), scale.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
+                                      Ho, Wo, Cout, stride, pad_t, pad_l, _stream()), 'estts_conv2d_c1')
+    return out
+
+
+def row_zero_mask(x, mask, M=None, D=None):
+    M = x.shape[0] if M is None else M
+    D = x.shape[1] if D is None else D
+    check(_lib.load().estts_row_zero_mask(x.data_ptr(), x.stride(0), mask.data_ptr(), M, D, _stream()), 'estts_row_zero_mask')
+    return mask
+
+
+def masked_mae(target, pred, out):
+    """target / pred: 2-D [rows, C] float32 views; out: zeroed 1-element float32 tensor (accumulated)."""
+    M, C = target.shape
+    check(_lib.load().estts_masked_mae(target.data_ptr(), target.stride(0), pred.data_ptr(), pred.stride(0), out.data_ptr(),
+                                       M, C, _stream()), 'estts_masked_mae')
+    return out
+
+
+def same_pad(n, k, stride):
+    """TensorFlow 'SAME': output size and low-side padding for extent n."""
+    out = -(-n // stride)
+    total = max((out - 1) * stride + k - n, 0)
+    return out, total // 2
 
 
 def positional_encoding_table(position, model_dim, device):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 3
+#define ESTTS_ABI_VERSION 5
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -54,7 +54,9 @@ const char* estts_last_error(void);
  * :58-67 (FFNResNorm d1/d2), :112-116,129-131,145 (MultiHeadAttention wq/wk/wv/dense),
  * :387-401 (DecoderPrenet), :636 (DurationPredictor.linear),
  * pretrained_models/for_text_encoder/models.py:350 (out);
- * nn.Linear / nn.Conv1d at WaveRNN/models/fatchord_version.py:13-25,32-45,109-114.
+ * nn.Linear / nn.Conv1d at WaveRNN/models/fatchord_version.py:13-25,32-45,109-114;
+ * with the 2-D geometry fields: Conv2D(3x3, stride 2, 'same') + BatchNormalization + ReLU of the GST
+ * reference encoder, TransformerTTS/model/layers.py:538-559 (layers with at least 4 input channels).
  *
  * precision: 1 = bf16 operands (one MFMA per product); 3 = split-bf16 (hi*hi + lo*hi + hi*lo,
  * fp32 accumulate; needs W_lo).  K, c_per_tap and lda must be multiples of 4; W rows are padded
@@ -97,6 +99,10 @@ typedef struct estts_gemm_args {
     int32_t* counters;   /* split-K tickets, may be NULL */
     int32_t n_counters;
     int32_t tune;
+    /* 2-D convolution geometry (NHWC, lda floats per pixel); conv_kw = 0 selects the dense / 1-D form above.
+     * Output row m = (image, ho, wo) on a conv_howo / conv_wo grid, tap = (kh, kw) with kw fastest,
+     * source pixel (ho * stride + kh - conv_pt, wo * stride + kw - conv_pl) of a conv_h x conv_w image. */
+    int32_t conv_h, conv_w, conv_wo, conv_howo, conv_kw, conv_stride, conv_pt, conv_pl;
 } estts_gemm_args;
 
 int estts_gemm(const estts_gemm_args* args, void* stream);
@@ -125,6 +131,7 @@ typedef struct estts_attention_args {
     int32_t B, H, Lq, Lk, depth;
     int32_t causal;
     int32_t precision;       /* 1 or 3, as in estts_gemm */
+    int32_t kv_shared;       /* 1 = k / v hold Lk rows used by every batch entry (style tokens) */
 } estts_attention_args;
 
 int estts_attention(const estts_attention_args* args, void* stream);
@@ -175,6 +182,28 @@ int estts_durations_cumsum(const float* dur, int32_t* cum, int32_t* totals, int3
  * create_mel_padding_mask on its output (pretrained_models/for_text_encoder/models.py:445). */
 int estts_expand(const float* x, int32_t ldx, const int32_t* cum, float* out, int32_t ldo, float* frame_mask,
                  int32_t B, int32_t N, int32_t T, int32_t D, void* stream);
+
+/* First layer of the GST reference encoder: 3 x 3 convolution with ONE input channel over the mel "image"
+ * x [B, H = frames, W = mel bins], stride `stride`, TensorFlow 'SAME' padding (pad_t / pad_l on the low side),
+ * followed by the folded inference BatchNormalization and ReLU:
+ *   out[b, ho, wo, co] = relu(scale[co] * sum_{kh,kw} x[b, ho s + kh - pad_t, wo s + kw - pad_l] w[kh*3+kw, co] + bias[co])
+ * out is NHWC [B, Ho, Wo, Cout].  HBM-bound (reads the mel once, writes Cout floats per output pixel).
+ * Replaces: Conv2D + BatchNormalization + ReLU, first iteration of ReferenceEncoderGST.call_convs,
+ * TransformerTTS/model/layers.py:554-559 after the expand_dims of :563. */
+int estts_conv2d_c1(const float* x, const float* w, const float* scale, const float* bias, float* out, int32_t B,
+                    int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t Cout, int32_t stride, int32_t pad_t,
+                    int32_t pad_l, void* stream);
+
+/* mask[m] = 1.0 if every element of row m of x [M, D] is zero, else 0.0.
+ * Replaces: create_mel_padding_mask, TransformerTTS/model/transformer_utils.py:66-69. */
+int estts_row_zero_mask(const float* x, int32_t ldx, float* mask, int32_t M, int32_t D, void* stream);
+
+/* Masked mean absolute error, forward value:  out[0] = sum_rows( any(target_row != 0) * mean_c |target - pred| ) / M
+ * (Keras MeanAbsoluteError with sample_weight under SUM_OVER_BATCH_SIZE: padded rows count in the denominator).
+ * out[0] must be zero on entry (accumulated with one float atomic per workgroup).
+ * Replaces: masked_mean_absolute_error, TransformerTTS/utils/losses.py:41-47. */
+int estts_masked_mae(const float* target, int32_t ldt, const float* pred, int32_t ldp, float* out, int32_t M,
+                     int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * WaveRNN generation, per-sample step kernels.  One "sequence" is one fold of one utterance

@@ -1,0 +1,121 @@
+"""GST reference encoder + teacher-forced AutoregressiveTransformer on the GPU against the float64 NumPy oracle
+(oracle/tts_numpy.py) on identical seeded weights and inputs.  Tolerances (bf16x3): 3e-4 on mel outputs,
+1e-3 on attention maps."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import estts
+from estts import configs, ops, weights
+from estts.autoregressive_transformer import AutoregressiveTransformer, ReferenceEncoderGST
+from estts.ops import PackedLinear
+from oracle import tts_numpy as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def small_cfg(system_type, dense=1):
+    return configs.autoregressive_config(
+        system_type=system_type, encoder_model_dimension=64, decoder_model_dimension=64, encoder_prenet_dimension=64,
+        decoder_prenet_dimension=48, encoder_num_heads=[2, 2], decoder_num_heads=[2, 2], encoder_dense_blocks=dense,
+        decoder_dense_blocks=dense, encoder_feed_forward_dimension=96, decoder_feed_forward_dimension=96,
+        encoder_attention_conv_filters=80, decoder_attention_conv_filters=80, ref_encoder_filters=[8, 8, 16],
+        ref_encoder_gru_cell_units=32, gst_style_embed_dim=64, gst_multi_num_heads=2, gst_heads=5, speaker_embed_dim=16,
+        mel_channels=80, max_r=3, postnet_conv_filters=32, postnet_conv_layers=3, vocab_size=30,
+        encoder_max_position_encoding=64, decoder_max_position_encoding=256)
+
+
+def test_conv2d_first_layer_and_implicit_gemm_layers():
+    rng = np.random.default_rng(0)
+    B, H, W = 2, 37, 80
+    x = rng.normal(size=(B, H, W)).astype(np.float32)
+    k0 = rng.normal(size=(3, 3, 1, 8)).astype(np.float32) * 0.3
+    k1 = rng.normal(size=(3, 3, 8, 16)).astype(np.float32) * 0.1
+    b0, b1 = rng.normal(size=8).astype(np.float32), rng.normal(size=16).astype(np.float32)
+    ref0 = np.maximum(O.conv2d_same(x[..., None].astype(np.float64), k0.astype(np.float64), b0.astype(np.float64), 2), 0)
+    ref1 = np.maximum(O.conv2d_same(ref0, k1.astype(np.float64), b1.astype(np.float64), 2), 0)
+    Ho, pt = ops.same_pad(H, 3, 2); Wo, pl = ops.same_pad(W, 3, 2)
+    y0 = torch.empty(B, Ho, Wo, 8, device=DEV)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    ops.conv2d_c1(t(x), t(k0.reshape(9, 8)), torch.ones(8, device=DEV), t(b0), y0, 2, pt, pl)
+    assert np.abs(y0.cpu().numpy() - ref0).max() < 1e-5
+    H2, pt2 = ops.same_pad(Ho, 3, 2); W2, pl2 = ops.same_pad(Wo, 3, 2)
+    lin = PackedLinear(k1.reshape(72, 16).T, bias=b1, device=DEV, taps=9, act='relu')
+    y1 = torch.empty(B * H2 * W2, 16, device=DEV)
+    ops.gemm(y0.view(B * Ho * Wo, 8), lin, y1, M=B * H2 * W2, conv2d=(Ho, Wo, H2, W2, 3, 2, pt2, pl2))
+    assert np.abs(y1.cpu().numpy().reshape(B, H2, W2, 16) - ref1).max() < 5e-5
+
+
+def test_row_zero_mask_and_masked_mae():
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(13, 80)).astype(np.float32)
+    x[3] = 0; x[9] = 0
+    m = torch.empty(13, device=DEV)
+    ops.row_zero_mask(torch.from_numpy(x).to(DEV), m)
+    assert m.cpu().numpy().tolist() == [1.0 if i in (3, 9) else 0.0 for i in range(13)]
+    pred = rng.normal(size=(13, 80)).astype(np.float32)
+    out = torch.zeros(1, device=DEV)
+    ops.masked_mae(torch.from_numpy(x).to(DEV), torch.from_numpy(pred).to(DEV), out)
+    ref = O.masked_mean_absolute_error(x[None], pred[None])
+    assert abs(out.item() - ref) < 1e-5
+
+
+def test_reference_encoder_gst_vs_oracle():
+    cfg = small_cfg('style_text')
+    w = weights.init_autoregressive_transformer(cfg, seed=5)
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(3, 45, 80)).astype(np.float32)
+    enc = ReferenceEncoderGST(w, 'style_encoder', cfg, torch.device(DEV))
+    out, attn = enc.run(torch.from_numpy(x).to(DEV), 'bf16x3')
+    w64 = {k: np.asarray(v, np.float64) for k, v in w.items()}
+    ref, ref_attn = O.reference_encoder_gst(x.astype(np.float64), w64, 'style_encoder', 3, 2, cfg['gst_multi_num_heads'])
+    assert np.abs(out.cpu().numpy() - ref[:, 0]).max() < 1e-4
+    assert np.abs(attn.cpu().numpy() - ref_attn).max() < 1e-4
+
+
+@pytest.mark.parametrize('system_type,dense,r', [('style_text', 1, 1), ('speaker_style_text', 2, 3), ('speaker_text', 0, 2),
+                                                 ('text', 1, 1)])
+def test_teacher_forced_call_vs_oracle(system_type, dense, r):
+    cfg = small_cfg(system_type, dense)
+    w = weights.init_autoregressive_transformer(cfg, seed=7)
+    rng = np.random.default_rng(3)
+    B, N, Tq = 2, 11, 14
+    tokens = rng.integers(1, cfg['vocab_size'], size=(B, N)).astype(np.int32); tokens[1, 8:] = 0
+    targets = rng.normal(size=(B, Tq, 80)).astype(np.float32); targets[1, 10:] = 0
+    spk = rng.normal(size=(B, 1, 16)).astype(np.float32)
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=r, decoder_prenet_dropout=0.0)
+    out = model.call(tokens, targets, spk)
+    ref = O.autoregressive_call(w, cfg, tokens, targets, spk, r=r)
+    assert tuple(out['final_output'].shape) == (B, Tq * r, 80)
+    for key, tol in (('final_output', 3e-4), ('mel_linear', 3e-4), ('stop_prob', 3e-4), ('text_enc_output', 3e-4),
+                     ('decoder_output', 3e-4)):
+        assert np.abs(out[key].cpu().numpy() - ref[key]).max() < tol, key
+    names = [f'Decoder_DenseBlock{i + 1}_CrossAttention' for i in range(dense)] + \
+            [f'Decoder_ConvBlock{i + 1}_CrossAttention' for i in range(2 - dense)]
+    for name, ra in zip(names, ref['decoder_attention']):
+        assert np.abs(out['decoder_attention'][name].cpu().numpy() - ra).max() < 1e-3
+    if 'style' in system_type:
+        assert np.abs(out['gst_output'].cpu().numpy() - ref['gst_output']).max() < 1e-4
+        assert np.abs(out['gst_encoder_attention']['RefEncoderGST_attention'].cpu().numpy() - ref['gst_encoder_attention']).max() < 1e-4
+
+
+def test_shipped_config_shapes_and_batch_independence():
+    """BASELINE config 3 dimensions (d 256, 4+4 dense blocks, GST filters 32..128) at a reduced batch: shapes,
+    finiteness, and row 0 of a batch equals the same utterance alone."""
+    cfg = configs.autoregressive_config(system_type='style_text')
+    w = weights.init_autoregressive_transformer(cfg, seed=1234)
+    rng = np.random.default_rng(4)
+    B, N, Tq = 3, 40, 120
+    tokens = rng.integers(1, cfg['vocab_size'], size=(B, N)).astype(np.int32)
+    targets = np.clip(rng.normal(0, 1.5, size=(B, Tq, 80)), -4, 4).astype(np.float32)
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=1)
+    out = model.call(tokens, targets, None)
+    assert tuple(out['final_output'].shape) == (B, Tq, 80) and torch.isfinite(out['final_output']).all()
+    assert tuple(out['gst_output'].shape) == (B, 1, 256)
+    alone = model.call(tokens[:1], targets[:1], None)
+    assert (out['final_output'][0] - alone['final_output'][0]).abs().max().item() < 1e-5

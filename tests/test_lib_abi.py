@@ -39,6 +39,6 @@ def test_abi_version_and_error_channel():
 
 def test_struct_sizes_match_header_layout():
     # pointer/int packing of the ctypes mirrors: 64-bit pointers, 4-byte ints, natural alignment
-    assert ctypes.sizeof(_lib.GemmArgs) == 168
+    assert ctypes.sizeof(_lib.GemmArgs) == 200
     assert ctypes.sizeof(_lib.AttentionArgs) == 112
     assert ctypes.sizeof(_lib.RownormArgs) == 128
