@@ -78,6 +78,31 @@ def time_kernels(trace, reps=20, rounds=3):
     return rows
 
 
+def wavernn_pass(precision):
+    """BASELINE config 4, one pass: 64 utterances x 560 frames, hop 256 @ 22.05 kHz, RAW 9-bit mu-law, batched folds
+    (target 11 000, overlap 550).  Reported beside the headline metric, not as `value`."""
+    from estts.wavernn import WaveRNN
+    hp = configs.wavernn_hparams_22k()
+    m = WaveRNN.from_hparams(hp, precision=precision)
+    m.load_state_dict(weights.init_wavernn(hp, seed=1234))
+    rng = np.random.default_rng(1234)
+    mels = [rng.uniform(0, 1, size=(hp['num_mels'], 560)).astype(np.float32) for _ in range(64)]
+    m.generate_batch(mels[:1], True, 1000, 100, True, seed=0)          # warm-up (library load, allocator)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = m.generate_batch(mels, True, hp['voc_target'], hp['voc_overlap'], True, seed=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    samples = sum(len(o) for o in outs)
+    audio = samples / hp['sample_rate']
+    steps = hp['voc_target'] + 2 * hp['voc_overlap']
+    return {'workload': 'WaveRNN RAW 9-bit mu-law, 64 utterances x 560 frames, hop 256 / 22050 Hz (BASELINE config 4)',
+            'rtf': dt / audio, 'wall_s': dt, 'audio_s': audio, 'samples_per_s': samples / dt, 'us_per_step': dt / steps * 1e6,
+            'sequences': int(sum(-(-(560 * 256 - 550) // 11550) for _ in range(64))), 'precision': precision,
+            'includes': 'conditioning network, 12100 sampling steps (50 per hipGraph replay), device-to-host copy, '
+                        'host cross-fade / mu-law expansion'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -92,28 +117,61 @@ def main():
                     help='skip materialising the attention maps the reference returns')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
+    ap.add_argument('--workload', default='forward', choices=['forward', 'gst'],
+                    help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
+                         "AutoregressiveTransformer (config 3; use --batch 32)")
+    ap.add_argument('--no-wavernn', action='store_true', help='skip the WaveRNN (config 4) pass reported under "wavernn"')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    from estts import parallel
+    rank, world, local_rank = parallel.env_ranks()
     torch.cuda.set_device(local_rank)
+    parallel.init_distributed('nccl')
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
-    cfg = configs.forward_config()
-    w = weights.init_forward_transformer(cfg, seed=1234)
     B, N, T = args.batch, args.tokens, args.frames
-    tokens, durs = synthetic_utterance(cfg, B, N, T, seed=1234 + rank)
-    model = ForwardTransformer(w, cfg, precision=args.precision)
-    tok_d = torch.from_numpy(tokens).cuda()
-    dur_d = torch.from_numpy(durs.astype(np.float32)).cuda()
     want_attn = not args.no_attention_weights
+    if args.workload == 'forward':
+        cfg = configs.forward_config()
+        w = weights.init_forward_transformer(cfg, seed=1234)
+        tokens, durs = synthetic_utterance(cfg, B, N, T, seed=1234 + rank)
+        model = ForwardTransformer(w, cfg, precision=args.precision)
+        tok_d = torch.from_numpy(tokens).cuda()
+        dur_d = torch.from_numpy(durs.astype(np.float32)).cuda()
 
-    def step():
-        return model.call(tok_d, target_durations=dur_d, max_frames=T, return_attention=want_attn)
+        def step():
+            return model.call(tok_d, target_durations=dur_d, max_frames=T, return_attention=want_attn)
+
+        def cpu_step():
+            from oracle import tts_torch as OT
+            return OT.forward_transformer_call(w, cfg, tokens, durs)['mel']
+        flops_per_step = B * algorithmic_flops(N, T)
+        label = (f'ForwardTransformer forward (non-AR, 80-mel), batch={B}, N={N} tokens, T={T} frames per GPU '
+                 f'(BASELINE config 2)')
+    else:
+        from estts.autoregressive_transformer import AutoregressiveTransformer
+        cfg = configs.autoregressive_config(system_type='style_text')
+        w = weights.init_autoregressive_transformer(cfg, seed=1234)
+        rng = np.random.default_rng(1234 + rank)
+        tokens = rng.integers(1, cfg['vocab_size'], size=(B, N)).astype(np.int32)
+        targets = np.clip(rng.normal(0, 1.5, size=(B, T, 80)), -4, 4).astype(np.float32)
+        model = AutoregressiveTransformer(w, cfg, precision=args.precision)
+        model.set_constants(reduction_factor=1)
+        tok_d, tar_d = torch.from_numpy(tokens).cuda(), torch.from_numpy(targets).cuda()
+
+        def step():
+            o = model.call(tok_d, tar_d, None, return_attention=want_attn)
+            o['mel'] = o['final_output']
+            return o
+
+        def cpu_step():
+            from oracle import tts_torch as OT
+            return OT.autoregressive_call(w, cfg, tokens, targets, None, r=1)['final_output']
+        flops_per_step = B * 9.6e9 * (T / 600.0)
+        label = (f'GST reference encoder + 10 style tokens + teacher-forced AutoregressiveTransformer (style_text, r=1), '
+                 f'batch={B}, N={N}, T={T} per GPU (BASELINE config 3)')
 
     out = step()
     torch.cuda.synchronize()
@@ -122,18 +180,19 @@ def main():
     cpu = None
     mel_l1 = None
     if rank == 0 and not args.no_cpu_baseline:
-        from oracle import tts_torch as OT
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
-        OT.forward_transformer_call(w, cfg, tokens, durs)                 # warm-up
+        if B * T <= 2400:
+            cpu_step()                                                    # warm-up
         runs, t_cpu = 0, 0.0
         while runs < 3 and t_cpu < 20.0:
             t0 = time.perf_counter()
-            ref = OT.forward_transformer_call(w, cfg, tokens, durs)
+            ref_mel = cpu_step()
             t_cpu += time.perf_counter() - t0
             runs += 1
-        mel_l1 = float(np.abs(out['mel'].cpu().numpy() - ref['mel']).mean())
+        mel_l1 = float(np.abs(out['mel'].cpu().numpy() - ref_mel).mean())
         cpu = {'value': B * T * runs / t_cpu, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': f'{runs} forward(s) of the same B={B}, N={N}, T={T} utterance, PyTorch CPU float32'}
+               'sample': f'{runs} pass(es) over the same batch (B={B}, N={N}, T={T}), op-for-op PyTorch CPU float32 '
+                         f'restatement (oracle/tts_torch.py)'}
 
     # per-kernel timing for the roofline entry
     # (the traced step's outputs must stay referenced while its launches are replayed: torch.cuda.graph() empties
@@ -212,15 +271,16 @@ def main():
             'metric': 'mel-frames/sec (fwd TransformerTTS)', 'value': value, 'unit': 'mel-frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'ForwardTransformer forward (non-AR, 80-mel), batch={B}, N={N} tokens, T={T} frames '
-                                   f'per GPU (BASELINE config 2); {args.precision} MFMA operands, fp32 accumulate',
+            'config': {'workload': f'{label}; {args.precision} MFMA operands, fp32 accumulate',
                        'global_batch': world * B, 'parallelism': f'replicas x{world}', 'hip_graph': graph is not None,
                        'attention_weights_materialised': want_attn, 'launches_per_step': len(rows)},
-            'algorithmic_tflops': world * B * algorithmic_flops(N, T) / (dt / args.steps) / 1e12,
+            'algorithmic_tflops': world * flops_per_step / (dt / args.steps) / 1e12,
             'mel_l1_vs_cpu_fp32': mel_l1,
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
+        if world == 1 and not args.no_wavernn:
+            line['wavernn'] = wavernn_pass(args.precision)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -281,3 +281,34 @@ class AutoregressiveTransformer:
         return out
 
     __call__ = call
+
+    def predict(self, inp, targets, spk_embed, max_length=1000, encode=True, verbose=True):
+        """AutoregressiveTransformer.py:265-296: encoder once, then the decoder is re-run on the growing output (as the
+        reference does, O(T^2) decoder work) until the stop class wins.  inp: phoneme string (encode=True) or token ids;
+        targets: reference mel (T, 80) for the style encoder or None; spk_embed: (1, D) or None."""
+        dev = self.device
+        if targets is not None:
+            targets = self.encode_ref(targets)
+        if spk_embed is not None:
+            spk_embed = torch.as_tensor(spk_embed, dtype=torch.float32, device=dev)[None]
+        if encode:
+            inp = self.encode_text(inp)
+        inp = torch.as_tensor(np.asarray(inp), dtype=torch.int32, device=dev)[None]
+        output = self.start_vec[None].clone()
+        output_concat = self.start_vec[None].clone()
+        out_dict = {}
+        enc, mask, text_attn, gst_attn, gst_tokens, _, _ = self.call_encoder(inp, targets, spk_embed)
+        for i in range(int(max_length // self.r) + 1):
+            model_out = self.call_decoder(enc, output, mask)
+            output = torch.cat([output, model_out['final_output'][:1, -1:, :]], dim=-2)
+            output_concat = torch.cat([output_concat, model_out['final_output'][:1, -self.r:, :]], dim=-2)
+            stop_pred = model_out['stop_prob'][:, -1].cpu()        # host decision every step, as in the reference
+            out_dict = {'mel': output_concat[0, 1:, :], 'decoder_attention': model_out['decoder_attention'],
+                        'text_encoder_attention': text_attn, 'gst_encoder_attention': gst_attn, 'gst_tokens': gst_tokens}
+            if verbose:
+                print(f'\rpred text mel: {i} stop out: {float(stop_pred[0, 2])}', end='')
+            if int(torch.argmax(stop_pred, dim=-1)) == self.stop_prob_index:
+                if verbose:
+                    print('Stopping')
+                break
+        return out_dict

@@ -30,10 +30,11 @@ def stop_trace():
     return t
 
 
-def _record(kind, info, fn, *args):
-    """Remember a launch; the relaunch callable passes whatever stream is current when it is called."""
+def _record(kind, info, fn, *args, keep=()):
+    """Remember a launch; the relaunch callable passes whatever stream is current when it is called.  `keep` holds the
+    tensors whose device pointers are baked into `args`, so that a replay can never touch freed memory."""
     if _trace is not None:
-        _trace.append((kind, info, lambda: fn(*args, _stream())))
+        _trace.append((kind, info, lambda _keep=tuple(keep): fn(*args, _stream())))
 
 
 def _stream():
@@ -156,7 +157,7 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     nsplit = 2 if precision == 'bf16x3' else 1
     _record('gemm', {'M': M, 'N': lin.N, 'K': lin.K, 'taps': lin.taps, 'flops': 2.0 * M * lin.N * lin.K,
                      'bytes': 4.0 * M * lin.K / lin.taps + 2.0 * nsplit * lin.N * lin.K + 4.0 * M * lin.N},
-            _lib.load().estts_gemm, a)
+            _lib.load().estts_gemm, a, keep=(x, out, residual, lin))
     return out
 
 
@@ -183,7 +184,7 @@ def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, at
     _record('attention', {'B': B, 'H': H, 'Lq': Lq, 'Lk': Lk, 'depth': depth, 'weights': attn is not None,
                           'flops': 4.0 * B * H * Lq * Lk * depth,
                           'bytes': 4.0 * B * H * depth * (2 * Lq + 2 * Lk) + (4.0 * B * H * Lq * Lk if attn is not None else 0)},
-            _lib.load().estts_attention, a)
+            _lib.load().estts_attention, a, keep=(q, k, v, ctx, attn, key_mask))
     return ctx
 
 
@@ -210,7 +211,7 @@ def rownorm(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=N
     check(_lib.load().estts_rownorm(a, _stream()), 'estts_rownorm')
     _record('rownorm', {'M': a.M, 'D': a.D, 'flops': 0.0,
                         'bytes': 4.0 * a.M * a.D * (1 + (residual is not None) + (out is not None))},
-            _lib.load().estts_rownorm, a)
+            _lib.load().estts_rownorm, a, keep=(y, out, residual, ln_a, ln_b, dot_w, dot_mask, dot_out))
     return out
 
 
@@ -227,7 +228,8 @@ def embed_posenc(tokens, emb, pe, pos_scalar, out, key_mask, scale, pe_stride=1)
                                          _stream()), 'estts_embed_posenc')
     _record('embed_posenc', {'B': B, 'N': N, 'D': D, 'flops': 0.0, 'bytes': 12.0 * B * N * D},
             _lib.load().estts_embed_posenc, tokens.data_ptr(), emb.data_ptr(), pe.data_ptr(), _ptr(pos_scalar),
-            out.data_ptr(), out.stride(0), _ptr(key_mask), B, N, D, scale, pe_stride)
+            out.data_ptr(), out.stride(0), _ptr(key_mask), B, N, D, scale, pe_stride,
+            keep=(tokens, emb, pe, pos_scalar, out, key_mask))
     return out
 
 
@@ -237,7 +239,8 @@ def durations_cumsum(dur, cum, totals):
     check(_lib.load().estts_durations_cumsum(dur.data_ptr(), cum.data_ptr(), totals.data_ptr(), B, N, _stream()),
           'estts_durations_cumsum')
     _record('durations_cumsum', {'B': B, 'N': N, 'flops': 0.0, 'bytes': 8.0 * B * N},
-            _lib.load().estts_durations_cumsum, dur.data_ptr(), cum.data_ptr(), totals.data_ptr(), B, N)
+            _lib.load().estts_durations_cumsum, dur.data_ptr(), cum.data_ptr(), totals.data_ptr(), B, N,
+            keep=(dur, cum, totals))
 
 
 def expand(x, cum, out, frame_mask, B, N, T, D):
@@ -245,7 +248,7 @@ def expand(x, cum, out, frame_mask, B, N, T, D):
                                    _ptr(frame_mask), B, N, T, D, _stream()), 'estts_expand')
     _record('expand', {'B': B, 'N': N, 'T': T, 'D': D, 'flops': 0.0, 'bytes': 8.0 * B * T * D},
             _lib.load().estts_expand, x.data_ptr(), x.stride(0), cum.data_ptr(), out.data_ptr(), out.stride(0),
-            _ptr(frame_mask), B, N, T, D)
+            _ptr(frame_mask), B, N, T, D, keep=(x, cum, out, frame_mask))
     return out
 
 

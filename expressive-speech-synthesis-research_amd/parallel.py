@@ -1,0 +1,65 @@
+"""One process per GPU: rendezvous from the torchrun environment, utterance sharding, rank reductions.
+
+Inference on this path shards by utterance (WaveRNN additionally by fold) with no data-path collective;
+collectives are used only to agree on timings / gather results.  Backend 'nccl' is RCCL on ROCm; 'gloo' is used
+by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_ranks():
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0')))
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed when WORLD_SIZE > 1.  Returns (rank, world, local_rank)."""
+    rank, world, local_rank = env_ranks()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+            kw['device_id'] = torch.device('cuda', local_rank)
+        dist.init_process_group(backend, **kw)
+    return rank, world, local_rank
+
+
+def shard_by_cost(costs, world):
+    """Greedy longest-first partition of items with the given costs (e.g. frames per utterance) into `world` shards of
+    near-equal total cost.  Returns a list of index lists, deterministic on every rank."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    shards, load = [[] for _ in range(world)], [0] * world
+    for i in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        shards[r].append(i)
+        load[r] += costs[i]
+    return [sorted(s) for s in shards]
+
+
+def max_over_ranks(value, device=None):
+    """Maximum of a Python float over all ranks (identity when not distributed)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_to_rank0(obj):
+    """Gather one picklable object per rank on rank 0 (list in rank order; None elsewhere)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(obj, out, dst=0)
+    return out
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

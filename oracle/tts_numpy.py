@@ -352,17 +352,11 @@ def reference_encoder_gst(x, w, prefix, n_convs, stride, num_heads):
     return out, attn
 
 
-def autoregressive_call(w, cfg, tokens, targets, spk_embed=None, r=1, dtype=np.float64):
-    """AutoregressiveTransformer.call (model/AutoregressiveTransformer.py:124-181,243-263), all training flags False.
-
-    targets: (B, T/r, 80) reduced, start-vector-prefixed decoder input (also fed to the style encoder,
-    as the reference does).  Returns final_output/mel_linear (B, T, 80), stop_prob (B, T, 3), attentions.
-    """
-    w = {k: np.asarray(v, dtype=dtype) for k, v in w.items()}
-    tokens = np.asarray(tokens)
-    targets = np.asarray(targets, dtype=dtype)
+def ar_encoder(w, cfg, tokens, style_targets, spk_embed):
+    """AutoregressiveTransformer.call_encoder (model/AutoregressiveTransformer.py:124-159), training flags False.
+    `w` already cast; returns (enc_output, enc_mask, text_attn, gst_attn, gst_out, text_out)."""
     st = cfg['system_type']
-    padding_mask = create_encoder_padding_mask(tokens).astype(dtype)
+    padding_mask = create_encoder_padding_mask(tokens).astype(w['text_encoder_prenet.embeddings'].dtype)
     x = w['text_encoder_prenet.embeddings'][tokens]
     text_out, text_attn = self_attention_blocks(
         x, padding_mask, w, 'text_encoder', cfg['encoder_model_dimension'], cfg['encoder_num_heads'],
@@ -372,15 +366,20 @@ def autoregressive_call(w, cfg, tokens, targets, spk_embed=None, r=1, dtype=np.f
     gst_out = gst_attn = None
     parts = [text_out]
     if st in ('speaker_style_text', 'style_text'):
-        gst_out, gst_attn = reference_encoder_gst(targets, w, 'style_encoder', len(cfg['ref_encoder_filters']),
+        gst_out, gst_attn = reference_encoder_gst(style_targets, w, 'style_encoder', len(cfg['ref_encoder_filters']),
                                                   cfg['ref_encoder_strides'], cfg['gst_multi_num_heads'])
         parts.append(np.tile(gst_out, (1, N, 1)))
     if st in ('speaker_style_text', 'speaker_text'):
-        parts.append(np.tile(np.asarray(spk_embed, dtype=dtype), (1, N, 1)))
+        parts.append(np.tile(np.asarray(spk_embed, dtype=text_out.dtype), (1, N, 1)))
     enc_output = np.concatenate(parts, axis=2)
-    enc_mask = create_mel_padding_mask(enc_output).astype(dtype)
+    enc_mask = create_mel_padding_mask(enc_output).astype(text_out.dtype)
+    return enc_output, enc_mask, text_attn, gst_attn, gst_out, text_out
 
-    dec_pad = create_mel_padding_mask(targets).astype(dtype)
+
+def ar_decoder(w, cfg, enc_output, enc_mask, targets, r):
+    """AutoregressiveTransformer.call_decoder (model/AutoregressiveTransformer.py:161-181), training=False,
+    decoder-prenet dropout rate 0."""
+    dec_pad = create_mel_padding_mask(targets).astype(targets.dtype)
     look = create_look_ahead_mask(targets.shape[1])
     combined = np.maximum(dec_pad, look)
     dec_in = decoder_prenet(targets, w, 'decoder_prenet')
@@ -392,10 +391,49 @@ def autoregressive_call(w, cfg, tokens, targets, spk_embed=None, r=1, dtype=np.f
     proj = dense(dec_out, w['final_proj_mel.kernel'], w['final_proj_mel.bias'])[:, :, :r * mc]
     mel = proj.reshape(proj.shape[0], proj.shape[1] * r, mc)
     out = postnet_ar(mel, w, 'decoder_postnet', cfg['postnet_conv_layers'])
-    out.update({'decoder_attention': dec_attn, 'decoder_output': dec_out, 'linear': mel,
-                'text_encoder_attention': text_attn, 'gst_encoder_attention': gst_attn,
+    out.update({'decoder_attention': dec_attn, 'decoder_output': dec_out, 'linear': mel})
+    return out
+
+
+def autoregressive_call(w, cfg, tokens, targets, spk_embed=None, r=1, dtype=np.float64):
+    """AutoregressiveTransformer.call (model/AutoregressiveTransformer.py:243-263), all training flags False.
+
+    targets: (B, T/r, 80) reduced, start-vector-prefixed decoder input (also fed to the style encoder,
+    as the reference does).  Returns final_output/mel_linear (B, T, 80), stop_prob (B, T, 3), attentions.
+    """
+    w = {k: np.asarray(v, dtype=dtype) for k, v in w.items()}
+    tokens = np.asarray(tokens)
+    targets = np.asarray(targets, dtype=dtype)
+    enc_output, enc_mask, text_attn, gst_attn, gst_out, text_out = ar_encoder(w, cfg, tokens, targets, spk_embed)
+    out = ar_decoder(w, cfg, enc_output, enc_mask, targets, r)
+    out.update({'text_encoder_attention': text_attn, 'gst_encoder_attention': gst_attn,
                 'gst_output': gst_out, 'text_enc_output': text_out})
     return out
+
+
+def autoregressive_predict(w, cfg, tokens, ref_mel, spk_embed=None, r=1, max_length=1000, dtype=np.float64):
+    """AutoregressiveTransformer.predict (model/AutoregressiveTransformer.py:265-296) for already-encoded tokens (N,):
+    encoder once, then the whole decoder re-run on the growing output until argmax(stop_prob) == 2.
+    ref_mel (T, 80) or None; spk_embed (1, D) or None.  Returns {'mel': (frames, 80), 'steps': int}."""
+    w = {k: np.asarray(v, dtype=dtype) for k, v in w.items()}
+    mc = cfg['mel_channels']
+    style = None
+    if ref_mel is not None:
+        style = np.asarray(ref_mel, dtype=dtype)[None][:, :-1][:, 0::r, :]
+    spk = None if spk_embed is None else np.asarray(spk_embed, dtype=dtype)[None]
+    inp = np.asarray(tokens)[None]
+    start = np.full((1, 1, mc), float(cfg['mel_start_value']), dtype=dtype)
+    output, output_concat = start.copy(), start.copy()
+    enc_output, enc_mask, *_ = ar_encoder(w, cfg, inp, style, spk)
+    steps = 0
+    for i in range(int(max_length // r) + 1):
+        out = ar_decoder(w, cfg, enc_output, enc_mask, output, r)
+        output = np.concatenate([output, out['final_output'][:1, -1:, :]], axis=-2)
+        output_concat = np.concatenate([output_concat, out['final_output'][:1, -r:, :]], axis=-2)
+        steps += 1
+        if int(np.argmax(out['stop_prob'][0, -1])) == 2:
+            break
+    return {'mel': output_concat[0, 1:, :], 'steps': steps}
 
 
 # --------------------------------------------------------------------------

@@ -119,3 +119,20 @@ def test_shipped_config_shapes_and_batch_independence():
     assert tuple(out['gst_output'].shape) == (B, 1, 256)
     alone = model.call(tokens[:1], targets[:1], None)
     assert (out['final_output'][0] - alone['final_output'][0]).abs().max().item() < 1e-5
+
+
+def test_predict_loop_vs_oracle():
+    """AR predict: same number of decoder steps and the same mel as the oracle loop (stop decided by argmax of the
+    stop logits; the stop bias is raised so that the random-weight model stops within a few steps)."""
+    cfg = small_cfg('style_text')
+    w = weights.init_autoregressive_transformer(cfg, seed=9)
+    w['decoder_postnet.stop_linear.bias'] = np.array([0.0, 0.3, 0.25], np.float32)
+    rng = np.random.default_rng(5)
+    tokens = rng.integers(1, cfg['vocab_size'], size=9)
+    ref_mel = np.clip(rng.normal(0, 1.5, size=(30, 80)), -4, 4).astype(np.float32)
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=2)
+    out = model.predict(tokens, ref_mel, None, max_length=24, encode=False, verbose=False)
+    ref = O.autoregressive_predict(w, cfg, tokens, ref_mel, None, r=2, max_length=24)
+    assert out['mel'].shape == ref['mel'].shape
+    assert np.abs(out['mel'].cpu().numpy() - ref['mel']).max() < 5e-4

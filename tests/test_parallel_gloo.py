@@ -1,0 +1,62 @@
+"""The N > 1 host path on CPU: two gloo ranks shard a list of utterances, agree on a max timing and gather results."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+import estts
+from estts import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import estts  # noqa: F401  (spawned interpreter)
+    from estts import parallel as par
+    r, w, _ = par.init_distributed('gloo')
+    frames = [560, 120, 870, 400, 400, 333, 640, 200, 555]
+    mine = par.shard_by_cost(frames, w)[r]
+    par.barrier()
+    t = par.max_over_ranks(1.0 + r)
+    got = par.gather_to_rank0({'rank': r, 'items': mine, 'frames': sum(frames[i] for i in mine)})
+    if r == 0:
+        q.put((t, got))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_sharding_and_reductions():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    t, got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert t == 2.0
+    items = sorted(i for g in got for i in g['items'])
+    assert items == list(range(9))                       # every utterance exactly once
+    loads = [g['frames'] for g in got]
+    assert abs(loads[0] - loads[1]) <= 120               # balanced to within the shortest utterance
+
+
+def test_shard_by_cost_is_deterministic_and_complete():
+    costs = list(np.random.default_rng(0).integers(100, 900, size=64))
+    a = parallel.shard_by_cost(costs, 8)
+    assert a == parallel.shard_by_cost(costs, 8)
+    assert sorted(i for s in a for i in s) == list(range(64))
+    loads = [sum(costs[i] for i in s) for s in a]
+    assert max(loads) - min(loads) < max(costs)
+    assert parallel.max_over_ranks(3.5) == 3.5 and parallel.gather_to_rank0('x') == ['x']
