@@ -57,6 +57,8 @@ def time_kernels(trace, reps=20, rounds=3):
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         for kind, info, fn in trace:
+            if ops._debug_sync:
+                print(f'[bench] timing {kind} {info}', file=sys.stderr, flush=True)
             fn()
             stream.synchronize()
             g = torch.cuda.CUDAGraph()

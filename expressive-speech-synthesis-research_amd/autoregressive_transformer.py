@@ -95,12 +95,9 @@ class ReferenceEncoderGST:
         h = torch.zeros(B, u, **f32)
         gh = torch.empty(B, 3 * u, **f32)
         hout = torch.empty(B, u, **f32)
-        lib = ops._lib.load()
         for t in range(steps):
             ops.gemm(h, self.gru_hh, gh, precision=precision)
-            g = gi3[:, t]
-            ops.check(lib.estts_gru_gates(g.data_ptr(), g.stride(0), gh.data_ptr(), gh.stride(0), h.data_ptr(), h.stride(0),
-                                          0, 0, hout.data_ptr(), hout.stride(0), B, u, ops._stream()), 'estts_gru_gates')
+            ops.gru_gates(gi3[:, t], gh, h, hout)
         qcat = torch.empty(B, u + self.sd, **f32)
         ops.gemm(h, self.rnn_proj, qcat[:, :u], precision=precision)
         q = torch.empty(B, self.sd, **f32)

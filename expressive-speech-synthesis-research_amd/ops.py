@@ -4,6 +4,8 @@ torch is used for device memory and the current stream only; no torch op
 computes anything on the hot path.
 """
 import math
+import os
+import sys
 
 import numpy as np
 import torch
@@ -16,6 +18,8 @@ PRECISION = {'bf16': 1, 'bf16x3': 3}
 # When set to a list, every op appends (kind, info dict, relaunch callable): used by bench.py to time
 # individual kernels with events and to price them against the roofline.
 _trace = None
+# ESTTS_DEBUG_SYNC=1: name every launch on stderr and wait for it, so that a faulting kernel is the last line printed
+_debug_sync = os.environ.get('ESTTS_DEBUG_SYNC', '') not in ('', '0')
 
 
 def start_trace():
@@ -33,6 +37,9 @@ def stop_trace():
 def _record(kind, info, fn, *args, keep=()):
     """Remember a launch; the relaunch callable passes whatever stream is current when it is called.  `keep` holds the
     tensors whose device pointers are baked into `args`, so that a replay can never touch freed memory."""
+    if _debug_sync:
+        print(f'[estts] {kind} {info}', file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
     if _trace is not None:
         _trace.append((kind, info, lambda _keep=tuple(keep): fn(*args, _stream())))
 
@@ -258,6 +265,23 @@ def conv2d_c1(x, w9, scale, bias, out, stride, pad_t, pad_l):
     _, Ho, Wo, Cout = out.shape
     check(_lib.load().estts_conv2d_c1(x.data_ptr(), w9.data_ptr(), scale.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
                                       Ho, Wo, Cout, stride, pad_t, pad_l, _stream()), 'estts_conv2d_c1')
+    _record('conv2d_c1', {'B': B, 'H': H, 'W': W, 'Cout': Cout, 'stride': stride, 'flops': 18.0 * B * Ho * Wo * Cout,
+                          'bytes': 4.0 * B * (H * W + Ho * Wo * Cout)},
+            _lib.load().estts_conv2d_c1, x.data_ptr(), w9.data_ptr(), scale.data_ptr(), bias.data_ptr(), out.data_ptr(), B, H, W,
+            Ho, Wo, Cout, stride, pad_t, pad_l, keep=(x, w9, scale, bias, out))
+    return out
+
+
+def gru_gates(gi, gh, h, out, x_res=None, M=None, H=None):
+    """GRU cell update from the two gate pre-activations (gate order r, z, n): h is replaced by the new state and
+    out = new state (+ x_res).  gi, gh: [M, >=3H] views; h, out, x_res: [M, >=H] views."""
+    M = h.shape[0] if M is None else M
+    H = h.shape[1] if H is None else H
+    args = (gi.data_ptr(), gi.stride(0), gh.data_ptr(), gh.stride(0), h.data_ptr(), h.stride(0), _ptr(x_res),
+            0 if x_res is None else x_res.stride(0), out.data_ptr(), out.stride(0), M, H)
+    check(_lib.load().estts_gru_gates(*args, _stream()), 'estts_gru_gates')
+    _record('gru_gates', {'M': M, 'H': H, 'flops': 0.0, 'bytes': 4.0 * M * H * (8 + (x_res is not None))},
+            _lib.load().estts_gru_gates, *args, keep=(gi, gh, h, out, x_res))
     return out
 
 
@@ -265,6 +289,8 @@ def row_zero_mask(x, mask, M=None, D=None):
     M = x.shape[0] if M is None else M
     D = x.shape[1] if D is None else D
     check(_lib.load().estts_row_zero_mask(x.data_ptr(), x.stride(0), mask.data_ptr(), M, D, _stream()), 'estts_row_zero_mask')
+    _record('row_zero_mask', {'M': M, 'D': D, 'flops': 0.0, 'bytes': 4.0 * M * (D + 1)},
+            _lib.load().estts_row_zero_mask, x.data_ptr(), x.stride(0), mask.data_ptr(), M, D, keep=(x, mask))
     return mask
 
 
