@@ -10,11 +10,11 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
-_vp, _i32, _f32 = C.c_void_p, C.c_int32, C.c_float
+_vp, _i32, _f32, _u32, _i64 = C.c_void_p, C.c_int32, C.c_float, C.c_uint32, C.c_int64
 
 
 class GemmArgs(C.Structure):
@@ -38,7 +38,33 @@ class AttentionArgs(C.Structure):
 class RownormArgs(C.Structure):
     _fields_ = [('y', _vp), ('ldy', _i32), ('x', _vp), ('ldx', _i32), ('ga', _vp), ('ba', _vp), ('gb', _vp), ('bb', _vp),
                 ('act', _i32), ('eps', _f32), ('out', _vp), ('ldo', _i32), ('M', _i32), ('D', _i32),
-                ('dot_w', _vp), ('dot_b', _f32), ('dot_scale', _f32), ('dot_mask', _vp), ('dot_out', _vp)]
+                ('dot_w', _vp), ('dot_b', _f32), ('dot_scale', _f32), ('dot_mask', _vp), ('dot_out', _vp),
+                ('drop_rate', _f32), ('drop_seed', _u32), ('drop_site', _u32)]
+
+
+class RownormBwdArgs(C.Structure):
+    _fields_ = [('f', RownormArgs), ('dout', _vp), ('lddout', _i32), ('ddot', _vp), ('dy', _vp), ('lddy', _i32),
+                ('dx', _vp), ('lddx', _i32), ('dx_accumulate', _i32), ('dga', _vp), ('dba', _vp), ('dgb', _vp), ('dbb', _vp),
+                ('ddot_w', _vp), ('ddot_b', _vp)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [('A', _vp), ('lda', _i32), ('seg_len', _i32), ('taps', _i32), ('c_per_tap', _i32), ('tap_lpad', _i32),
+                ('dY', _vp), ('lddy', _i32), ('M', _i32), ('N', _i32), ('K', _i32), ('dW', _vp), ('lddw', _i32),
+                ('precision', _i32), ('splits', _i32)]
+
+
+class AttentionBwdArgs(C.Structure):
+    _fields_ = [('q', _vp), ('ldq', _i32), ('k', _vp), ('ldk', _i32), ('v', _vp), ('ldv', _i32), ('ctx', _vp), ('ldo', _i32),
+                ('dctx', _vp), ('lddo', _i32), ('attn', _vp), ('delta', _vp), ('dq', _vp), ('lddq', _i32),
+                ('dk', _vp), ('lddk', _i32), ('dv', _vp), ('lddv', _i32),
+                ('B', _i32), ('H', _i32), ('Lq', _i32), ('Lk', _i32), ('depth', _i32), ('precision', _i32)]
+
+
+class ColreduceArgs(C.Structure):
+    _fields_ = [('z', _vp), ('ldz', _i32), ('g', _vp), ('ldg', _i32), ('a', _vp), ('lda', _i32), ('act', _i32),
+                ('mean', _vp), ('rstd', _vp), ('out0', _vp), ('out1', _vp), ('dy_out', _vp), ('lddy', _i32),
+                ('M', _i32), ('C', _i32), ('mode', _i32)]
 
 
 class WavernnPrepArgs(C.Structure):
@@ -70,6 +96,21 @@ SIGNATURES = {
     'estts_wavernn_prep': (_i32, [C.POINTER(WavernnPrepArgs), _vp]),
     'estts_gru_gates': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_wavernn_sample': (_i32, [C.POINTER(WavernnSampleArgs), _vp]),
+    'estts_pack_weight': (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'estts_gemm_wgrad': (_i32, [C.POINTER(WgradArgs), _vp]),
+    'estts_attention_bwd': (_i32, [C.POINTER(AttentionBwdArgs), _vp]),
+    'estts_rownorm_bwd': (_i32, [C.POINTER(RownormBwdArgs), _vp]),
+    'estts_colreduce': (_i32, [C.POINTER(ColreduceArgs), _vp]),
+    'estts_bn_finalize': (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'estts_affine_act': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    'estts_bn_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'estts_dropout': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _u32, _u32, _vp]),
+    'estts_axpby': (_i32, [_vp, _i32, _f32, _vp, _i32, _f32, _i32, _i32, _vp]),
+    'estts_head_scale': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
+    'estts_embed_bwd': (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
+    'estts_expand_bwd': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'estts_masked_mae_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
+    'estts_adam': (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
 _lib = None

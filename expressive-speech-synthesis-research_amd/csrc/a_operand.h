@@ -1,0 +1,52 @@
+// A-operand addressing shared by the forward / data-gradient product (gemm.hip) and the weight gradient (gemm_wgrad.hip).
+#pragma once
+#include "common.h"
+
+// ---- A operand addressing.  Output row m is pixel (img, ho, wo) of a [*, Ho, Wo] output grid; K index kk is
+// (tap, channel) with tap = (kh, kw); the source pixel is (ho * stride + kh - pad_top, wo * stride + kw - pad_left) of a
+// [*, H, W] input grid with lda floats per pixel; pixels outside the grid read as zero.  A dense layer is the 1 x 1 case
+// (H = Ho = 1, W = Wo = M), a 1-D convolution over rows has H = 1, W = seg_len, kw = taps.
+struct ARow {
+    int pix0;   // img * H * W
+    int h0, w0; // ho * stride - pad_top, wo * stride - pad_left
+    bool ok;
+};
+struct ATap {
+    int dh, dw, c;
+    bool ok;
+};
+
+__device__ __forceinline__ ARow make_arow(const estts_gemm_args& p, int m) {
+    ARow r;
+    r.ok = m < p.M;
+    const int img = m / p.conv_howo;
+    const int rem = m - img * p.conv_howo;
+    const int ho = rem / p.conv_wo;
+    const int wo = rem - ho * p.conv_wo;
+    r.pix0 = img * p.conv_h * p.conv_w;
+    r.h0 = ho * p.conv_stride - p.conv_pt;
+    r.w0 = wo * p.conv_stride - p.conv_pl;
+    return r;
+}
+
+__device__ __forceinline__ ATap make_atap(const estts_gemm_args& p, int kk) {
+    ATap t;
+    t.ok = kk < p.K;
+    int tap = 0;
+    t.c = kk;
+    if (p.taps > 1) {
+        tap = kk / p.c_per_tap;
+        t.c = kk - tap * p.c_per_tap;
+    }
+    t.dh = tap / p.conv_kw;
+    t.dw = tap - t.dh * p.conv_kw;
+    return t;
+}
+
+__device__ __forceinline__ float4 load_a(const estts_gemm_args& p, const ARow& r, const ATap& t) {
+    const int hi = r.h0 + t.dh;
+    const int wi = r.w0 + t.dw;
+    const bool ok = r.ok && t.ok && hi >= 0 && hi < p.conv_h && wi >= 0 && wi < p.conv_w;
+    const float* ap = p.A + (long)(r.pix0 + hi * p.conv_w + wi) * p.lda + t.c;
+    return ok ? *reinterpret_cast<const float4*>(ap) : make_float4(0.f, 0.f, 0.f, 0.f);
+}

@@ -56,3 +56,27 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
     hi = (__bf16)x;
     lo = (__bf16)(x - (float)hi);
 }
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+// keep decision of the counter-based dropout generator for element (row, col) of call site `site`
+__device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t site, uint32_t row, uint32_t col, float rate) {
+    uint32_t x = mix32(seed ^ (site * 0x9E3779B9u));
+    x = mix32(x ^ (row * 0x85EBCA6Bu + 0x27D4EB2Fu));
+    x = mix32(x ^ (col * 0xC2B2AE35u + 0x165667B1u));
+    return (x >> 8) * (1.0f / 16777216.0f) >= rate;
+}
+
+// derivative of the activation expressed through its OUTPUT r
+__device__ __forceinline__ float act_grad_from_output(float r, int act) {
+    if (act == ESTTS_ACT_RELU) return r > 0.0f ? 1.0f : 0.0f;
+    if (act == ESTTS_ACT_TANH) return 1.0f - r * r;
+    return 1.0f;
+}
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}

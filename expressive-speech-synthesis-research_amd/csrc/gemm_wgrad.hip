@@ -1,0 +1,196 @@
+// Weight gradient of a dense / 1-D convolution layer on the matrix cores (estts_gemm_wgrad in include/estts.h):
+//   dW[k, n] += sum_m A(m, k) * dY[m, n]          A(m, k) addressed as in estts_gemm (taps, segment borders)
+//
+// The reduction runs over the ROW index of both operands, so both MFMA operands are "transposed" views of row-major
+// tiles.  A workgroup owns a 64 (k) x 64 (n) tile of dW and walks its row range in steps of 32 rows: the A tile
+// [32][64] and the dY tile [32][64] are read with coalesced float4 loads (one step ahead), split into bf16 hi (+ lo)
+// and staged in LDS with 144-byte rows; every operand fragment then comes from the transposing ds_read_b64_tr_b16
+// (4 rows x 16 columns per 16-lane group, delivered column-per-lane).  Both operands use the same slot <-> row
+// permutation, so the product needs no reordering.  Row ranges are spread over gridDim.z and the partial tiles are
+// added to dW with hardware float atomics.
+#include "common.h"
+#include "a_operand.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+constexpr int LD = 72;  // bf16 per staged row (64 + 8 pad = 144 B)
+
+__device__ __forceinline__ bf16x8 tr_read_pair(const __bf16* p0, const __bf16* p1) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p1);
+    const s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, const float* dY, const int lddy, float* dW,
+                                                    const int lddw, const int rows_per_split) {
+    constexpr int NS = (NSPLIT > 1) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][32 * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ys[2][NS][32 * LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int m_begin = blockIdx.z * rows_per_split;
+    const int m_end = min(m_begin + rows_per_split, ga.M);
+
+    const int chunk = tid & 15;
+    const int r0 = tid >> 4;
+    const ATap tp = make_atap(ga, k0 + chunk * 4);
+    const int ncol = n0 + chunk * 4;
+    const bool ycol_ok = ncol < ga.N;
+
+    float4 a_reg[2], y_reg[2];
+    auto load = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + r0 + 16 * i;
+            const ARow ar = make_arow(ga, row);
+            a_reg[i] = load_a(ga, ar, tp);
+            y_reg[i] = (row < ga.M && ycol_ok) ? *reinterpret_cast<const float4*>(dY + (long)row * lddy + ncol)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = (r0 + 16 * i) * LD + chunk * 4;
+            const float av[4] = {a_reg[i].x, a_reg[i].y, a_reg[i].z, a_reg[i].w};
+            const float yv[4] = {y_reg[i].x, y_reg[i].y, y_reg[i].z, y_reg[i].w};
+            bf16x4 ah, al, yh, yl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 h, l;
+                split_bf16(av[e], h, l);
+                ah[e] = h;
+                al[e] = l;
+                split_bf16(yv[e], h, l);
+                yh[e] = h;
+                yl[e] = l;
+            }
+            *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = ah;
+            *reinterpret_cast<bf16x4*>(&Ys[buf][0][o]) = yh;
+            if (NS == 2) {
+                *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = al;
+                *reinterpret_cast<bf16x4*>(&Ys[buf][NS - 1][o]) = yl;
+            }
+        }
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frag = (4 * g + (i16 >> 2)) * LD + 4 * (i16 & 3);
+    if (m_begin < m_end) load(m_begin);
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+        stage(buf);
+        __syncthreads();
+        if (m0 + 32 < m_end) load(m0 + 32);
+        bf16x8 af[NS][2], yf[NS][2];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const __bf16* pa = &As[buf][s][frag + wk * 32 + i * 16];
+                const __bf16* py = &Ys[buf][s][frag + wn * 32 + i * 16];
+                af[s][i] = tr_read_pair(pa, pa + 16 * LD);
+                yf[s][i] = tr_read_pair(py, py + 16 * LD);
+            }
+        if (NS == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NS - 1][i], yf[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], yf[NS - 1][j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], yf[0][j], acc[i][j], 0, 0, 0);
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 32 + j * 16 + i16;
+            if (col >= ga.N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = k0 + wk * 32 + i * 16 + 4 * g + r;
+                if (row < ga.K) atomic_add_f32(dW + (long)row * lddw + col, acc[i][j][r]);
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_gemm_wgrad: null args");
+    const estts_wgrad_args& a = *args;
+    ESTTS_CHECK_ARG(a.A && a.dY && a.dW, "estts_gemm_wgrad: null A/dY/dW");
+    ESTTS_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "estts_gemm_wgrad: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    ESTTS_CHECK_ARG(a.precision == 1 || a.precision == 3, "estts_gemm_wgrad: precision must be 1 or 3");
+    ESTTS_CHECK_ARG(a.taps >= 1 && a.c_per_tap > 0 && a.taps * a.c_per_tap == a.K, "estts_gemm_wgrad: taps*c_per_tap != K");
+    ESTTS_CHECK_ARG((a.K & 3) == 0 && (a.c_per_tap & 3) == 0 && (a.lda & 3) == 0 && (a.N & 3) == 0 && (a.lddy & 3) == 0,
+                    "estts_gemm_wgrad: K, c_per_tap, N, lda and lddy must be multiples of 4");
+    ESTTS_CHECK_ARG((((uintptr_t)a.A | (uintptr_t)a.dY) & 15) == 0, "estts_gemm_wgrad: A / dY must be 16-byte aligned");
+    ESTTS_CHECK_ARG(a.seg_len == 0 || a.M % a.seg_len == 0, "estts_gemm_wgrad: M not a multiple of seg_len");
+    ESTTS_CHECK_ARG(a.lddy >= a.N && a.lddw >= a.N && (a.taps == 1 ? a.lda >= a.K : a.lda >= a.c_per_tap), "estts_gemm_wgrad: ld too small");
+
+    estts_gemm_args ga = {};
+    ga.A = a.A;
+    ga.lda = a.lda;
+    ga.taps = a.taps;
+    ga.c_per_tap = a.c_per_tap;
+    ga.M = a.M;
+    ga.N = a.N;
+    ga.K = a.K;
+    ga.conv_h = 1;
+    ga.conv_w = a.seg_len > 0 ? a.seg_len : a.M;
+    ga.conv_wo = ga.conv_w;
+    ga.conv_howo = ga.conv_w;
+    ga.conv_kw = a.taps;
+    ga.conv_stride = 1;
+    ga.conv_pt = 0;
+    ga.conv_pl = a.tap_lpad;
+
+    const int tiles = ((a.K + 63) / 64) * ((a.N + 63) / 64);
+    int splits = a.splits;
+    if (splits <= 0) {
+        splits = 1024 / tiles;
+        const int by_rows = (a.M + 255) / 256;
+        if (splits > by_rows) splits = by_rows;
+        if (splits > 64) splits = 64;
+        if (splits < 1) splits = 1;
+    }
+    const int steps = (a.M + 31) / 32;
+    const int rows_per_split = ((steps + splits - 1) / splits) * 32;
+    splits = (a.M + rows_per_split - 1) / rows_per_split;
+    dim3 grid((a.K + 63) / 64, (a.N + 63) / 64, splits);
+    if (a.precision == 3)
+        hipLaunchKernelGGL((wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split);
+    ESTTS_CHECK_LAUNCH("estts_gemm_wgrad");
+    return 0;
+}

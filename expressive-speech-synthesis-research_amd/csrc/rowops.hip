@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void embed_posenc_kernel(const int32_t* tokens
 }
 
 // ------------------------------------------------------------------------------------------
-// out = LNb(act(LNa(y)) + x), one wave per row, up to 4 float4 per lane (D <= 1024)
+// out = LNb(dropout(act(LNa(y))) + x), one wave per row, up to 4 float4 per lane (D <= 1024)
 __device__ __forceinline__ void ln_inplace(float4 (&v)[4], int nch, int lane, int dq, int D, const float* gamma,
                                            const float* beta, float eps) {
     float s = 0.f;
@@ -92,6 +92,14 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const estts_rownorm_args p
             v[i].y = apply_act(v[i].y, p.act);
             v[i].z = apply_act(v[i].z, p.act);
             v[i].w = apply_act(v[i].w, p.act);
+            if (p.drop_rate > 0.0f) {
+                const int c = (lane + 64 * i) * 4;
+                const float keep = 1.0f / (1.0f - p.drop_rate);
+                v[i].x = dropout_keep(p.drop_seed, p.drop_site, row, c, p.drop_rate) ? v[i].x * keep : 0.0f;
+                v[i].y = dropout_keep(p.drop_seed, p.drop_site, row, c + 1, p.drop_rate) ? v[i].y * keep : 0.0f;
+                v[i].z = dropout_keep(p.drop_seed, p.drop_site, row, c + 2, p.drop_rate) ? v[i].z * keep : 0.0f;
+                v[i].w = dropout_keep(p.drop_seed, p.drop_site, row, c + 3, p.drop_rate) ? v[i].w * keep : 0.0f;
+            }
             if (p.x) {
                 const float4 r = *reinterpret_cast<const float4*>(p.x + (long)row * p.ldx + (lane + 64 * i) * 4);
                 v[i].x += r.x;
@@ -273,6 +281,7 @@ extern "C" int estts_rownorm(const estts_rownorm_args* args, void* stream) {
     ESTTS_CHECK_ARG(!a.ga || a.ba, "estts_rownorm: ga without ba");
     ESTTS_CHECK_ARG(!a.gb || a.bb, "estts_rownorm: gb without bb");
     ESTTS_CHECK_ARG(!a.dot_w || a.dot_out, "estts_rownorm: dot_w without dot_out");
+    ESTTS_CHECK_ARG(a.drop_rate >= 0.0f && a.drop_rate < 1.0f, "estts_rownorm: drop_rate must be in [0, 1)");
     hipLaunchKernelGGL(rownorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_rownorm");
     return 0;

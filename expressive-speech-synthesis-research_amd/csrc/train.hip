@@ -1,0 +1,638 @@
+// Training-side HBM-bound kernels: weight re-packing, LayerNorm-combo backward, BatchNorm batch statistics and
+// backward, dropout, gradient plumbing (embedding, length regulator, loss) and Adam.
+// (see the "Training" block of include/estts.h)
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// master float32 [K][ld] -> bf16 hi/lo fragment-major.  One thread per (16-row block, 32-column step, lane): 8 values.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, int ld, int K, int N, int taps, int mode,
+                                                          uint16_t* hi, uint16_t* lo, int rows, int cols, int KS, long total) {
+    const int cin = K / taps;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int l = (int)(idx & 63);
+        const long blk = idx >> 6;
+        const int ks = (int)(blk % KS);
+        const int nb = (int)(blk / KS);
+        const int r = nb * 16 + (l & 15);          // destination row
+        const int c0 = ks * 32 + (l >> 4) * 8;     // first destination column
+        bf16x8 h, lw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            float v = 0.0f;
+            if (r < rows && c < cols) {
+                if (mode == 0) {
+                    v = src[(long)c * ld + r];
+                } else {
+                    const int tp = c / N;
+                    const int n = c - tp * N;
+                    v = src[(long)((taps - 1 - tp) * cin + r) * ld + n];
+                }
+            }
+            __bf16 a, b;
+            split_bf16(v, a, b);
+            h[j] = a;
+            lw[j] = b;
+        }
+        *reinterpret_cast<bf16x8*>(hi + idx * 8) = h;
+        *reinterpret_cast<bf16x8*>(lo + idx * 8) = lw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise helpers: thread per float4, grid-stride
+template <typename F>
+__device__ __forceinline__ void for_each_f4(int M, int D, F f) {
+    const int dq = D >> 2;
+    const long total = (long)M * dq;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / dq);
+        const int c = (int)(idx - (long)row * dq) * 4;
+        f(row, c);
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* z, int ldz, const float* scale, const float* shift,
+                                                         int act, const float* R, int ldr, float* out, int ldo, int M, int C) {
+    for_each_f4(M, C, [&](int row, int c) {
+        float4 v = ld4(z + (long)row * ldz + c);
+        if (scale) {
+            const float4 s = ld4(scale + c), b = ld4(shift + c);
+            v.x = v.x * s.x + b.x; v.y = v.y * s.y + b.y; v.z = v.z * s.z + b.z; v.w = v.w * s.w + b.w;
+        }
+        v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+        if (R) {
+            const float4 r = ld4(R + (long)row * ldr + c);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        st4(out + (long)row * ldo + c, v);
+    });
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* dy, int lddy, const float* z, int ldz, const float* mean,
+                                                     const float* rstd, const float* gamma, const float* dgamma,
+                                                     const float* dbeta, float* dz, int lddz, int M, int C) {
+    const float inv_m = 1.0f / (float)M;
+    for_each_f4(M, C, [&](int row, int c) {
+        const float4 g = ld4(dy + (long)row * lddy + c), x = ld4(z + (long)row * ldz + c);
+        const float4 mu = ld4(mean + c), rs = ld4(rstd + c), ga = ld4(gamma + c), dg = ld4(dgamma + c), db = ld4(dbeta + c);
+        float4 r;
+        r.x = ga.x * rs.x * (g.x - db.x * inv_m - (x.x - mu.x) * rs.x * dg.x * inv_m);
+        r.y = ga.y * rs.y * (g.y - db.y * inv_m - (x.y - mu.y) * rs.y * dg.y * inv_m);
+        r.z = ga.z * rs.z * (g.z - db.z * inv_m - (x.z - mu.z) * rs.z * dg.z * inv_m);
+        r.w = ga.w * rs.w * (g.w - db.w * inv_m - (x.w - mu.w) * rs.w * dg.w * inv_m);
+        st4(dz + (long)row * lddz + c, r);
+    });
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, int ldx, float* out, int ldo, int M, int D, float rate,
+                                                      uint32_t seed, uint32_t site) {
+    const float keep = 1.0f / (1.0f - rate);
+    for_each_f4(M, D, [&](int row, int c) {
+        float4 v = ld4(x + (long)row * ldx + c);
+        v.x = dropout_keep(seed, site, row, c, rate) ? v.x * keep : 0.0f;
+        v.y = dropout_keep(seed, site, row, c + 1, rate) ? v.y * keep : 0.0f;
+        v.z = dropout_keep(seed, site, row, c + 2, rate) ? v.z * keep : 0.0f;
+        v.w = dropout_keep(seed, site, row, c + 3, rate) ? v.w * keep : 0.0f;
+        st4(out + (long)row * ldo + c, v);
+    });
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* x, int ldx, float alpha, float* out, int ldo, float beta,
+                                                    int M, int D) {
+    for_each_f4(M, D, [&](int row, int c) {
+        const float4 a = ld4(x + (long)row * ldx + c);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (beta != 0.0f) o = ld4(out + (long)row * ldo + c);
+        o.x = beta * o.x + alpha * a.x; o.y = beta * o.y + alpha * a.y;
+        o.z = beta * o.z + alpha * a.z; o.w = beta * o.w + alpha * a.w;
+        st4(out + (long)row * ldo + c, o);
+    });
+}
+
+__global__ __launch_bounds__(256) void head_scale_kernel(float* x, int ldx, const float* scale, int rows, int L, int H,
+                                                         int depth) {
+    for_each_f4(rows, H * depth, [&](int row, int c) {
+        const float s = scale[(row / L) * H + c / depth];
+        float4 v = ld4(x + (long)row * ldx + c);
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        st4(x + (long)row * ldx + c, v);
+    });
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* tokens, const float* dx, int lddx, float* demb, int rows,
+                                                        int D, float scale) {
+    for_each_f4(rows, D, [&](int row, int c) {
+        const float4 g = ld4(dx + (long)row * lddx + c);
+        float* d = demb + (long)tokens[row] * D + c;
+        atomic_add_f32(d, g.x * scale);
+        atomic_add_f32(d + 1, g.y * scale);
+        atomic_add_f32(d + 2, g.z * scale);
+        atomic_add_f32(d + 3, g.w * scale);
+    });
+}
+
+// one wave per token
+__global__ __launch_bounds__(256) void expand_bwd_kernel(const float* dout, int lddo, const int32_t* cum, float* dx, int lddx,
+                                                         int B, int N, int T, int D) {
+    const int lane = threadIdx.x & 63;
+    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= (long)B * N) return;
+    const int b = (int)(tok / N);
+    const int n = (int)(tok - (long)b * N);
+    const int t0 = n > 0 ? cum[tok - 1] : 0;
+    const int t1 = min(cum[tok], T);
+    const int dq = D >> 2;
+    for (int ch = lane; ch < dq; ch += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = t0; t < t1; ++t) {
+            const float4 g = ld4(dout + ((long)b * T + t) * lddo + ch * 4);
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        }
+        st4(dx + tok * lddx + ch * 4, acc);
+    }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void masked_mae_bwd_kernel(const float* target, int ldt, const float* pred, int ldp,
+                                                             float* dpred, int lddp, int M, int C, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float nz = 0.f;
+    for (int c = lane; c < C; c += 64) nz += target[(long)row * ldt + c] != 0.0f ? 1.0f : 0.0f;
+    nz = wave_sum(nz);
+    const float w = nz > 0.f ? scale / ((float)M * (float)C) : 0.0f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = pred[(long)row * ldp + c] - target[(long)row * ldt + c];
+        dpred[(long)row * lddp + c] = d > 0.f ? w : (d < 0.f ? -w : 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* grad, float* m, float* v, long n4, float lr_t,
+                                                   float b1, float b2, float eps, float gs) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 g = ld4(grad + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4), pp = ld4(p + i * 4);
+        g.x *= gs; g.y *= gs; g.z *= gs; g.w *= gs;
+        mm.x = b1 * mm.x + (1.f - b1) * g.x; mm.y = b1 * mm.y + (1.f - b1) * g.y;
+        mm.z = b1 * mm.z + (1.f - b1) * g.z; mm.w = b1 * mm.w + (1.f - b1) * g.w;
+        vv.x = b2 * vv.x + (1.f - b2) * g.x * g.x; vv.y = b2 * vv.y + (1.f - b2) * g.y * g.y;
+        vv.z = b2 * vv.z + (1.f - b2) * g.z * g.z; vv.w = b2 * vv.w + (1.f - b2) * g.w * g.w;
+        pp.x -= lr_t * mm.x / (sqrtf(vv.x) + eps); pp.y -= lr_t * mm.y / (sqrtf(vv.y) + eps);
+        pp.z -= lr_t * mm.z / (sqrtf(vv.z) + eps); pp.w -= lr_t * mm.w / (sqrtf(vv.w) + eps);
+        st4(m + i * 4, mm); st4(v + i * 4, vv); st4(p + i * 4, pp);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// column reductions: a workgroup covers 256 columns (64 float4 chunks) x 4 row lanes; gridDim.y splits the rows
+__global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_args p) {
+    __shared__ float4 red[2][4][64];
+    const int chunk = threadIdx.x & 63;
+    const int rl = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + chunk) * 4;
+    const bool live = c < p.C;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (live) {
+        float4 k0 = s0, mu = s0, rs = s0;
+        if (p.mode == 0) k0 = ld4(p.z + c);
+        if (p.mode == 2) { mu = ld4(p.mean + c); rs = ld4(p.rstd + c); }
+        for (int row = blockIdx.y * 4 + rl; row < p.M; row += gridDim.y * 4) {
+            if (p.mode == 0) {
+                const float4 z = ld4(p.z + (long)row * p.ldz + c);
+                const float a = z.x - k0.x, b = z.y - k0.y, cc = z.z - k0.z, d = z.w - k0.w;
+                s0.x += a; s0.y += b; s0.z += cc; s0.w += d;
+                s1.x += a * a; s1.y += b * b; s1.z += cc * cc; s1.w += d * d;
+            } else {
+                float4 g = ld4(p.g + (long)row * p.ldg + c);
+                if (p.a) {
+                    const float4 a = ld4(p.a + (long)row * p.lda + c);
+                    g.x *= act_grad_from_output(a.x, p.act); g.y *= act_grad_from_output(a.y, p.act);
+                    g.z *= act_grad_from_output(a.z, p.act); g.w *= act_grad_from_output(a.w, p.act);
+                }
+                if (p.dy_out) st4(p.dy_out + (long)row * p.lddy + c, g);
+                s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+                if (p.mode == 2) {
+                    const float4 z = ld4(p.z + (long)row * p.ldz + c);
+                    s1.x += g.x * (z.x - mu.x) * rs.x; s1.y += g.y * (z.y - mu.y) * rs.y;
+                    s1.z += g.z * (z.z - mu.z) * rs.z; s1.w += g.w * (z.w - mu.w) * rs.w;
+                }
+            }
+        }
+    }
+    red[0][rl][chunk] = s0;
+    red[1][rl][chunk] = s1;
+    __syncthreads();
+    if (rl == 0 && live) {
+        float4 a = red[0][0][chunk], b = red[1][0][chunk];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            const float4 x = red[0][r][chunk], y = red[1][r][chunk];
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+        }
+        atomic_add_f32(p.out0 + c, a.x); atomic_add_f32(p.out0 + c + 1, a.y);
+        atomic_add_f32(p.out0 + c + 2, a.z); atomic_add_f32(p.out0 + c + 3, a.w);
+        if (p.mode != 1) {
+            atomic_add_f32(p.out1 + c, b.x); atomic_add_f32(p.out1 + c + 1, b.y);
+            atomic_add_f32(p.out1 + c + 2, b.z); atomic_add_f32(p.out1 + c + 3, b.w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* s0, const float* s1, const float* z0, int M, int C,
+                                                          float eps, float momentum, const float* gamma, const float* beta,
+                                                          float* moving_mean, float* moving_var, float* mean, float* rstd,
+                                                          float* scale, float* shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float a = s0[c] / (float)M;
+    const float mu = z0[c] + a;
+    const float var = fmaxf(s1[c] / (float)M - a * a, 0.0f);
+    const float rs = rsqrtf(var + eps);
+    mean[c] = mu;
+    rstd[c] = rs;
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+    if (moving_mean) {
+        moving_mean[c] = moving_mean[c] * momentum + mu * (1.0f - momentum);
+        moving_var[c] = moving_var[c] * momentum + var * (1.0f - momentum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of out = LNb(dropout(act(LNa(y))) + x) (+ the dot output); one wave per row, grid-stride over rows,
+// parameter gradients kept per lane and reduced through LDS at the end
+struct RowStats {
+    float mean, rstd;
+};
+
+__device__ __forceinline__ RowStats row_stats(const float4 (&v)[4], int nch, int lane, int dq, int D, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    RowStats r;
+    r.mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) {
+            const float a = v[i].x - r.mean, b = v[i].y - r.mean, c = v[i].z - r.mean, d = v[i].w - r.mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    r.rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    return r;
+}
+
+#define F4_OP(dst, expr)                 \
+    do {                                 \
+        { const int e = 0; dst.x = expr; } \
+        { const int e = 1; dst.y = expr; } \
+        { const int e = 2; dst.z = expr; } \
+        { const int e = 3; dst.w = expr; } \
+    } while (0)
+
+__device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
+
+// LayerNorm input gradient for one row: g = dout * gamma (in), xh = normalised input; returns rstd * (g - mean(g) - xh * mean(g xh))
+__device__ __forceinline__ void ln_bwd_row(float4 (&g)[4], const float4 (&xh)[4], int nch, int lane, int dq, int D, float rstd) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) {
+            a += g[i].x + g[i].y + g[i].z + g[i].w;
+            b += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+        }
+    a = wave_sum(a) / (float)D;
+    b = wave_sum(b) / (float)D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nch && lane + 64 * i < dq) F4_OP(g[i], rstd * (f4e(g[i], e) - a - f4e(xh[i], e) * b));
+}
+
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bwd_args p) {
+    __shared__ float red[4][1024];
+    const estts_rownorm_args& f = p.f;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int dq = f.D >> 2;
+    const int nch = (dq + 63) >> 6;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc_ga[4], acc_ba[4], acc_gb[4], acc_bb[4], acc_dw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc_ga[i] = acc_ba[i] = acc_gb[i] = acc_bb[i] = acc_dw[i] = zero;
+    float acc_db = 0.f;
+    const float keep = f.drop_rate > 0.f ? 1.0f / (1.0f - f.drop_rate) : 1.0f;
+
+    for (int row = blockIdx.x * 4 + wave; row < f.M; row += gridDim.x * 4) {
+        float4 xh1[4], r[4], xh2[4], d[4];
+        float rstd1 = 1.f, rstd2 = 1.f;
+        // ---- recompute the forward pass
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xh1[i] = r[i] = xh2[i] = d[i] = zero;
+            if (i < nch && lane + 64 * i < dq) r[i] = ld4(f.y + (long)row * f.ldy + (lane + 64 * i) * 4);
+        }
+        if (f.ga) {
+            const RowStats s = row_stats(r, nch, lane, dq, f.D, f.eps);
+            rstd1 = s.rstd;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nch && lane + 64 * i < dq) {
+                    const int c = (lane + 64 * i) * 4;
+                    const float4 ga = ld4(f.ga + c), ba = ld4(f.ba + c);
+                    F4_OP(xh1[i], (f4e(r[i], e) - s.mean) * s.rstd);
+                    F4_OP(r[i], f4e(xh1[i], e) * f4e(ga, e) + f4e(ba, e));
+                }
+        }
+        // r = act(a); km = dropout factor; s = r * km + x
+        float4 km[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            km[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (i < nch && lane + 64 * i < dq) {
+                const int c = (lane + 64 * i) * 4;
+                F4_OP(r[i], apply_act(f4e(r[i], e), f.act));
+                if (f.drop_rate > 0.f) F4_OP(km[i], dropout_keep(f.drop_seed, f.drop_site, row, c + e, f.drop_rate) ? keep : 0.0f);
+                F4_OP(xh2[i], f4e(r[i], e) * f4e(km[i], e));
+                if (f.x) {
+                    const float4 x = ld4(f.x + (long)row * f.ldx + c);
+                    F4_OP(xh2[i], f4e(xh2[i], e) + f4e(x, e));
+                }
+            }
+        }
+        float4 out[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = xh2[i];
+        if (f.gb) {
+            const RowStats s = row_stats(xh2, nch, lane, dq, f.D, f.eps);
+            rstd2 = s.rstd;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nch && lane + 64 * i < dq) {
+                    const int c = (lane + 64 * i) * 4;
+                    const float4 gb = ld4(f.gb + c), bb = ld4(f.bb + c);
+                    F4_OP(xh2[i], (f4e(xh2[i], e) - s.mean) * s.rstd);
+                    F4_OP(out[i], f4e(xh2[i], e) * f4e(gb, e) + f4e(bb, e));
+                }
+        }
+        // ---- gradient w.r.t. out
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (p.dout && i < nch && lane + 64 * i < dq) d[i] = ld4(p.dout + (long)row * p.lddout + (lane + 64 * i) * 4);
+        if (p.ddot) {
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nch && lane + 64 * i < dq) {
+                    const float4 w = ld4(f.dot_w + (lane + 64 * i) * 4);
+                    dot += out[i].x * w.x + out[i].y * w.y + out[i].z * w.z + out[i].w * w.w;
+                }
+            dot = wave_sum(dot) + f.dot_b;
+            float gm = dot > 0.f ? p.ddot[row] * f.dot_scale : 0.0f;
+            if (f.dot_mask) gm *= 1.0f - f.dot_mask[row];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nch && lane + 64 * i < dq) {
+                    const float4 w = ld4(f.dot_w + (lane + 64 * i) * 4);
+                    F4_OP(acc_dw[i], f4e(acc_dw[i], e) + gm * f4e(out[i], e));
+                    F4_OP(d[i], f4e(d[i], e) + gm * f4e(w, e));
+                }
+            if (lane == 0) acc_db += gm;
+        }
+        // ---- LNb
+        if (f.gb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nch && lane + 64 * i < dq) {
+                    const float4 gb = ld4(f.gb + (lane + 64 * i) * 4);
+                    F4_OP(acc_gb[i], f4e(acc_gb[i], e) + f4e(d[i], e) * f4e(xh2[i], e));
+                    F4_OP(acc_bb[i], f4e(acc_bb[i], e) + f4e(d[i], e));
+                    F4_OP(d[i], f4e(d[i], e) * f4e(gb, e));
+                }
+            ln_bwd_row(d, xh2, nch, lane, dq, f.D, rstd2);
+        }
+        // ---- residual branch, dropout and activation
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nch && lane + 64 * i < dq) {
+                const int c = (lane + 64 * i) * 4;
+                if (p.dx) {
+                    float4 o = d[i];
+                    if (p.dx_accumulate) {
+                        const float4 old = ld4(p.dx + (long)row * p.lddx + c);
+                        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                    }
+                    st4(p.dx + (long)row * p.lddx + c, o);
+                }
+                F4_OP(d[i], f4e(d[i], e) * f4e(km[i], e) * act_grad_from_output(f4e(r[i], e), f.act));
+            }
+        // ---- LNa
+        if (f.ga) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nch && lane + 64 * i < dq) {
+                    const float4 ga = ld4(f.ga + (lane + 64 * i) * 4);
+                    F4_OP(acc_ga[i], f4e(acc_ga[i], e) + f4e(d[i], e) * f4e(xh1[i], e));
+                    F4_OP(acc_ba[i], f4e(acc_ba[i], e) + f4e(d[i], e));
+                    F4_OP(d[i], f4e(d[i], e) * f4e(ga, e));
+                }
+            ln_bwd_row(d, xh1, nch, lane, dq, f.D, rstd1);
+        }
+        if (p.dy) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nch && lane + 64 * i < dq) st4(p.dy + (long)row * p.lddy + (lane + 64 * i) * 4, d[i]);
+        }
+    }
+
+    // ---- parameter gradients: sum the four waves through LDS, then one atomic per column and workgroup
+    auto flush = [&](const float4 (&acc)[4], float* dst) {
+        if (dst == nullptr) return;  // uniform across the workgroup
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nch && lane + 64 * i < dq) *reinterpret_cast<float4*>(&red[wave][(lane + 64 * i) * 4]) = acc[i];
+        __syncthreads();
+        for (int c = threadIdx.x; c < f.D; c += 256) atomic_add_f32(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    };
+    flush(acc_ga, f.ga ? p.dga : nullptr);
+    flush(acc_ba, f.ga ? p.dba : nullptr);
+    flush(acc_gb, f.gb ? p.dgb : nullptr);
+    flush(acc_bb, f.gb ? p.dbb : nullptr);
+    flush(acc_dw, p.ddot ? p.ddot_w : nullptr);
+    if (p.ddot && p.ddot_b) {
+        __syncthreads();
+        if (lane == 0) red[0][wave] = acc_db;
+        __syncthreads();
+        if (threadIdx.x == 0) atomic_add_f32(p.ddot_b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    }
+}
+
+int ew_grid(long total4) {
+    const long b = (total4 + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int estts_pack_weight(const float* src, int32_t ld_src, int32_t K, int32_t N, int32_t taps, int32_t mode,
+                                 uint16_t* hi, uint16_t* lo, void* stream) {
+    ESTTS_CHECK_ARG(src && hi && lo, "estts_pack_weight: null pointer");
+    ESTTS_CHECK_ARG(K > 0 && N > 0 && taps >= 1 && K % taps == 0 && ld_src >= N && (mode == 0 || mode == 1),
+                    "estts_pack_weight: bad shape K=%d N=%d taps=%d mode=%d", K, N, taps, mode);
+    const int rows = mode == 0 ? N : K / taps;
+    const int cols = mode == 0 ? K : taps * N;
+    const int rp = (rows + 63) / 64 * 64, cp = (cols + 63) / 64 * 64;
+    const long total = (long)(rp / 16) * (cp / 32) * 64;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, ld_src, K, N, taps,
+                       mode, hi, lo, rows, cols, cp / 32, total);
+    ESTTS_CHECK_LAUNCH("estts_pack_weight");
+    return 0;
+}
+
+extern "C" int estts_affine_act(const float* z, int32_t ldz, const float* scale, const float* shift, int32_t act,
+                                const float* R, int32_t ldr, float* out, int32_t ldo, int32_t M, int32_t C, void* stream) {
+    ESTTS_CHECK_ARG(z && out && M > 0 && C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (ldo & 3) == 0 && (!R || (ldr & 3) == 0),
+                    "estts_affine_act: bad arguments (C and ld must be multiples of 4)");
+    ESTTS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "estts_affine_act: scale and shift go together");
+    hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid((long)M * (C >> 2))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale,
+                       shift, act, R, ldr, out, ldo, M, C);
+    ESTTS_CHECK_LAUNCH("estts_affine_act");
+    return 0;
+}
+
+extern "C" int estts_bn_bwd(const float* dy, int32_t lddy, const float* z, int32_t ldz, const float* mean, const float* rstd,
+                            const float* gamma, const float* dgamma, const float* dbeta, float* dz, int32_t lddz, int32_t M,
+                            int32_t C, void* stream) {
+    ESTTS_CHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && dz, "estts_bn_bwd: null pointer");
+    ESTTS_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0 && (lddy & 3) == 0 && (ldz & 3) == 0 && (lddz & 3) == 0, "estts_bn_bwd: bad shape");
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(ew_grid((long)M * (C >> 2))), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz,
+                       mean, rstd, gamma, dgamma, dbeta, dz, lddz, M, C);
+    ESTTS_CHECK_LAUNCH("estts_bn_bwd");
+    return 0;
+}
+
+extern "C" int estts_dropout(const float* x, int32_t ldx, float* out, int32_t ldo, int32_t M, int32_t D, float rate,
+                             uint32_t seed, uint32_t site, void* stream) {
+    ESTTS_CHECK_ARG(x && out && M > 0 && D > 0 && (D & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "estts_dropout: bad shape");
+    ESTTS_CHECK_ARG(rate >= 0.0f && rate < 1.0f, "estts_dropout: rate must be in [0, 1)");
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid((long)M * (D >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, M,
+                       D, rate, seed, site);
+    ESTTS_CHECK_LAUNCH("estts_dropout");
+    return 0;
+}
+
+extern "C" int estts_axpby(const float* x, int32_t ldx, float alpha, float* out, int32_t ldo, float beta, int32_t M, int32_t D,
+                           void* stream) {
+    ESTTS_CHECK_ARG(x && out && M > 0 && D > 0 && (D & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "estts_axpby: bad shape");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid((long)M * (D >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, out,
+                       ldo, beta, M, D);
+    ESTTS_CHECK_LAUNCH("estts_axpby");
+    return 0;
+}
+
+extern "C" int estts_head_scale(float* x, int32_t ldx, const float* scale, int32_t B, int32_t L, int32_t H, int32_t depth,
+                                void* stream) {
+    ESTTS_CHECK_ARG(x && scale && B > 0 && L > 0 && H > 0 && depth > 0 && (depth & 3) == 0 && (ldx & 3) == 0 && ldx >= H * depth,
+                    "estts_head_scale: bad arguments");
+    hipLaunchKernelGGL(head_scale_kernel, dim3(ew_grid((long)B * L * (H * depth >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       scale, B * L, L, H, depth);
+    ESTTS_CHECK_LAUNCH("estts_head_scale");
+    return 0;
+}
+
+extern "C" int estts_embed_bwd(const int32_t* tokens, const float* dx, int32_t lddx, float* demb, int32_t B, int32_t N, int32_t D,
+                               float scale, void* stream) {
+    ESTTS_CHECK_ARG(tokens && dx && demb && B > 0 && N > 0 && D > 0 && (D & 3) == 0 && (lddx & 3) == 0, "estts_embed_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid((long)B * N * (D >> 2))), dim3(256), 0, (hipStream_t)stream, tokens, dx,
+                       lddx, demb, B * N, D, scale);
+    ESTTS_CHECK_LAUNCH("estts_embed_bwd");
+    return 0;
+}
+
+extern "C" int estts_expand_bwd(const float* dout, int32_t lddo, const int32_t* cum, float* dx, int32_t lddx, int32_t B, int32_t N,
+                                int32_t T, int32_t D, void* stream) {
+    ESTTS_CHECK_ARG(dout && cum && dx && B > 0 && N > 0 && T > 0 && D > 0 && (D & 3) == 0 && (lddo & 3) == 0 && (lddx & 3) == 0,
+                    "estts_expand_bwd: bad arguments");
+    const long toks = (long)B * N;
+    hipLaunchKernelGGL(expand_bwd_kernel, dim3((unsigned)((toks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, lddo, cum, dx,
+                       lddx, B, N, T, D);
+    ESTTS_CHECK_LAUNCH("estts_expand_bwd");
+    return 0;
+}
+
+extern "C" int estts_masked_mae_bwd(const float* target, int32_t ldt, const float* pred, int32_t ldp, float* dpred, int32_t lddp,
+                                    int32_t M, int32_t C, float scale, void* stream) {
+    ESTTS_CHECK_ARG(target && pred && dpred && M > 0 && C > 0 && ldt >= C && ldp >= C && lddp >= C, "estts_masked_mae_bwd: bad arguments");
+    hipLaunchKernelGGL(masked_mae_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, target, ldt, pred, ldp, dpred,
+                       lddp, M, C, scale);
+    ESTTS_CHECK_LAUNCH("estts_masked_mae_bwd");
+    return 0;
+}
+
+extern "C" int estts_adam(float* p, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                          float eps, float grad_scale, void* stream) {
+    ESTTS_CHECK_ARG(p && grad && m && v && n > 0 && (n & 3) == 0, "estts_adam: n must be a positive multiple of 4");
+    ESTTS_CHECK_ARG((((uintptr_t)p | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "estts_adam: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (long)(n / 4), lr_t,
+                       beta1, beta2, eps, grad_scale);
+    ESTTS_CHECK_LAUNCH("estts_adam");
+    return 0;
+}
+
+extern "C" int estts_colreduce(const estts_colreduce_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_colreduce: null args");
+    const estts_colreduce_args& a = *args;
+    ESTTS_CHECK_ARG(a.M > 0 && a.C > 0 && (a.C & 3) == 0 && a.mode >= 0 && a.mode <= 2, "estts_colreduce: bad shape / mode");
+    ESTTS_CHECK_ARG(a.out0 && (a.mode == 1 || a.out1), "estts_colreduce: null output");
+    if (a.mode == 0) {
+        ESTTS_CHECK_ARG(a.z && (a.ldz & 3) == 0, "estts_colreduce: mode 0 needs z");
+    } else {
+        ESTTS_CHECK_ARG(a.g && (a.ldg & 3) == 0 && (!a.a || (a.lda & 3) == 0) && (!a.dy_out || (a.lddy & 3) == 0),
+                        "estts_colreduce: modes 1/2 need g (ld multiples of 4)");
+        ESTTS_CHECK_ARG(a.mode == 1 || (a.z && a.mean && a.rstd && (a.ldz & 3) == 0), "estts_colreduce: mode 2 needs z, mean, rstd");
+    }
+    int ysplit = (a.M + 63) / 64;
+    if (ysplit > 128) ysplit = 128;
+    dim3 grid((a.C + 255) / 256, ysplit);
+    hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_CHECK_LAUNCH("estts_colreduce");
+    return 0;
+}
+
+extern "C" int estts_bn_finalize(const float* s0, const float* s1, const float* z0, int32_t M, int32_t C, float eps,
+                                 float momentum, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                                 float* mean, float* rstd, float* scale, float* shift, void* stream) {
+    ESTTS_CHECK_ARG(s0 && s1 && z0 && gamma && beta && mean && rstd && scale && shift && M > 0 && C > 0, "estts_bn_finalize: bad arguments");
+    ESTTS_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "estts_bn_finalize: moving statistics go together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s0, s1, z0, M, C, eps, momentum,
+                       gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift);
+    ESTTS_CHECK_LAUNCH("estts_bn_finalize");
+    return 0;
+}
+
+extern "C" int estts_rownorm_bwd(const estts_rownorm_bwd_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_rownorm_bwd: null args");
+    const estts_rownorm_bwd_args& a = *args;
+    const estts_rownorm_args& f = a.f;
+    ESTTS_CHECK_ARG(f.y && f.M > 0 && f.D > 0 && f.D <= 1024 && (f.D & 3) == 0, "estts_rownorm_bwd: D=%d must be <=1024, multiple of 4", f.D);
+    ESTTS_CHECK_ARG(a.dout || a.ddot, "estts_rownorm_bwd: no incoming gradient");
+    ESTTS_CHECK_ARG(!a.ddot || f.dot_w, "estts_rownorm_bwd: ddot without dot_w");
+    ESTTS_CHECK_ARG((f.ldy & 3) == 0 && (!f.x || (f.ldx & 3) == 0) && (!a.dout || (a.lddout & 3) == 0) && (!a.dy || (a.lddy & 3) == 0) &&
+                        (!a.dx || (a.lddx & 3) == 0),
+                    "estts_rownorm_bwd: ld not multiple of 4");
+    ESTTS_CHECK_ARG(!a.dx || f.x, "estts_rownorm_bwd: dx without a residual input");
+    int grid = (f.M + 3) / 4;
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_CHECK_LAUNCH("estts_rownorm_bwd");
+    return 0;
+}

@@ -195,9 +195,9 @@ def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, at
     return ctx
 
 
-def rownorm(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=None, D=None,
-            dot_w=None, dot_b=0.0, dot_scale=1.0, dot_mask=None, dot_out=None):
-    """out = LNb(act(LNa(y)) + residual); ln_a / ln_b are (gamma, beta) tensor pairs or None."""
+def rownorm_args(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=None, D=None,
+                 dot_w=None, dot_b=0.0, dot_scale=1.0, dot_mask=None, dot_out=None, dropout=None):
+    """Fills the argument block of estts_rownorm (also embedded in the backward call)."""
     _check_f32(y, 'y')
     a = RownormArgs()
     a.y, a.ldy = y.data_ptr(), y.stride(0)
@@ -214,7 +214,17 @@ def rownorm(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=N
     a.D = y.shape[1] if D is None else D
     if dot_w is not None:
         a.dot_w, a.dot_b, a.dot_scale = dot_w.data_ptr(), dot_b, dot_scale
-        a.dot_mask, a.dot_out = _ptr(dot_mask), dot_out.data_ptr()
+        a.dot_mask, a.dot_out = _ptr(dot_mask), _ptr(dot_out)
+    if dropout is not None and dropout[0] > 0.0:
+        a.drop_rate, a.drop_seed, a.drop_site = dropout
+    return a
+
+
+def rownorm(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=None, D=None,
+            dot_w=None, dot_b=0.0, dot_scale=1.0, dot_mask=None, dot_out=None, dropout=None):
+    """out = LNb(dropout(act(LNa(y))) + residual); ln_a / ln_b are (gamma, beta) tensor pairs or None;
+    dropout = (rate, seed, site) or None."""
+    a = rownorm_args(y, out, ln_a, act, residual, ln_b, eps, M, D, dot_w, dot_b, dot_scale, dot_mask, dot_out, dropout)
     check(_lib.load().estts_rownorm(a, _stream()), 'estts_rownorm')
     _record('rownorm', {'M': a.M, 'D': a.D, 'flops': 0.0,
                         'bytes': 4.0 * a.M * a.D * (1 + (residual is not None) + (out is not None))},

@@ -1,0 +1,189 @@
+"""Host-side wrappers of the training kernels (the "Training" block of include/estts.h): torch tensors in,
+HIP launches out.  No torch op computes anything here; torch provides memory, views and the stream."""
+import torch
+
+from . import _lib, ops
+from ._lib import (ACT, AttentionBwdArgs, ColreduceArgs, RownormBwdArgs, WgradArgs, check)
+from .ops import PRECISION, _ceil, _ptr, _stream
+
+
+class TrainLinear:
+    """A dense / conv1d layer whose float32 master weight lives in a caller-owned buffer (Keras layout: kernel
+    [K = taps * cin, N], row-major view; bias [N] or None).  Holds the two packed bf16 operands estts_gemm needs:
+    `fwd` (y = x W) and `bwd` (dx = dy W^T, taps flipped for convolutions); repack() refreshes them from the master
+    after an optimizer step.  `fwd` / `bwd` quack like ops.PackedLinear."""
+
+    class _Packed:
+        pass
+
+    def __init__(self, kernel, bias, taps=1, lpad=0, act=None):
+        if kernel.dim() != 2 or kernel.stride(1) != 1 or kernel.dtype != torch.float32:
+            raise ValueError('kernel must be a float32 [K, N] view with contiguous rows')
+        self.kernel, self.bias = kernel, bias
+        self.K, self.N = kernel.shape
+        if self.K % taps or (self.K // taps) % 4:
+            raise ValueError('K must be taps * cin with cin a multiple of 4')
+        self.taps, self.lpad = taps, lpad
+        self.cin = self.K // taps
+        dev = kernel.device
+        f, b = self._Packed(), self._Packed()
+        f.N, f.K, f.taps, f.lpad, f.c_per_tap = self.N, self.K, taps, lpad, self.cin
+        b.N, b.K, b.taps, b.lpad, b.c_per_tap = self.cin, taps * self.N, taps, taps - 1 - lpad, self.N
+        for pk, act_ in ((f, act), (b, None)):
+            pk.act = ACT[act_]
+            pk.ldw = _ceil(pk.K, 64)
+            n = _ceil(pk.N, 64) * pk.ldw
+            pk.w_hi = torch.empty(n, dtype=torch.int16, device=dev)
+            pk.w_lo = torch.empty(n, dtype=torch.int16, device=dev)
+            pk.s1 = pk.s2 = pk.b2 = None
+            pk.b1 = None
+        f.b1 = bias
+        self.fwd, self.bwd = f, b
+        if self.N % 4 and taps > 1:
+            raise ValueError('conv layers need N % 4 == 0 for the data gradient')
+        self.repack()
+
+    def repack(self):
+        lib = _lib.load()
+        k = self.kernel
+        check(lib.estts_pack_weight(k.data_ptr(), k.stride(0), self.K, self.N, self.taps, 0, self.fwd.w_hi.data_ptr(),
+                                    self.fwd.w_lo.data_ptr(), _stream()), 'estts_pack_weight')
+        check(lib.estts_pack_weight(k.data_ptr(), k.stride(0), self.K, self.N, self.taps, 1, self.bwd.w_hi.data_ptr(),
+                                    self.bwd.w_lo.data_ptr(), _stream()), 'estts_pack_weight')
+
+
+def wgrad(x, dy, dw, taps=1, lpad=0, M=None, seg_len=0, precision='bf16x3', splits=0):
+    """dw[K, N] += conv-unfolded(x)^T dy (float atomics; dw must be zero or hold a partial sum)."""
+    a = WgradArgs()
+    a.A, a.lda = x.data_ptr(), x.stride(0)
+    K, N = dw.shape
+    a.seg_len, a.taps, a.c_per_tap, a.tap_lpad = seg_len, taps, K // taps, lpad
+    a.dY, a.lddy = dy.data_ptr(), dy.stride(0)
+    a.M, a.N, a.K = (x.shape[0] if M is None else M), N, K
+    a.dW, a.lddw = dw.data_ptr(), dw.stride(0)
+    a.precision, a.splits = PRECISION[precision], splits
+    check(_lib.load().estts_gemm_wgrad(a, _stream()), 'estts_gemm_wgrad')
+
+
+def attention_bwd(q, k, v, ctx, dctx, attn, delta, dq, dk, dv, B, H, Lq, Lk, depth, precision='bf16x3'):
+    a = AttentionBwdArgs()
+    a.q, a.ldq, a.k, a.ldk, a.v, a.ldv = q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0)
+    a.ctx, a.ldo, a.dctx, a.lddo = ctx.data_ptr(), ctx.stride(0), dctx.data_ptr(), dctx.stride(0)
+    a.attn, a.delta = attn.data_ptr(), delta.data_ptr()
+    a.dq, a.lddq, a.dk, a.lddk, a.dv, a.lddv = (dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(),
+                                                dv.stride(0))
+    a.B, a.H, a.Lq, a.Lk, a.depth, a.precision = B, H, Lq, Lk, depth, PRECISION[precision]
+    if tuple(attn.shape) != (B, H, Lq, Lk) or not attn.is_contiguous() or delta.numel() < B * H * Lq:
+        raise ValueError('attention_bwd: attn must be contiguous [B,H,Lq,Lk], delta at least B*H*Lq floats')
+    check(_lib.load().estts_attention_bwd(a, _stream()), 'estts_attention_bwd')
+
+
+def rownorm_bwd(fwd_args, dout=None, ddot=None, dy=None, dx=None, dx_accumulate=False, dln_a=None, dln_b=None,
+                ddot_w=None, ddot_b=None):
+    """fwd_args: the RownormArgs of the forward call (ops.rownorm_args); dln_a / dln_b: (dgamma, dbeta) tensors."""
+    a = RownormBwdArgs()
+    a.f = fwd_args
+    if dout is not None:
+        a.dout, a.lddout = dout.data_ptr(), dout.stride(0)
+    a.ddot = _ptr(ddot)
+    if dy is not None:
+        a.dy, a.lddy = dy.data_ptr(), dy.stride(0)
+    if dx is not None:
+        a.dx, a.lddx, a.dx_accumulate = dx.data_ptr(), dx.stride(0), int(dx_accumulate)
+    if dln_a is not None:
+        a.dga, a.dba = dln_a[0].data_ptr(), dln_a[1].data_ptr()
+    if dln_b is not None:
+        a.dgb, a.dbb = dln_b[0].data_ptr(), dln_b[1].data_ptr()
+    a.ddot_w, a.ddot_b = _ptr(ddot_w), _ptr(ddot_b)
+    check(_lib.load().estts_rownorm_bwd(a, _stream()), 'estts_rownorm_bwd')
+
+
+def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None, rstd=None, dy_out=None, M=None, C=None):
+    r = ColreduceArgs()
+    ref = z if z is not None else g
+    r.M = ref.shape[0] if M is None else M
+    r.C = ref.shape[1] if C is None else C
+    if z is not None:
+        r.z, r.ldz = z.data_ptr(), z.stride(0)
+    if g is not None:
+        r.g, r.ldg = g.data_ptr(), g.stride(0)
+    if a is not None:
+        r.a, r.lda = a.data_ptr(), a.stride(0)
+    r.act = ACT[act]
+    r.mean, r.rstd = _ptr(mean), _ptr(rstd)
+    r.out0, r.out1 = out0.data_ptr(), _ptr(out1)
+    if dy_out is not None:
+        r.dy_out, r.lddy = dy_out.data_ptr(), dy_out.stride(0)
+    r.mode = mode
+    check(_lib.load().estts_colreduce(r, _stream()), 'estts_colreduce')
+
+
+def bn_finalize(s0, s1, z, M, C, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, eps=1e-3, momentum=0.99):
+    check(_lib.load().estts_bn_finalize(s0.data_ptr(), s1.data_ptr(), z.data_ptr(), M, C, eps, momentum, gamma.data_ptr(),
+                                        beta.data_ptr(), _ptr(moving_mean), _ptr(moving_var), mean.data_ptr(), rstd.data_ptr(),
+                                        scale.data_ptr(), shift.data_ptr(), _stream()), 'estts_bn_finalize')
+
+
+def affine_act(z, out, scale=None, shift=None, act=None, residual=None, M=None, C=None):
+    M = z.shape[0] if M is None else M
+    C = z.shape[1] if C is None else C
+    check(_lib.load().estts_affine_act(z.data_ptr(), z.stride(0), _ptr(scale), _ptr(shift), ACT[act], _ptr(residual),
+                                       0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, C,
+                                       _stream()), 'estts_affine_act')
+    return out
+
+
+def bn_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dz, M=None, C=None):
+    M = z.shape[0] if M is None else M
+    C = z.shape[1] if C is None else C
+    check(_lib.load().estts_bn_bwd(dy.data_ptr(), dy.stride(0), z.data_ptr(), z.stride(0), mean.data_ptr(), rstd.data_ptr(),
+                                   gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), dz.stride(0), M, C,
+                                   _stream()), 'estts_bn_bwd')
+    return dz
+
+
+def dropout(x, out, rate, seed, site, M=None, D=None):
+    M = x.shape[0] if M is None else M
+    D = x.shape[1] if D is None else D
+    check(_lib.load().estts_dropout(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), M, D, rate, seed, site, _stream()),
+          'estts_dropout')
+    return out
+
+
+def axpby(x, out, alpha=1.0, beta=1.0, M=None, D=None):
+    M = x.shape[0] if M is None else M
+    D = x.shape[1] if D is None else D
+    check(_lib.load().estts_axpby(x.data_ptr(), x.stride(0), alpha, out.data_ptr(), out.stride(0), beta, M, D, _stream()),
+          'estts_axpby')
+    return out
+
+
+def head_scale(x, scale, B, L, H, depth):
+    check(_lib.load().estts_head_scale(x.data_ptr(), x.stride(0), scale.data_ptr(), B, L, H, depth, _stream()), 'estts_head_scale')
+    return x
+
+
+def embed_bwd(tokens, dx, demb, scale):
+    B, N = tokens.shape
+    check(_lib.load().estts_embed_bwd(tokens.data_ptr(), dx.data_ptr(), dx.stride(0), demb.data_ptr(), B, N, demb.shape[1], scale,
+                                      _stream()), 'estts_embed_bwd')
+
+
+def expand_bwd(dout, cum, dx, B, N, T, D):
+    check(_lib.load().estts_expand_bwd(dout.data_ptr(), dout.stride(0), cum.data_ptr(), dx.data_ptr(), dx.stride(0), B, N, T, D,
+                                       _stream()), 'estts_expand_bwd')
+    return dx
+
+
+def masked_mae_bwd(target, pred, dpred, scale, M=None, C=None):
+    M = target.shape[0] if M is None else M
+    C = target.shape[1] if C is None else C
+    check(_lib.load().estts_masked_mae_bwd(target.data_ptr(), target.stride(0), pred.data_ptr(), pred.stride(0), dpred.data_ptr(),
+                                           dpred.stride(0), M, C, scale, _stream()), 'estts_masked_mae_bwd')
+    return dpred
+
+
+def adam(p, grad, m, v, lr_t, beta1=0.9, beta2=0.98, eps=1e-9, grad_scale=1.0):
+    n = p.numel()
+    check(_lib.load().estts_adam(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr_t, beta1, beta2, eps, grad_scale,
+                                 _stream()), 'estts_adam')

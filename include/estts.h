@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 5
+#define ESTTS_ABI_VERSION 6
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -137,8 +137,10 @@ typedef struct estts_attention_args {
 int estts_attention(const estts_attention_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Row-wise normalisation combos:   out = LNb( act( LNa(y) ) + x )
+ * Row-wise normalisation combos:   out = LNb( dropout( act( LNa(y) ) ) + x )
  * each stage optional; LayerNorm over the last axis (biased variance, eps inside the sqrt).
+ * dropout keeps element (m, c) when estts_dropout's generator says so for (drop_seed, drop_site, m, c) and
+ * scales kept values by 1 / (1 - drop_rate) (tf.keras.layers.Dropout in training mode).
  * Optionally also emits dot[m] = relu(out[m,:] . dot_w + dot_b) * dot_scale * (dot_mask ? 1 - dot_mask[m] : 1).
  *
  * Replaces: LayerNormalization chains at TransformerTTS/model/layers.py:65-71 (FFNResNorm),
@@ -159,6 +161,8 @@ typedef struct estts_rownorm_args {
     float dot_b; float dot_scale;
     const float* dot_mask;              /* [M] 1.0 = padded row */
     float* dot_out;                     /* [M] */
+    float drop_rate;                    /* training: Dropout between act and the residual add; 0 = none */
+    uint32_t drop_seed; uint32_t drop_site;
 } estts_rownorm_args;
 
 int estts_rownorm(const estts_rownorm_args* args, void* stream);
@@ -268,6 +272,143 @@ typedef struct estts_wavernn_sample_args {
 } estts_wavernn_sample_args;
 
 int estts_wavernn_sample(const estts_wavernn_sample_args* args, void* stream);
+
+/* ==========================================================================================
+ * Training (ForwardTransformer._train_step, pretrained_models/for_text_encoder/models.py:389-404:
+ * forward with training=True, loss, gradients, Adam).  Master weights are float32 in the Keras layout
+ * (kernel [K = taps * cin][N = cout], row-major), gradients have the same layout.
+ * ========================================================================================== */
+
+/* Re-packs a float32 master weight into the bf16 hi/lo fragment-major operand of estts_gemm.
+ * mode 0 (forward):  W[n][k]          = src[k * ld_src + n]                       n < N,  k < K
+ * mode 1 (data gradient of a dense / 1-D conv layer): with cin = K / taps,
+ *                    W'[c][t' * N + n] = src[((taps - 1 - t') * cin + c) * ld_src + n]   c < cin, t' < taps, n < N
+ *   so that dX = estts_gemm(A = dY, W', taps, c_per_tap = N, tap_lpad = taps - 1 - forward tap_lpad).
+ * Destination rows / columns are padded with zeros to multiples of 64 (hi and lo each
+ * ceil64(rows) * ceil64(cols) uint16). */
+int estts_pack_weight(const float* src, int32_t ld_src, int32_t K, int32_t N, int32_t taps, int32_t mode,
+                      uint16_t* hi, uint16_t* lo, void* stream);
+
+/* Weight gradient of a dense / 1-D conv layer on the matrix cores:
+ *   dW[tap * c_per_tap + c, n] += sum_m A[row(m) + tap - tap_lpad, c] * dY[m, n]
+ * (same row addressing as estts_gemm; float32 atomic accumulation: dW must be zeroed by the caller and the
+ * summation order is not fixed).  splits: number of row ranges worked on concurrently, 0 = automatic.
+ * Replaces: the kernel gradients tf.GradientTape produces for Dense / Conv1D (models.py:402). */
+typedef struct estts_wgrad_args {
+    const float* A; int32_t lda;
+    int32_t seg_len, taps, c_per_tap, tap_lpad;
+    const float* dY; int32_t lddy;
+    int32_t M, N, K;
+    float* dW; int32_t lddw;
+    int32_t precision;
+    int32_t splits;
+} estts_wgrad_args;
+
+int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream);
+
+/* Gradients of estts_attention given the saved weights P = attn [B, H, Lq, Lk] and dctx:
+ *   dV = P^T dctx;  dP = dctx V^T;  dS = P o (dP - delta);  dQ = dS K / sqrt(depth);  dK = dS^T Q / sqrt(depth)
+ * with delta[b, h, i] = sum_f dctx[b, i, h, f] * ctx[b, i, h, f]  (computed into `delta`, [B, H, Lq] floats).
+ * q/k/v/ctx/dctx and dq/dk/dv use the row layouts of estts_attention. */
+typedef struct estts_attention_bwd_args {
+    const float* q; int32_t ldq;
+    const float* k; int32_t ldk;
+    const float* v; int32_t ldv;
+    const float* ctx; int32_t ldo;
+    const float* dctx; int32_t lddo;
+    const float* attn;
+    float* delta;
+    float* dq; int32_t lddq;
+    float* dk; int32_t lddk;
+    float* dv; int32_t lddv;
+    int32_t B, H, Lq, Lk, depth;
+    int32_t precision;
+} estts_attention_bwd_args;
+
+int estts_attention_bwd(const estts_attention_bwd_args* args, void* stream);
+
+/* Backward of estts_rownorm (`f` describes the forward call; its `out` / `dot_out` are not read: everything is
+ * recomputed from y and x).  dout may be NULL when only the dot output carries gradient (ddot [M]).
+ * dy receives the gradient w.r.t. y; dx the gradient w.r.t. the residual x (added to dx when dx_accumulate).
+ * Parameter gradients are accumulated with float atomics (buffers zeroed by the caller; NULL = not wanted). */
+typedef struct estts_rownorm_bwd_args {
+    estts_rownorm_args f;
+    const float* dout; int32_t lddout;
+    const float* ddot;
+    float* dy; int32_t lddy;
+    float* dx; int32_t lddx; int32_t dx_accumulate;
+    float* dga; float* dba; float* dgb; float* dbb;
+    float* ddot_w; float* ddot_b;
+} estts_rownorm_bwd_args;
+
+int estts_rownorm_bwd(const estts_rownorm_bwd_args* args, void* stream);
+
+/* Column reductions over the rows of [M, C] matrices (float atomics into out0 / out1, zeroed by the caller).
+ * With dy[m, c] = g[m, c] * act'(a[m, c])  (a = the activation OUTPUT, NULL = identity):
+ *   mode 0 (moments):   out0[c] += sum_m (z - z[0, c]);  out1[c] += sum_m (z - z[0, c])^2
+ *   mode 1 (bias grad): out0[c] += sum_m dy
+ *   mode 2 (BatchNorm): out0[c] += sum_m dy;  out1[c] += sum_m dy * (z - mean[c]) * rstd[c]
+ * modes 1 / 2 also store dy to dy_out when it is not NULL (may alias g).
+ * Replaces: the batch statistics of tf.keras.layers.BatchNormalization(training=True) (layers.py:31,38,45,47)
+ * and the bias / gamma / beta gradients of the tape. */
+typedef struct estts_colreduce_args {
+    const float* z; int32_t ldz;
+    const float* g; int32_t ldg;
+    const float* a; int32_t lda;
+    int32_t act;
+    const float* mean; const float* rstd;
+    float* out0; float* out1;
+    float* dy_out; int32_t lddy;
+    int32_t M, C, mode;
+} estts_colreduce_args;
+
+int estts_colreduce(const estts_colreduce_args* args, void* stream);
+
+/* Batch statistics from mode-0 sums:  mean = z0 + s0 / M;  var = s1 / M - (s0 / M)^2 (biased);  rstd = (var + eps)^-1/2;
+ * scale = gamma * rstd;  shift = beta - mean * scale;  moving = moving * momentum + batch * (1 - momentum).
+ * z0 is row 0 of the reduced matrix (the shift used by mode 0). */
+int estts_bn_finalize(const float* s0, const float* s1, const float* z0, int32_t M, int32_t C, float eps, float momentum,
+                      const float* gamma, const float* beta, float* moving_mean, float* moving_var, float* mean,
+                      float* rstd, float* scale, float* shift, void* stream);
+
+/* out[m, c] = act(z[m, c] * scale[c] + shift[c]) + (R ? R[m, c] : 0)   (scale / shift NULL = 1 / 0) */
+int estts_affine_act(const float* z, int32_t ldz, const float* scale, const float* shift, int32_t act, const float* R,
+                     int32_t ldr, float* out, int32_t ldo, int32_t M, int32_t C, void* stream);
+
+/* BatchNorm input gradient:  dz = gamma * rstd * (dy - dbeta / M - (z - mean) * rstd * dgamma / M). */
+int estts_bn_bwd(const float* dy, int32_t lddy, const float* z, int32_t ldz, const float* mean, const float* rstd,
+                 const float* gamma, const float* dgamma, const float* dbeta, float* dz, int32_t lddz, int32_t M,
+                 int32_t C, void* stream);
+
+/* out[m, c] = x[m, c] * keep(seed, site, m, c) / (1 - rate): tf.keras.layers.Dropout in training mode with a
+ * counter-based generator (the same call on a gradient is the backward pass).  May run in place. */
+int estts_dropout(const float* x, int32_t ldx, float* out, int32_t ldo, int32_t M, int32_t D, float rate, uint32_t seed,
+                  uint32_t site, void* stream);
+
+/* out[m, c] = beta * out[m, c] + alpha * x[m, c]   (gradient accumulation on residual paths) */
+int estts_axpby(const float* x, int32_t ldx, float alpha, float* out, int32_t ldo, float beta, int32_t M, int32_t D,
+                void* stream);
+
+/* Per-(batch, head) scaling of the attention context (HeadDrop, layers.py:74-97): x[b*L + t, h*depth + f] *= scale[b*H + h]. */
+int estts_head_scale(float* x, int32_t ldx, const float* scale, int32_t B, int32_t L, int32_t H, int32_t depth, void* stream);
+
+/* demb[tokens[b, n], :] += dx[b * N + n, :] * scale  (float atomics): gradient of the Embedding lookup. */
+int estts_embed_bwd(const int32_t* tokens, const float* dx, int32_t lddx, float* demb, int32_t B, int32_t N, int32_t D,
+                    float scale, void* stream);
+
+/* Gradient of estts_expand: dx[b, n, :] = sum of dout[b, t, :] over the frames t of token n (cum[n-1] <= t < cum[n]). */
+int estts_expand_bwd(const float* dout, int32_t lddo, const int32_t* cum, float* dx, int32_t lddx, int32_t B, int32_t N,
+                     int32_t T, int32_t D, void* stream);
+
+/* Gradient of estts_masked_mae times `scale`: dpred[m, c] = scale * sign(pred - target) * any(target_row != 0) / (M * C). */
+int estts_masked_mae_bwd(const float* target, int32_t ldt, const float* pred, int32_t ldp, float* dpred, int32_t lddp,
+                         int32_t M, int32_t C, float scale, void* stream);
+
+/* Keras Adam (utils/config_manager.py:172-176) over flat buffers, gradient pre-scaled by grad_scale:
+ *   g = grad * grad_scale;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr_t * m / (sqrt(v) + eps)
+ * lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) is computed by the caller. */
+int estts_adam(float* p, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+               float eps, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

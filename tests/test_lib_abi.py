@@ -37,8 +37,21 @@ def test_abi_version_and_error_channel():
     assert rc != 0 and b'null args' in lib.estts_last_error()
 
 
-def test_struct_sizes_match_header_layout():
-    # pointer/int packing of the ctypes mirrors: 64-bit pointers, 4-byte ints, natural alignment
+def test_struct_sizes_match_header_layout(tmp_path):
+    """sizeof of every ctypes mirror equals what the C compiler computes from include/estts.h."""
+    import subprocess
+    pairs = {'estts_gemm_args': _lib.GemmArgs, 'estts_attention_args': _lib.AttentionArgs,
+             'estts_rownorm_args': _lib.RownormArgs, 'estts_wavernn_prep_args': _lib.WavernnPrepArgs,
+             'estts_wavernn_sample_args': _lib.WavernnSampleArgs, 'estts_wgrad_args': _lib.WgradArgs,
+             'estts_attention_bwd_args': _lib.AttentionBwdArgs, 'estts_rownorm_bwd_args': _lib.RownormBwdArgs,
+             'estts_colreduce_args': _lib.ColreduceArgs}
+    src = tmp_path / 'sizes.c'
+    src.write_text('#include <stdio.h>\n#include "estts.h"\nint main(void) {\n' +
+                   ''.join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + '  return 0;\n}\n')
+    exe = tmp_path / 'sizes'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for name, cls in pairs.items():
+        assert ctypes.sizeof(cls) == int(sizes[name]), name
     assert ctypes.sizeof(_lib.GemmArgs) == 200
-    assert ctypes.sizeof(_lib.AttentionArgs) == 112
-    assert ctypes.sizeof(_lib.RownormArgs) == 128
