@@ -39,7 +39,7 @@ class RownormArgs(C.Structure):
     _fields_ = [('y', _vp), ('ldy', _i32), ('x', _vp), ('ldx', _i32), ('ga', _vp), ('ba', _vp), ('gb', _vp), ('bb', _vp),
                 ('act', _i32), ('eps', _f32), ('out', _vp), ('ldo', _i32), ('M', _i32), ('D', _i32),
                 ('dot_w', _vp), ('dot_b', _f32), ('dot_scale', _f32), ('dot_mask', _vp), ('dot_out', _vp),
-                ('drop_rate', _f32), ('drop_seed', _u32), ('drop_site', _u32)]
+                ('drop_rate', _f32), ('drop_seed', _u32), ('drop_site', _u32), ('dot_b_ptr', _vp)]
 
 
 class RownormBwdArgs(C.Structure):
@@ -64,7 +64,7 @@ class AttentionBwdArgs(C.Structure):
 class ColreduceArgs(C.Structure):
     _fields_ = [('z', _vp), ('ldz', _i32), ('g', _vp), ('ldg', _i32), ('a', _vp), ('lda', _i32), ('act', _i32),
                 ('mean', _vp), ('rstd', _vp), ('out0', _vp), ('out1', _vp), ('dy_out', _vp), ('lddy', _i32),
-                ('M', _i32), ('C', _i32), ('mode', _i32)]
+                ('M', _i32), ('C', _i32), ('mode', _i32), ('scale', _vp), ('shift', _vp)]
 
 
 class WavernnPrepArgs(C.Structure):
@@ -102,7 +102,7 @@ SIGNATURES = {
     'estts_rownorm_bwd': (_i32, [C.POINTER(RownormBwdArgs), _vp]),
     'estts_colreduce': (_i32, [C.POINTER(ColreduceArgs), _vp]),
     'estts_bn_finalize': (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    'estts_affine_act': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    'estts_affine_act': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_bn_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'estts_dropout': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _u32, _u32, _vp]),
     'estts_axpby': (_i32, [_vp, _i32, _f32, _vp, _i32, _f32, _i32, _i32, _vp]),

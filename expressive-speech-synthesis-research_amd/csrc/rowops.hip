@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const estts_rownorm_args p
     if (p.dot_w) {
         dot = wave_sum(dot);
         if (lane == 0) {
-            float d = fmaxf(dot + p.dot_b, 0.0f) * p.dot_scale;
+            float d = fmaxf(dot + (p.dot_b_ptr ? p.dot_b_ptr[0] : p.dot_b), 0.0f) * p.dot_scale;
             if (p.dot_mask) d *= (1.0f - p.dot_mask[row]);
             p.dot_out[row] = d;
         }

@@ -58,7 +58,8 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* z, int ldz, const float* scale, const float* shift,
-                                                         int act, const float* R, int ldr, float* out, int ldo, int M, int C) {
+                                                         int act, const float* R, int ldr, int r_mod, float* out, int ldo, int M,
+                                                         int C) {
     for_each_f4(M, C, [&](int row, int c) {
         float4 v = ld4(z + (long)row * ldz + c);
         if (scale) {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* z, int ldz
         }
         v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
         if (R) {
-            const float4 r = ld4(R + (long)row * ldr + c);
+            const float4 r = ld4(R + (long)(r_mod > 0 ? row % r_mod : row) * ldr + c);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         st4(out + (long)row * ldo + c, v);
@@ -199,9 +200,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_ar
     const bool live = c < p.C;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     if (live) {
-        float4 k0 = s0, mu = s0, rs = s0;
+        float4 k0 = s0, mu = s0, rs = s0, sc = s0, sh = s0;
         if (p.mode == 0) k0 = ld4(p.z + c);
         if (p.mode == 2) { mu = ld4(p.mean + c); rs = ld4(p.rstd + c); }
+        const bool recompute = p.mode != 0 && !p.a && p.scale && p.act != ESTTS_ACT_NONE;
+        if (recompute) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
         for (int row = blockIdx.y * 4 + rl; row < p.M; row += gridDim.y * 4) {
             if (p.mode == 0) {
                 const float4 z = ld4(p.z + (long)row * p.ldz + c);
@@ -210,15 +213,21 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_ar
                 s1.x += a * a; s1.y += b * b; s1.z += cc * cc; s1.w += d * d;
             } else {
                 float4 g = ld4(p.g + (long)row * p.ldg + c);
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.mode == 2 || recompute) z = ld4(p.z + (long)row * p.ldz + c);
                 if (p.a) {
                     const float4 a = ld4(p.a + (long)row * p.lda + c);
                     g.x *= act_grad_from_output(a.x, p.act); g.y *= act_grad_from_output(a.y, p.act);
                     g.z *= act_grad_from_output(a.z, p.act); g.w *= act_grad_from_output(a.w, p.act);
+                } else if (recompute) {
+                    g.x *= act_grad_from_output(apply_act(z.x * sc.x + sh.x, p.act), p.act);
+                    g.y *= act_grad_from_output(apply_act(z.y * sc.y + sh.y, p.act), p.act);
+                    g.z *= act_grad_from_output(apply_act(z.z * sc.z + sh.z, p.act), p.act);
+                    g.w *= act_grad_from_output(apply_act(z.w * sc.w + sh.w, p.act), p.act);
                 }
                 if (p.dy_out) st4(p.dy_out + (long)row * p.lddy + c, g);
                 s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
                 if (p.mode == 2) {
-                    const float4 z = ld4(p.z + (long)row * p.ldz + c);
                     s1.x += g.x * (z.x - mu.x) * rs.x; s1.y += g.y * (z.y - mu.y) * rs.y;
                     s1.z += g.z * (z.z - mu.z) * rs.z; s1.w += g.w * (z.w - mu.w) * rs.w;
                 }
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
                     const float4 w = ld4(f.dot_w + (lane + 64 * i) * 4);
                     dot += out[i].x * w.x + out[i].y * w.y + out[i].z * w.z + out[i].w * w.w;
                 }
-            dot = wave_sum(dot) + f.dot_b;
+            dot = wave_sum(dot) + (f.dot_b_ptr ? f.dot_b_ptr[0] : f.dot_b);
             float gm = dot > 0.f ? p.ddot[row] * f.dot_scale : 0.0f;
             if (f.dot_mask) gm *= 1.0f - f.dot_mask[row];
 #pragma unroll
@@ -499,12 +508,13 @@ extern "C" int estts_pack_weight(const float* src, int32_t ld_src, int32_t K, in
 }
 
 extern "C" int estts_affine_act(const float* z, int32_t ldz, const float* scale, const float* shift, int32_t act,
-                                const float* R, int32_t ldr, float* out, int32_t ldo, int32_t M, int32_t C, void* stream) {
+                                const float* R, int32_t ldr, int32_t r_mod, float* out, int32_t ldo, int32_t M, int32_t C,
+                                void* stream) {
     ESTTS_CHECK_ARG(z && out && M > 0 && C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (ldo & 3) == 0 && (!R || (ldr & 3) == 0),
                     "estts_affine_act: bad arguments (C and ld must be multiples of 4)");
     ESTTS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "estts_affine_act: scale and shift go together");
     hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid((long)M * (C >> 2))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale,
-                       shift, act, R, ldr, out, ldo, M, C);
+                       shift, act, R, ldr, r_mod, out, ldo, M, C);
     ESTTS_CHECK_LAUNCH("estts_affine_act");
     return 0;
 }
@@ -599,6 +609,8 @@ extern "C" int estts_colreduce(const estts_colreduce_args* args, void* stream) {
         ESTTS_CHECK_ARG(a.g && (a.ldg & 3) == 0 && (!a.a || (a.lda & 3) == 0) && (!a.dy_out || (a.lddy & 3) == 0),
                         "estts_colreduce: modes 1/2 need g (ld multiples of 4)");
         ESTTS_CHECK_ARG(a.mode == 1 || (a.z && a.mean && a.rstd && (a.ldz & 3) == 0), "estts_colreduce: mode 2 needs z, mean, rstd");
+        ESTTS_CHECK_ARG((a.scale == nullptr) == (a.shift == nullptr), "estts_colreduce: scale and shift go together");
+        ESTTS_CHECK_ARG(!a.scale || a.a || (a.z && (a.ldz & 3) == 0), "estts_colreduce: recomputing the activation needs z");
     }
     int ysplit = (a.M + 63) / 64;
     if (ysplit > 128) ysplit = 128;

@@ -213,10 +213,17 @@ def rownorm_args(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6
     a.M = y.shape[0] if M is None else M
     a.D = y.shape[1] if D is None else D
     if dot_w is not None:
-        a.dot_w, a.dot_b, a.dot_scale = dot_w.data_ptr(), dot_b, dot_scale
+        a.dot_w, a.dot_scale = dot_w.data_ptr(), dot_scale
+        if torch.is_tensor(dot_b):
+            a.dot_b_ptr = dot_b.data_ptr()
+        else:
+            a.dot_b = dot_b
         a.dot_mask, a.dot_out = _ptr(dot_mask), _ptr(dot_out)
     if dropout is not None and dropout[0] > 0.0:
         a.drop_rate, a.drop_seed, a.drop_site = dropout
+    # the block holds raw device pointers: keep their tensors alive for as long as the block is (a backward pass
+    # re-reads y and the residual long after the forward call returned)
+    a._keep = (y, out, residual, ln_a, ln_b, dot_w, dot_b, dot_mask, dot_out)
     return a
 
 

@@ -1,8 +1,9 @@
-"""One process per GPU: rendezvous from the torchrun environment, utterance sharding, rank reductions.
+"""One process per GPU: rendezvous from the torchrun environment, utterance sharding, rank reductions, and the
+gradient exchange of data-parallel training.
 
 Inference on this path shards by utterance (WaveRNN additionally by fold) with no data-path collective;
-collectives are used only to agree on timings / gather results.  Backend 'nccl' is RCCL on ROCm; 'gloo' is used
-by the CPU tests.
+collectives are used only to agree on timings / gather results.  Training exchanges one flat gradient buffer per step
+(sum over ranks) in a few large buckets.  Backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.
 """
 import os
 
@@ -63,3 +64,31 @@ def gather_to_rank0(obj):
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def bucket_ranges(n, bucket_elems):
+    """[(start, end)] covering range(n) in pieces of at most bucket_elems elements."""
+    bucket_elems = max(int(bucket_elems), 1)
+    return [(o, min(o + bucket_elems, n)) for o in range(0, n, bucket_elems)]
+
+
+def allreduce_buckets(flat, bucket_elems, group=None, comm_stream=None):
+    """Sums the 1-D tensor `flat` over all ranks in place, one asynchronous all-reduce per bucket (xGMI rings are
+    per-link bound, so a handful of ~25 MB buckets keeps every link busy without the latency of many small calls).
+    On a GPU the collectives are issued on `comm_stream` (which first waits for the current stream) and the current
+    stream waits for them at the end; on the CPU (gloo) they are simply waited for.  No-op when not distributed."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    ranges = bucket_ranges(flat.numel(), bucket_elems)
+    if flat.is_cuda and comm_stream is not None:
+        cur = torch.cuda.current_stream(flat.device)
+        comm_stream.wait_stream(cur)
+        with torch.cuda.stream(comm_stream):
+            works = [dist.all_reduce(flat[a:b], group=group, async_op=True) for a, b in ranges]
+            for w in works:
+                w.wait()
+        cur.wait_stream(comm_stream)
+    else:
+        works = [dist.all_reduce(flat[a:b], group=group, async_op=True) for a, b in ranges]
+        for w in works:
+            w.wait()

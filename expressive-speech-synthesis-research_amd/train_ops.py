@@ -16,7 +16,7 @@ class TrainLinear:
     class _Packed:
         pass
 
-    def __init__(self, kernel, bias, taps=1, lpad=0, act=None):
+    def __init__(self, kernel, bias, taps=1, lpad=0, act=None, need_fwd=True, need_bwd=True):
         if kernel.dim() != 2 or kernel.stride(1) != 1 or kernel.dtype != torch.float32:
             raise ValueError('kernel must be a float32 [K, N] view with contiguous rows')
         self.kernel, self.bias = kernel, bias
@@ -29,27 +29,27 @@ class TrainLinear:
         f, b = self._Packed(), self._Packed()
         f.N, f.K, f.taps, f.lpad, f.c_per_tap = self.N, self.K, taps, lpad, self.cin
         b.N, b.K, b.taps, b.lpad, b.c_per_tap = self.cin, taps * self.N, taps, taps - 1 - lpad, self.N
-        for pk, act_ in ((f, act), (b, None)):
+        for pk, act_, need in ((f, act, need_fwd), (b, None, need_bwd)):
             pk.act = ACT[act_]
             pk.ldw = _ceil(pk.K, 64)
-            n = _ceil(pk.N, 64) * pk.ldw
+            n = _ceil(pk.N, 64) * pk.ldw if need else 0
             pk.w_hi = torch.empty(n, dtype=torch.int16, device=dev)
             pk.w_lo = torch.empty(n, dtype=torch.int16, device=dev)
             pk.s1 = pk.s2 = pk.b2 = None
             pk.b1 = None
         f.b1 = bias
-        self.fwd, self.bwd = f, b
-        if self.N % 4 and taps > 1:
-            raise ValueError('conv layers need N % 4 == 0 for the data gradient')
+        self.fwd, self.bwd = (f if need_fwd else None), (b if need_bwd else None)
+        if need_bwd and self.N % 4:
+            raise ValueError('the data gradient needs N % 4 == 0')
         self.repack()
 
     def repack(self):
         lib = _lib.load()
         k = self.kernel
-        check(lib.estts_pack_weight(k.data_ptr(), k.stride(0), self.K, self.N, self.taps, 0, self.fwd.w_hi.data_ptr(),
-                                    self.fwd.w_lo.data_ptr(), _stream()), 'estts_pack_weight')
-        check(lib.estts_pack_weight(k.data_ptr(), k.stride(0), self.K, self.N, self.taps, 1, self.bwd.w_hi.data_ptr(),
-                                    self.bwd.w_lo.data_ptr(), _stream()), 'estts_pack_weight')
+        for mode, pk in ((0, self.fwd), (1, self.bwd)):
+            if pk is not None:
+                check(lib.estts_pack_weight(k.data_ptr(), k.stride(0), self.K, self.N, self.taps, mode, pk.w_hi.data_ptr(),
+                                            pk.w_lo.data_ptr(), _stream()), 'estts_pack_weight')
 
 
 def wgrad(x, dy, dw, taps=1, lpad=0, M=None, seg_len=0, precision='bf16x3', splits=0):
@@ -98,7 +98,8 @@ def rownorm_bwd(fwd_args, dout=None, ddot=None, dy=None, dx=None, dx_accumulate=
     check(_lib.load().estts_rownorm_bwd(a, _stream()), 'estts_rownorm_bwd')
 
 
-def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None, rstd=None, dy_out=None, M=None, C=None):
+def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None, rstd=None, dy_out=None, M=None, C=None,
+              scale=None, shift=None):
     r = ColreduceArgs()
     ref = z if z is not None else g
     r.M = ref.shape[0] if M is None else M
@@ -115,6 +116,7 @@ def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None
     if dy_out is not None:
         r.dy_out, r.lddy = dy_out.data_ptr(), dy_out.stride(0)
     r.mode = mode
+    r.scale, r.shift = _ptr(scale), _ptr(shift)
     check(_lib.load().estts_colreduce(r, _stream()), 'estts_colreduce')
 
 
@@ -124,11 +126,11 @@ def bn_finalize(s0, s1, z, M, C, gamma, beta, moving_mean, moving_var, mean, rst
                                         scale.data_ptr(), shift.data_ptr(), _stream()), 'estts_bn_finalize')
 
 
-def affine_act(z, out, scale=None, shift=None, act=None, residual=None, M=None, C=None):
+def affine_act(z, out, scale=None, shift=None, act=None, residual=None, r_mod=0, M=None, C=None):
     M = z.shape[0] if M is None else M
     C = z.shape[1] if C is None else C
     check(_lib.load().estts_affine_act(z.data_ptr(), z.stride(0), _ptr(scale), _ptr(shift), ACT[act], _ptr(residual),
-                                       0 if residual is None else residual.stride(0), out.data_ptr(), out.stride(0), M, C,
+                                       0 if residual is None else residual.stride(0), r_mod, out.data_ptr(), out.stride(0), M, C,
                                        _stream()), 'estts_affine_act')
     return out
 

@@ -163,6 +163,7 @@ typedef struct estts_rownorm_args {
     float* dot_out;                     /* [M] */
     float drop_rate;                    /* training: Dropout between act and the residual add; 0 = none */
     uint32_t drop_seed; uint32_t drop_site;
+    const float* dot_b_ptr;             /* when not NULL, dot_b is read from device memory (a trainable bias) */
 } estts_rownorm_args;
 
 int estts_rownorm(const estts_rownorm_args* args, void* stream);
@@ -344,7 +345,8 @@ typedef struct estts_rownorm_bwd_args {
 int estts_rownorm_bwd(const estts_rownorm_bwd_args* args, void* stream);
 
 /* Column reductions over the rows of [M, C] matrices (float atomics into out0 / out1, zeroed by the caller).
- * With dy[m, c] = g[m, c] * act'(a[m, c])  (a = the activation OUTPUT, NULL = identity):
+ * With dy[m, c] = g[m, c] * act'(a[m, c]), where a = the activation OUTPUT: the stored tensor `a`, or, when a is
+ * NULL and scale / shift are given, recomputed as act(z * scale[c] + shift[c]); identity when neither is given:
  *   mode 0 (moments):   out0[c] += sum_m (z - z[0, c]);  out1[c] += sum_m (z - z[0, c])^2
  *   mode 1 (bias grad): out0[c] += sum_m dy
  *   mode 2 (BatchNorm): out0[c] += sum_m dy;  out1[c] += sum_m dy * (z - mean[c]) * rstd[c]
@@ -360,6 +362,7 @@ typedef struct estts_colreduce_args {
     float* out0; float* out1;
     float* dy_out; int32_t lddy;
     int32_t M, C, mode;
+    const float* scale; const float* shift;
 } estts_colreduce_args;
 
 int estts_colreduce(const estts_colreduce_args* args, void* stream);
@@ -371,9 +374,9 @@ int estts_bn_finalize(const float* s0, const float* s1, const float* z0, int32_t
                       const float* gamma, const float* beta, float* moving_mean, float* moving_var, float* mean,
                       float* rstd, float* scale, float* shift, void* stream);
 
-/* out[m, c] = act(z[m, c] * scale[c] + shift[c]) + (R ? R[m, c] : 0)   (scale / shift NULL = 1 / 0) */
+/* out[m, c] = act(z[m, c] * scale[c] + shift[c]) + (R ? R[r_mod ? m % r_mod : m, c] : 0)   (scale / shift NULL = 1 / 0) */
 int estts_affine_act(const float* z, int32_t ldz, const float* scale, const float* shift, int32_t act, const float* R,
-                     int32_t ldr, float* out, int32_t ldo, int32_t M, int32_t C, void* stream);
+                     int32_t ldr, int32_t r_mod, float* out, int32_t ldo, int32_t M, int32_t C, void* stream);
 
 /* BatchNorm input gradient:  dz = gamma * rstd * (dy - dbeta / M - (z - mean) * rstd * dgamma / M). */
 int estts_bn_bwd(const float* dy, int32_t lddy, const float* z, int32_t ldz, const float* mean, const float* rstd,

@@ -1,0 +1,168 @@
+"""CPU oracle for one ForwardTransformer training step (float64 PyTorch autograd).
+
+TEST INFRASTRUCTURE ONLY (tests/, bench.py's cpu_baseline leg).
+
+Restates ForwardTransformer._train_step (TransformerTTS/pretrained_models/for_text_encoder/models.py:389-404):
+`__call__(training=True)` -> 3 * masked MAE(mel) + masked MAE(duration) (utils/losses.py:41-47,71-78) -> gradients ->
+Keras Adam(beta_1 0.9, beta_2 0.98, epsilon 1e-9) (utils/config_manager.py:172-176).  Training-mode semantics restated
+from Keras: BatchNormalization uses the batch mean / biased variance over (batch, time) -- padded frames included -- and
+moves the moving statistics with momentum 0.99; the CNNResNorm inside a SelfAttentionConvBlock is called without
+`training=` (layers.py:211) and inherits training=True from the enclosing call; Dropout keeps with probability
+1 - rate and scales by 1 / (1 - rate); HeadDrop (layers.py:74-97) zeroes whole heads per sample and rescales.
+Random masks are INPUTS here (`masks`: list consumed in call order; `head_keep`: list of [B, H] arrays), so that the
+device path and this oracle can be run on identical draws.
+
+PARITY STATUS vs TensorFlow: unpinned (TensorFlow is not installable here); gradients come from autograd over the
+same forward restatement as oracle/tts_torch.py.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .tts_torch import _act, _conv1d, _pe
+
+
+class _Ctx:
+    def __init__(self, masks, head_keep, new_stats):
+        self.masks = list(masks) if masks is not None else None
+        self.head_keep = list(head_keep) if head_keep is not None else None
+        self.new_stats = new_stats
+
+    def dropout(self, x):
+        if self.masks is None:
+            return x
+        m = self.masks.pop(0)
+        return x * torch.as_tensor(np.asarray(m), dtype=x.dtype).reshape(x.shape)
+
+    def heads(self, ctx4):
+        if self.head_keep is None:
+            return ctx4
+        k = torch.as_tensor(np.asarray(self.head_keep.pop(0)), dtype=ctx4.dtype)
+        return ctx4 * k[:, :, None, None]
+
+
+def _ln(x, w, p):
+    return F.layer_norm(x, (x.shape[-1],), w[p + '.gamma'], w[p + '.beta'], 1e-6)
+
+
+def _bn_train(x, w, p, c):
+    """Keras BatchNormalization(training=True) on (B, T, C): statistics over (B, T), eps 1e-3, momentum 0.99."""
+    mean = x.mean(dim=(0, 1))
+    var = x.var(dim=(0, 1), unbiased=False)
+    c.new_stats[p + '.moving_mean'] = (w[p + '.moving_mean'] * 0.99 + mean.detach() * 0.01).numpy()
+    c.new_stats[p + '.moving_variance'] = (w[p + '.moving_variance'] * 0.99 + var.detach() * 0.01).numpy()
+    return (x - mean) / torch.sqrt(var + 1e-3) * w[p + '.gamma'] + w[p + '.beta']
+
+
+def _cnn_res_norm(x, w, p, n_layers, inner, last, padding, kind, c):
+    norm = (lambda t, q: _ln(t, w, q)) if kind == 'layer' else (lambda t, q: _bn_train(t, w, q, c))
+    y = x
+    for i in range(n_layers - 1):
+        y = _act(norm(_conv1d(y, w[f'{p}.conv{i}.kernel'], w[f'{p}.conv{i}.bias'], padding), f'{p}.norm{i}'), inner)
+    y = _conv1d(y, w[p + '.last_conv.kernel'], w[p + '.last_conv.bias'], padding)
+    y = _act(norm(y, f'{p}.norm{n_layers - 1}'), last)
+    return norm(x + y, f'{p}.norm{n_layers}')
+
+
+def _mha(x, mask, w, p, H, c):
+    B, L, _ = x.shape
+    q = F.linear(x, w[p + '.wq.kernel'].t(), w[p + '.wq.bias'])
+    k = F.linear(x, w[p + '.wk.kernel'].t(), w[p + '.wk.bias'])
+    v = F.linear(x, w[p + '.wv.kernel'].t(), w[p + '.wv.bias'])
+    d = q.shape[-1]
+    dh = d // H
+    q = q.view(B, L, H, dh).permute(0, 2, 1, 3)
+    k = k.view(B, L, H, dh).permute(0, 2, 3, 1)
+    v = v.view(B, L, H, dh).permute(0, 2, 1, 3)
+    logits = torch.matmul(q, k) / math.sqrt(dh) + mask * -1e9
+    pw = torch.softmax(logits, dim=-1)
+    ctx = c.heads(torch.matmul(pw, v)).permute(0, 2, 1, 3).reshape(B, L, d)
+    return F.linear(torch.cat([x, ctx], dim=-1), w[p + '.dense.kernel'].t(), w[p + '.dense.bias']), pw
+
+
+def _sa_blocks(x, mask, w, p, d, heads, dense_blocks, max_pos, c):
+    L = x.shape[1]
+    pe = _pe(max_pos, d, x.dtype)
+    x = x * math.sqrt(float(np.float32(d))) + w[p + '.pos_encoding_scalar'] * pe[None, :L, :]
+    x = c.dropout(x)
+    attn = []
+    for i, H in enumerate(heads):
+        b = f'{p}.block{i}'
+        a, pw = _mha(x, mask, w, b + '.sarn.mha', H, c)
+        x = _ln(c.dropout(_ln(a, w, b + '.sarn.ln')) + x, w, b + '.sarn.last_ln')
+        if i < dense_blocks:
+            y = F.linear(x, w[b + '.ffn.d1.kernel'].t(), w[b + '.ffn.d1.bias'])
+            y = F.linear(y, w[b + '.ffn.d2.kernel'].t(), w[b + '.ffn.d2.bias'])
+            y = c.dropout(torch.relu(_ln(y, w, b + '.ffn.ln')))
+            x = _ln(y + x, w, b + '.ffn.last_ln')
+        else:
+            x = _cnn_res_norm(x, w, b + '.conv', 2, 'relu', 'relu', 'same', 'batch', c)
+        attn.append(pw)
+    return x, attn
+
+
+def masked_mae(targets, pred):
+    """utils/losses.py:41-47: MeanAbsoluteError with sample_weight = any(target != 0), SUM_OVER_BATCH_SIZE."""
+    wgt = (targets != 0).any(dim=-1).to(pred.dtype)
+    per = (targets - pred).abs().mean(dim=-1) * wgt
+    return per.sum() / per.numel()
+
+
+def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=None):
+    """One forward + backward.  Returns dict(loss, mel_loss, dur_loss, mel, duration, grads {name: ndarray},
+    new_stats {moving statistic name: ndarray}); weights are NOT updated (see adam_update)."""
+    dt = torch.float64
+    wt = {}
+    for k, v in w.items():
+        t = torch.as_tensor(np.asarray(v)).to(dt)
+        trainable = not (k.endswith('moving_mean') or k.endswith('moving_variance') or k.endswith('pos_encoding_scalar'))
+        wt[k] = t.clone().requires_grad_(trainable)
+    c = _Ctx(masks, head_keep, {})
+    tokens = torch.as_tensor(np.asarray(tokens)).long()
+    B, N = tokens.shape
+    pad = (tokens == 0).to(dt)
+    x = F.embedding(tokens, wt['encoder_prenet.embeddings'])
+    x, enc_attn = _sa_blocks(x, pad[:, None, None, :], wt, 'encoder', cfg['encoder_model_dimension'], cfg['encoder_num_heads'],
+                             cfg['encoder_dense_blocks'], cfg['encoder_max_position_encoding'], c)
+    dp = _cnn_res_norm(x, wt, 'dur_pred.conv_blocks', 2, 'relu', 'relu', 'same', 'layer', c)
+    dur = torch.relu(F.linear(dp, wt['dur_pred.linear.kernel'].t(), wt['dur_pred.linear.bias']))
+    dur = (1.0 - pad)[:, :, None] * dur
+    td = torch.as_tensor(np.asarray(durations)).to(dt).reshape(B, N, 1)
+    reps = torch.round(td[..., 0]).long().clamp(min=0)
+    T = int(reps.sum(dim=1).max())
+    rows = []
+    for b in range(B):
+        e = torch.repeat_interleave(x[b], reps[b], dim=0)
+        rows.append(F.pad(e, (0, 0, 0, T - e.shape[0])))
+    mels = torch.stack(rows)
+    emask = (mels.detach().abs().sum(-1) == 0).to(dt)[:, None, None, :]
+    y = torch.relu(F.linear(mels, wt['decoder_prenet.d1.kernel'].t(), wt['decoder_prenet.d1.bias']))
+    y = torch.relu(F.linear(y, wt['decoder_prenet.d2.kernel'].t(), wt['decoder_prenet.d2.bias']))
+    y, dec_attn = _sa_blocks(y, emask, wt, 'decoder', cfg['decoder_model_dimension'], cfg['decoder_num_heads'],
+                             cfg['decoder_dense_blocks'], cfg['decoder_max_position_encoding'], c)
+    y = F.linear(y, wt['out.kernel'].t(), wt['out.bias'])
+    y = _cnn_res_norm(y, wt, 'decoder_postnet', cfg['postnet_conv_layers'], 'tanh', 'linear', 'same', 'batch', c)
+    mel_t = torch.as_tensor(np.asarray(mel)).to(dt)
+    l_mel = masked_mae(mel_t, y[:, :mel_t.shape[1]])
+    l_dur = masked_mae(td, dur)
+    loss = 3.0 * l_mel + 1.0 * l_dur
+    loss.backward()
+    grads = {k: (t.grad.numpy() if t.grad is not None else np.zeros(t.shape)) for k, t in wt.items() if t.requires_grad}
+    return {'loss': float(loss.detach()), 'mel_loss': float(l_mel.detach()), 'dur_loss': float(l_dur.detach()), 'mel': y.detach().numpy(),
+            'duration': dur.detach().numpy(), 'grads': grads, 'new_stats': c.new_stats,
+            'encoder_attention': [a.detach().numpy() for a in enc_attn], 'decoder_attention': [a.detach().numpy() for a in dec_attn]}
+
+
+def adam_update(w, grads, state, lr, t, beta1=0.9, beta2=0.98, eps=1e-9):
+    """Keras Adam, step t (1-based); state = {name: (m, v)} updated in place; returns the new weights."""
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    out = dict(w)
+    for k, g in grads.items():
+        m, v = state.get(k, (np.zeros_like(g), np.zeros_like(g)))
+        m = beta1 * m + (1 - beta1) * g
+        v = beta2 * v + (1 - beta2) * g * g
+        state[k] = (m, v)
+        out[k] = np.asarray(w[k], np.float64) - lr_t * m / (np.sqrt(v) + eps)
+    return out

@@ -249,7 +249,10 @@ def test_batchnorm_training_forward_backward(T, M, C, act):
     # backward
     g2 = torch.zeros(2, C, device='cuda')
     dy = torch.empty(M, C, device='cuda')
-    T.colreduce(2, g2[0], g2[1], z=zd, g=dev(dout), a=a if act else None, act=act, mean=mean, rstd=rstd, dy_out=dy)
+    if C == 512:       # activation output recomputed from z instead of read back
+        T.colreduce(2, g2[0], g2[1], z=zd, g=dev(dout), act=act, mean=mean, rstd=rstd, dy_out=dy, scale=scale, shift=shift)
+    else:
+        T.colreduce(2, g2[0], g2[1], z=zd, g=dev(dout), a=a if act else None, act=act, mean=mean, rstd=rstd, dy_out=dy)
     assert rel_err(g2[0], bt.grad) < 2e-5 and rel_err(g2[1], gt.grad) < 2e-5
     dz = torch.empty(M, C, device='cuda')
     T.bn_bwd(dy, zd, mean, rstd, gd, g2[1], g2[0], dz)

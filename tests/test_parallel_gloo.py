@@ -29,8 +29,12 @@ def _worker(rank, world, port, q):
     par.barrier()
     t = par.max_over_ranks(1.0 + r)
     got = par.gather_to_rank0({'rank': r, 'items': mine, 'frames': sum(frames[i] for i in mine)})
+    # data-parallel gradient exchange: flat buffer summed over ranks in buckets (odd sizes, last bucket short)
+    g = torch.arange(1003, dtype=torch.float32) * (r + 1)
+    par.allreduce_buckets(g, 250)
+    ok = bool(torch.equal(g, torch.arange(1003, dtype=torch.float32) * 3))
     if r == 0:
-        q.put((t, got))
+        q.put((t, got, ok))
     torch.distributed.destroy_process_group()
 
 
@@ -41,11 +45,12 @@ def test_two_rank_sharding_and_reductions():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    t, got = q.get(timeout=120)
+    t, got, grads_ok = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert t == 2.0
+    assert grads_ok
     items = sorted(i for g in got for i in g['items'])
     assert items == list(range(9))                       # every utterance exactly once
     loads = [g['frames'] for g in got]
@@ -60,3 +65,7 @@ def test_shard_by_cost_is_deterministic_and_complete():
     loads = [sum(costs[i] for i in s) for s in a]
     assert max(loads) - min(loads) < max(costs)
     assert parallel.max_over_ranks(3.5) == 3.5 and parallel.gather_to_rank0('x') == ['x']
+    assert parallel.bucket_ranges(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    g = torch.ones(5)
+    parallel.allreduce_buckets(g, 2)                      # not distributed: untouched
+    assert torch.equal(g, torch.ones(5))
