@@ -105,6 +105,121 @@ def wavernn_pass(precision):
                         'host cross-fade / mu-law expansion'}
 
 
+def roofline_from_trace(trace, kernel_table, rank):
+    """Times every traced launch in isolation and prices the dominant kernel group against its roofline."""
+    rows = time_kernels(trace)
+    total_iso = sum(r[2] for r in rows)
+    groups = {}
+    for kind, info, t in rows:
+        key = (kind,) + tuple(sorted((k, v) for k, v in info.items() if k not in ('flops', 'bytes')))
+        g = groups.setdefault(key, {'kind': kind, 'info': info, 'n': 0, 't': 0.0})
+        g['n'] += 1
+        g['t'] += t
+    dom = max(groups.values(), key=lambda g: g['t'])
+    if kernel_table and rank == 0:
+        for g in sorted(groups.values(), key=lambda g: -g['t']):
+            shape = {k: v for k, v in g['info'].items() if k not in ('flops', 'bytes')}
+            print(f"{g['kind']:13s} x{g['n']:2d} avg {g['t'] / g['n'] * 1e6:8.2f} us  share {g['t'] / total_iso:5.1%} "
+                  f"{g['info']['flops'] / (g['t'] / g['n']) / 1e12:8.2f} TF/s {g['info']['bytes'] / (g['t'] / g['n']) / 1e9:8.1f} GB/s {shape}",
+                  file=sys.stderr)
+        print(f'launches {len(rows)}, sum of isolated kernel times {total_iso * 1e6:.1f} us', file=sys.stderr)
+    avg = dom['t'] / dom['n']
+    if dom['kind'] in ('gemm', 'attention', 'wgrad', 'attention_bwd'):
+        roofline = {'bound': 'mfma', 'achieved': dom['info']['flops'] / avg / 1e12, 'peak': MFMA_BF16_PEAK / 1e12,
+                    'unit': 'TFLOP/s'}
+    else:
+        roofline = {'bound': 'hbm', 'achieved': dom['info']['bytes'] / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s'}
+    roofline['frac'] = roofline['achieved'] / roofline['peak']
+    roofline['traffic'] = None
+    roofline['kernel'] = dom['kind'] + ' ' + json.dumps({k: v for k, v in dom['info'].items() if k not in ('flops', 'bytes')})
+    roofline['avg_us'] = avg * 1e6
+    roofline['launches_per_step'] = dom['n']
+    roofline['share_of_step'] = dom['t'] / total_iso
+    return roofline, len(rows)
+
+
+def train_bench(args, rank, world, dist):
+    """BASELINE config 5: ForwardTransformer training step (forward with dropout / batch statistics, masked-MAE losses,
+    backward, bucketed gradient all-reduce over RCCL, Adam), `--batch` utterances per GPU (weak scaling)."""
+    from estts.forward_training import ForwardTransformerTrainer
+    B, N, T = args.batch, args.tokens, args.frames
+    cfg = configs.forward_config()
+    w = weights.init_forward_transformer(cfg, seed=1234)                 # same seed: identical replicas on every rank
+    tokens, durs = synthetic_utterance(cfg, B, N, T, seed=1234 + rank)
+    rng = np.random.default_rng(99 + rank)
+    mel = np.clip(rng.normal(0, 1.5, size=(B, T, cfg['mel_channels'])), -4, 4).astype(np.float32)
+    model = ForwardTransformerTrainer(w, cfg, precision=args.precision, seed=1234)
+    model.set_constants(learning_rate=1e-4, decoder_prenet_dropout=0.0, drop_n_heads=0)
+    tok_d = torch.from_numpy(tokens).cuda()
+    mel_d = torch.from_numpy(mel).cuda()
+
+    def step():
+        return model.train_step(tok_d, mel_d, durs)
+
+    out = step()
+    torch.cuda.synchronize()
+    loss0 = float(out['loss'])
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import tts_train_torch as OTT
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        bs = min(B, 2)
+        t0 = time.perf_counter()
+        OTT.forward_train_step(w, cfg, tokens[:bs], mel[:bs], durs[:bs], dtype=torch.float32)
+        t_cpu = time.perf_counter() - t0
+        cpu = {'value': bs * T / t_cpu, 'unit': 'mel-frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': f'1 training step (forward + autograd backward, no optimizer) on {bs} of the {B} utterances '
+                         f'(N={N}, T={T}), PyTorch CPU float32 restatement (oracle/tts_train_torch.py)'}
+
+    roofline, launches = None, None
+    if rank == 0 or world > 1:
+        ops.start_trace()
+        traced = step()
+        trace = ops.stop_trace()
+        torch.cuda.synchronize()
+        roofline, launches = roofline_from_trace(trace, args.kernel_table, rank)
+        del traced, trace
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt * 1e3 / args.steps
+    if rank == 0:
+        flops = 3.0 * B * algorithmic_flops(N, T)           # forward + data gradient + weight gradient
+        line = {
+            'metric': 'mel-frames/sec (ForwardTransformer training step)', 'value': world * B * T / (dt / args.steps),
+            'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'ForwardTransformer train_step: forward (dropout 0.1, BatchNorm batch statistics) + backward + '
+                                   f'gradient all-reduce + Adam, batch={B} per GPU, N={N}, T={T} (BASELINE config 5); '
+                                   f'{args.precision} MFMA operands, fp32 accumulate, fp32 master weights',
+                       'global_batch': world * B, 'parallelism': f'dp{world}', 'hip_graph': False,
+                       'launches_per_step': launches},
+            'steps_per_s': args.steps / dt, 'algorithmic_tflops': world * flops / (dt / args.steps) / 1e12,
+            'loss_first_step': loss0, 'loss_last_step': float(out['loss']),
+            'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -119,9 +234,10 @@ def main():
                     help='skip materialising the attention maps the reference returns')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
-    ap.add_argument('--workload', default='forward', choices=['forward', 'gst'],
+    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train'],
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
-                         "AutoregressiveTransformer (config 3; use --batch 32)")
+                         "AutoregressiveTransformer (config 3; use --batch 32); train: ForwardTransformer training step, "
+                         "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
     ap.add_argument('--no-wavernn', action='store_true', help='skip the WaveRNN (config 4) pass reported under "wavernn"')
     args = ap.parse_args()
 
@@ -135,6 +251,8 @@ def main():
 
     B, N, T = args.batch, args.tokens, args.frames
     want_attn = not args.no_attention_weights
+    if args.workload == 'train':
+        return train_bench(args, rank, world, dist)
     if args.workload == 'forward':
         cfg = configs.forward_config()
         w = weights.init_forward_transformer(cfg, seed=1234)
@@ -203,35 +321,8 @@ def main():
     traced_out = step()
     trace = ops.stop_trace()
     torch.cuda.synchronize()
-    rows = time_kernels(trace)
-    del traced_out
-    total_iso = sum(r[2] for r in rows)
-    groups = {}
-    for kind, info, t in rows:
-        key = (kind,) + tuple(sorted((k, v) for k, v in info.items() if k not in ('flops', 'bytes')))
-        g = groups.setdefault(key, {'kind': kind, 'info': info, 'n': 0, 't': 0.0})
-        g['n'] += 1
-        g['t'] += t
-    dom = max(groups.values(), key=lambda g: g['t'])
-    if args.kernel_table and rank == 0:
-        for g in sorted(groups.values(), key=lambda g: -g['t']):
-            shape = {k: v for k, v in g['info'].items() if k not in ('flops', 'bytes')}
-            print(f"{g['kind']:10s} x{g['n']:2d} avg {g['t'] / g['n'] * 1e6:8.2f} us  share {g['t'] / total_iso:5.1%} "
-                  f"{g['info']['flops'] / (g['t'] / g['n']) / 1e12:8.2f} TF/s {g['info']['bytes'] / (g['t'] / g['n']) / 1e9:8.1f} GB/s {shape}",
-                  file=sys.stderr)
-        print(f'launches {len(rows)}, sum of isolated kernel times {total_iso * 1e6:.1f} us', file=sys.stderr)
-    avg = dom['t'] / dom['n']
-    if dom['kind'] in ('gemm', 'attention'):
-        roofline = {'bound': 'mfma', 'achieved': dom['info']['flops'] / avg / 1e12, 'peak': MFMA_BF16_PEAK / 1e12,
-                    'unit': 'TFLOP/s'}
-    else:
-        roofline = {'bound': 'hbm', 'achieved': dom['info']['bytes'] / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s'}
-    roofline['frac'] = roofline['achieved'] / roofline['peak']
-    roofline['traffic'] = None
-    roofline['kernel'] = dom['kind'] + ' ' + json.dumps({k: v for k, v in dom['info'].items() if k not in ('flops', 'bytes')})
-    roofline['avg_us'] = avg * 1e6
-    roofline['launches_per_step'] = dom['n']
-    roofline['share_of_step'] = dom['t'] / total_iso
+    roofline, n_launches = roofline_from_trace(trace, args.kernel_table, rank)
+    del traced_out, trace
 
     # whole-forward timing
     graph = None
@@ -275,7 +366,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'{label}; {args.precision} MFMA operands, fp32 accumulate',
                        'global_batch': world * B, 'parallelism': f'replicas x{world}', 'hip_graph': graph is not None,
-                       'attention_weights_materialised': want_attn, 'launches_per_step': len(rows)},
+                       'attention_weights_materialised': want_attn, 'launches_per_step': n_launches},
             'algorithmic_tflops': world * flops_per_step / (dt / args.steps) / 1e12,
             'mel_l1_vs_cpu_fp32': mel_l1,
             'roofline': roofline,

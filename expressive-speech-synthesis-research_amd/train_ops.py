@@ -63,6 +63,9 @@ def wgrad(x, dy, dw, taps=1, lpad=0, M=None, seg_len=0, precision='bf16x3', spli
     a.dW, a.lddw = dw.data_ptr(), dw.stride(0)
     a.precision, a.splits = PRECISION[precision], splits
     check(_lib.load().estts_gemm_wgrad(a, _stream()), 'estts_gemm_wgrad')
+    ops._record('wgrad', {'M': a.M, 'N': N, 'K': K, 'taps': taps, 'flops': 2.0 * a.M * N * K,
+                          'bytes': 4.0 * a.M * (K / taps + N) + 4.0 * N * K},
+                _lib.load().estts_gemm_wgrad, a, keep=(x, dy, dw))
 
 
 def attention_bwd(q, k, v, ctx, dctx, attn, delta, dq, dk, dv, B, H, Lq, Lk, depth, precision='bf16x3'):
@@ -76,6 +79,9 @@ def attention_bwd(q, k, v, ctx, dctx, attn, delta, dq, dk, dv, B, H, Lq, Lk, dep
     if tuple(attn.shape) != (B, H, Lq, Lk) or not attn.is_contiguous() or delta.numel() < B * H * Lq:
         raise ValueError('attention_bwd: attn must be contiguous [B,H,Lq,Lk], delta at least B*H*Lq floats')
     check(_lib.load().estts_attention_bwd(a, _stream()), 'estts_attention_bwd')
+    ops._record('attention_bwd', {'B': B, 'H': H, 'Lq': Lq, 'Lk': Lk, 'depth': depth, 'flops': 10.0 * B * H * Lq * Lk * depth,
+                                  'bytes': 4.0 * B * H * (2.0 * Lq * Lk + depth * (4 * Lq + 4 * Lk))},
+                _lib.load().estts_attention_bwd, a, keep=(q, k, v, ctx, dctx, attn, delta, dq, dk, dv))
 
 
 def rownorm_bwd(fwd_args, dout=None, ddot=None, dy=None, dx=None, dx_accumulate=False, dln_a=None, dln_b=None,
@@ -189,3 +195,23 @@ def adam(p, grad, m, v, lr_t, beta1=0.9, beta2=0.98, eps=1e-9, grad_scale=1.0):
     n = p.numel()
     check(_lib.load().estts_adam(p.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr_t, beta1, beta2, eps, grad_scale,
                                  _stream()), 'estts_adam')
+
+
+def _debug_wrap(fn):
+    import functools
+    import sys
+
+    @functools.wraps(fn)
+    def inner(*a, **kw):
+        r = fn(*a, **kw)
+        shapes = [tuple(t.shape) for t in a if torch.is_tensor(t)]
+        print(f'[estts] {fn.__name__} {shapes}', file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        return r
+    return inner
+
+
+if ops._debug_sync:      # ESTTS_DEBUG_SYNC=1: name every training launch and wait for it (fault localisation)
+    for _n in ('wgrad', 'attention_bwd', 'rownorm_bwd', 'colreduce', 'bn_finalize', 'affine_act', 'bn_bwd', 'dropout', 'axpby',
+               'head_scale', 'embed_bwd', 'expand_bwd', 'masked_mae_bwd', 'adam'):
+        globals()[_n] = _debug_wrap(globals()[_n])

@@ -110,10 +110,10 @@ def masked_mae(targets, pred):
     return per.sum() / per.numel()
 
 
-def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=None):
+def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=None, dtype=torch.float64):
     """One forward + backward.  Returns dict(loss, mel_loss, dur_loss, mel, duration, grads {name: ndarray},
     new_stats {moving statistic name: ndarray}); weights are NOT updated (see adam_update)."""
-    dt = torch.float64
+    dt = dtype
     wt = {}
     for k, v in w.items():
         t = torch.as_tensor(np.asarray(v)).to(dt)
