@@ -12,13 +12,14 @@
 // A convolution is the same product with K = taps * c_per_tap: a K-chunk maps to (tap, channel), the A row
 // is shifted by tap - tap_lpad, and rows that leave the sequence read as zero.
 //
-// Two kernels:
-//  * gemm_small_kernel (tile id 4; batch-1 synthesis, M up to ~1k rows).  No barrier in the K loop: a
+// Three kernels:
+//  * gemm_big_kernel (tile id 5; batched synthesis and training, thousands of rows): see its own header below.
+//  * gemm_small_kernel (tile id 4; batch-1 synthesis and everything that does not fill the chip with 128 x 128 tiles).  No barrier in the K loop: a
 //    workgroup owns a 32 x 32 tile of C and its NW waves take interleaved K-steps.  Each wave loads its
 //    A slice (32 rows x 32 k) with coalesced float4 loads, converts, and turns it into MFMA fragments
 //    through a wave-private LDS image (80-byte rows: bank-conflict-free for ds_read_b128); the loads of the
 //    next K-step are in flight during the MFMAs.  Partial tiles are summed through LDS at the end.
-//  * gemm_kernel (tile ids 1-3; large M).  Classic LDS-staged BM x BN tile, K stages of 64, register
+//  * gemm_kernel (tile ids 1-3; explicit selection only).  Classic LDS-staged BM x BN tile, K stages of 64, register
 //    prefetch of the next stage, two LDS buffers, one barrier per stage.
 // Both support split-K over gridDim.z: every workgroup writes its float32 partial to a slab, takes a ticket
 // from a per-tile counter, and the last arriver sums the slabs and runs the epilogue.  Hand-off: every wave
@@ -418,6 +419,149 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p, cons
     }
 }
 
+// ======================================================================================================
+// big-tile kernel (tile id 5; M in the thousands): 128 x 128 tile of C per workgroup, K stages of 32, the four waves
+// each own 64 x 64 as 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 (lane l: r = l & 31, h = l >> 5 holds A[row r][k 8h..+7],
+// B[k 8h..+7][col r]; D[row (reg & 3) + 8 (reg >> 2) + 4 h][col r]).  Per MFMA this shape needs half the LDS fragment
+// reads of the 16 x 16 x 32 one, and the 128-wide tile halves the LDS stores per MFMA, which is what bounds the 64 x 64
+// kernel (the LDS store path moves ~75 B/clk/CU).  A is staged as in the other kernels (bf16 hi + lo, 80-byte rows);
+// W blocks are copied to LDS in their packed order and a lane picks its 16 bytes out of the 16 x 16 x 32 fragment
+// image: 16-column half (r >> 4), k-group 2 q + h of K-step q.
+// ======================================================================================================
+constexpr int BG_LD = 40;  // bf16 per staged A row (32 + 8 pad = 80 B)
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int NSPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const estts_gemm_args p) {
+    constexpr int NS = (NSPLIT > 1) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][128 * BG_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][NS][8 * 512];  // eight 16-column blocks of one 32-wide K-step
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * 128;
+    const int n0 = blockIdx.x * 128;
+    const int KS = p.ldw >> 5;
+
+    const int nb_end = ((p.N + 63) / 64) * 4;  // 16-column blocks present in W
+    const int a_ch = tid & 7;    // float4 chunk of the 32-wide K slice
+    const int a_r0 = tid >> 3;   // rows a_r0 + 32 i
+    ARow a_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_row[i] = make_arow(p, m0 + a_r0 + 32 * i);
+
+    float4 a_reg[4];
+    uint4 w_reg[NS][2];
+    auto load_tiles = [&](int kt) {
+        const ATap tp = make_atap(p, kt * 32 + a_ch * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_reg[i] = load_a(p, a_row[i], tp);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256;  // 16-byte unit: block idx >> 6, lane slot idx & 63
+            const int nb = (n0 >> 4) + (idx >> 6);
+            const long off = ((long)nb * KS + kt) * 512 + (idx & 63) * 8;
+            const bool ok = nb < nb_end;   // W holds ceil(N / 64) * 64 rows: the last 128-wide tile may be half empty
+            w_reg[0][i] = ok ? *reinterpret_cast<const uint4*>(p.W_hi + off) : make_uint4(0, 0, 0, 0);
+            if (NS == 2) w_reg[NS - 1][i] = ok ? *reinterpret_cast<const uint4*>(p.W_lo + off) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (a_r0 + 32 * i) * BG_LD + a_ch * 4;
+            const float v[4] = {a_reg[i].x, a_reg[i].y, a_reg[i].z, a_reg[i].w};
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 hh, ll;
+                split_bf16(v[j], hh, ll);
+                hi[j] = hh;
+                lo[j] = ll;
+            }
+            *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = hi;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = (tid + i * 256) * 8;
+            *reinterpret_cast<uint4*>(&Ws[buf][0][o]) = w_reg[0][i];
+            if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][o]) = w_reg[NS - 1][i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = (p.K + 31) / 32;
+    const int a_base = (wm * 64 + r) * BG_LD + 8 * h;
+    const int w_base = (wn * 4 + (r >> 4)) * 512 + ((r & 15) + 16 * h) * 8;
+
+    load_tiles(0);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tiles(buf);
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16x8 af[NS][2], wf[NS][2];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[s][i] = *reinterpret_cast<const bf16x8*>(&As[buf][s][a_base + i * 32 * BG_LD + q * 16]);
+                    wf[s][i] = *reinterpret_cast<const bf16x8*>(&Ws[buf][s][w_base + i * 2 * 512 + q * 32 * 8]);
+                }
+            if (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NS - 1][i], wf[0][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], wf[NS - 1][j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], wf[0][j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + r;
+        if (col >= p.N) continue;
+        const float s1 = p.s1 ? p.s1[col] : 1.0f;
+        const float b1 = p.b1 ? p.b1[col] : 0.0f;
+        const float s2 = p.s2 ? p.s2[col] : 1.0f;
+        const float b2 = p.s2 ? p.b2[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value(p, acc[i][j][e], row, col, s1, b1, s2, b2);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 bool splitk_fits(const estts_gemm_args& a, dim3 grid, long tile_elems) {
     const long need = (long)grid.z * grid.x * grid.y * tile_elems * sizeof(float);
@@ -465,6 +609,16 @@ int launch(const estts_gemm_args& a, int splitk, hipStream_t st) {
     return 0;
 }
 
+int launch_big(const estts_gemm_args& a, hipStream_t st) {
+    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, 1);
+    if (a.precision == 3)
+        hipLaunchKernelGGL((gemm_big_kernel<3>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((gemm_big_kernel<1>), grid, dim3(256), 0, st, a);
+    ESTTS_CHECK_LAUNCH("estts_gemm");
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
@@ -504,8 +658,10 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
     int tile = a.tune & 0xff;
     int splitk = (a.tune >> 8) & 0xff;
     if (tile == 0) {
-        const long t64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-        tile = t64 < 512 ? 4 : 1;
+        // measured on MI355X (tools/tune_gemm_big.py): the 128 x 128 kernel wins once its tiles fill most of the chip,
+        // below that the barrier-free 32 x 32 kernel does; the 64 x 64 kernels are kept for explicit selection only
+        const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        tile = (t128 >= 192 && a.N >= 128) ? 5 : 4;
     }
     long tiles;
     int nk;  // K units that one split must keep at least two of
@@ -514,6 +670,7 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         case 2: tiles = (long)((a.M + 31) / 32) * ((a.N + 63) / 64); nk = (a.K + BK - 1) / BK; break;
         case 3: tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32); nk = (a.K + BK - 1) / BK; break;
         case 4: tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32); nk = (a.K + 31) / 32 / 8; break;
+        case 5: return launch_big(a, st);
         default: estts_set_error("estts_gemm: unknown tile id %d", tile); return -1;
     }
     if (nk < 1) nk = 1;

@@ -68,8 +68,8 @@ const char* estts_last_error(void);
  * output tile through float32 slabs in ws (ws_bytes >= splitk * tiles * tile_elems * 4) and one
  * int32 ticket per tile in counters (n_counters of them, zero before the first launch; the kernel
  * leaves them zero).  Calls that may overlap on the GPU must not share ws / counters.
- * tune: 0 = choose tile and split automatically; else (tile id 1..4) | (splitk << 8) | (waves << 16,
- * tile 4 only: 4, 8 or 16 waves per workgroup, 0 = by K).
+ * tune: 0 = choose tile and split automatically; else (tile id 1..5) | (splitk << 8) | (waves << 16,
+ * tile 4 only: 4, 8 or 16 waves per workgroup, 0 = by K).  Tile 5 (128 x 128) does not split K.
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_gemm_args {
     const float* A;

@@ -33,7 +33,7 @@ def test_gemm_dense(M, N, K, precision, tol):
     assert err < tol, err
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 4])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5])
 @pytest.mark.parametrize('splitk', [1, 2, 8])
 def test_gemm_tiles_and_split_k(tile, splitk):
     # every tile shape x split-K factor against float64, several back-to-back launches sharing the workspace
@@ -84,6 +84,31 @@ def test_gemm_conv_epilogue(taps, lpad, cin, cout, T, B):
     err = ((out_full[:, :cout].cpu().double() - ref).abs().max() / ref.abs().max()).item()
     assert err < 3e-5, err
     assert (out_full[:, cout:] == 0).all()
+
+
+@pytest.mark.parametrize('tile', [1, 4, 5])
+def test_gemm_tile_layouts_identity_and_conv(tile):
+    # identity input picks out W^T exactly (values exact in bf16): catches permuted fragment maps of each kernel
+    K, N = 96, 160
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125
+    lin = PackedLinear(w.numpy(), device=DEV)
+    out = torch.empty(K, N, device=DEV)
+    ops.gemm(torch.eye(K).to(DEV), lin, out, precision='bf16', tune=tile)
+    assert torch.equal(out.cpu(), w.t())
+    # causal conv, 3 segments, N = 80 (partial column tile), every epilogue stage
+    taps, lpad, cin, cout, T, B = 5, 4, 80, 80, 67, 3
+    x = _rand(B * T, cin, seed=4)
+    kern = _rand(taps, cin, cout, seed=5, scale=1 / math.sqrt(taps * cin))
+    s1, b1, s2, b2 = _rand(cout, seed=6).abs() + 0.5, _rand(cout, seed=7), _rand(cout, seed=8).abs() + 0.5, _rand(cout, seed=9)
+    res = _rand(B * T, cout, seed=10)
+    lin = PackedLinear(kern.reshape(taps * cin, cout).t().numpy(), bias=b1.numpy(), scale=s1.numpy(), device=DEV,
+                       taps=taps, lpad=lpad, act='tanh', s2=s2.numpy(), b2=b2.numpy())
+    out = torch.empty(B * T, cout, device=DEV)
+    ops.gemm(x.to(DEV), lin, out, seg_len=T, residual=res.to(DEV), precision='bf16x3', tune=tile)
+    xp = torch.nn.functional.pad(x.double().view(B, T, cin), (0, 0, lpad, taps - 1 - lpad))
+    acc = sum(xp[:, j:j + T] @ kern[j].double() for j in range(taps)).reshape(B * T, cout)
+    ref = (torch.tanh(acc * s1.double() + b1.double()) + res.double()) * s2.double() + b2.double()
+    assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
 
 
 def test_gemm_posenc_residual_shared_rows():
