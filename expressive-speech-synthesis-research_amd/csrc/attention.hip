@@ -12,7 +12,8 @@
 // into bf16 hi (+ lo) and staged in a wave-private LDS image [32 keys][depth + 8]: K fragments come back with
 // ds_read_b128, V^T fragments with the transposing ds_read_b64_tr_b16 (4 keys x 16 features per 16-lane group,
 // delivered feature-per-lane), in the key order of the P^T slots above.
-// The optional attention-weight output is a second sweep that recomputes S against the merged (m, l).
+// The optional attention-weight output keeps the scaled scores of up to 8 key tiles per wave (Lk <= 1024) in registers
+// and writes exp(s - m) / l after the merge; longer key ranges recompute S in a second sweep.
 #include "common.h"
 
 namespace {
@@ -55,7 +56,9 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const __bf16* p0, const __bf16* p
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int DH, int NS>
+// MAXT > 0: the attention weights are wanted and every wave sweeps at most MAXT key tiles (Lk <= 128 MAXT): the scaled
+// scores stay in registers and the weights are written after the merge, without a second sweep over K.
+template <int DH, int NS, int MAXT>
 __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_args p) {
     constexpr int KS = DH / 32;        // k-steps of the score product
     constexpr int NT = DH / 16;        // 16-feature tiles of the output
@@ -164,10 +167,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
         load_tile(kbase, p.ldk, wave, kx);
         load_tile(vbase, p.ldv, wave, vx);
     }
-    for (int kt = wave; kt < nkt; kt += 4) {
+    auto tile_step = [&](int kt, float (&s)[2][4]) {
         stage_tile(kx);
         if (kt + 4 < nkt) load_tile(kbase, p.ldk, kt + 4, kx);
-        float s[2][4];
         scores(kt, s);
         float tmax = -INFINITY;
 #pragma unroll
@@ -203,6 +205,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
             if (NS == 2) vf.v[NS - 1] = tr_read_pair(stage + IMG + o0, stage + IMG + o0 + 16 * LD);
             o[nt] = o[nt] * alpha;
             o[nt] = mfma_split<NS>(vf, pf, o[nt]);
+        }
+    };
+    constexpr int KEEP = MAXT > 0 ? MAXT : 1;
+    float sk[KEEP][8];
+    if constexpr (MAXT > 0) {
+#pragma unroll
+        for (int it = 0; it < MAXT; ++it) {
+            const int kt = wave + 4 * it;
+            if (kt < nkt) {
+                float s[2][4];
+                tile_step(kt, s);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sk[it][e] = s[e >> 2][e & 3];
+            }
+        }
+    } else {
+        for (int kt = wave; kt < nkt; kt += 4) {
+            float s[2][4];
+            tile_step(kt, s);
         }
     }
 
@@ -244,7 +265,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
         }
     }
 
-    if (p.attn) {
+    if constexpr (MAXT > 0) {
+        if (qi < p.Lq) {
+            float* ap = p.attn + (((long)b * p.H + h) * p.Lq + qrow) * p.Lk;
+            const bool vec = (p.Lk & 3) == 0;
+#pragma unroll
+            for (int it = 0; it < MAXT; ++it) {
+                const int kt = wave + 4 * it;
+                if (kt < nkt) {
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        const int key0 = kt * 32 + sub * 16 + 4 * g;
+                        float w4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = expf(sk[it][sub * 4 + j] - m_all) * inv_l;
+                        if (vec && key0 + 3 < p.Lk) {
+                            *reinterpret_cast<float4*>(ap + key0) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (key0 + j < p.Lk) ap[key0 + j] = w4[j];
+                        }
+                    }
+                }
+            }
+        }
+    } else if (p.attn) {
         __syncthreads();  // merge buffer is dead; the staging images are reused
         float* ap = p.attn + (((long)b * p.H + h) * p.Lq + qrow) * p.Lk;
         const bool vec = (p.Lk & 3) == 0;
@@ -274,15 +320,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     }
 }
 
-template <int DH>
-int launch(const estts_attention_args& a, hipStream_t st) {
+template <int DH, int MAXT>
+int launch_t(const estts_attention_args& a, hipStream_t st) {
     dim3 grid((a.Lq + 15) / 16, a.H, a.B);
     if (a.precision == 3)
-        hipLaunchKernelGGL((attention_kernel<DH, 2>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attention_kernel<DH, 2, MAXT>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((attention_kernel<DH, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attention_kernel<DH, 1, MAXT>), grid, dim3(256), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_attention");
     return 0;
+}
+
+template <int DH>
+int launch(const estts_attention_args& a, hipStream_t st) {
+    const int per_wave = ((a.Lk + 31) / 32 + 3) / 4;   // key tiles each wave sweeps
+    if (a.attn && per_wave <= 2) return launch_t<DH, 2>(a, st);
+    if (a.attn && per_wave <= 5) return launch_t<DH, 5>(a, st);
+    if (a.attn && per_wave <= 8) return launch_t<DH, 8>(a, st);
+    return launch_t<DH, 0>(a, st);
 }
 
 }  // namespace
