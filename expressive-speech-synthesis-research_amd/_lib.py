@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -61,6 +61,13 @@ class AttentionBwdArgs(C.Structure):
                 ('B', _i32), ('H', _i32), ('Lq', _i32), ('Lk', _i32), ('depth', _i32), ('precision', _i32)]
 
 
+class WavernnPrepBwdArgs(C.Structure):
+    _fields_ = [('dxin', _vp), ('ld_dxin', _i32), ('da2', _vp), ('ld_da2', _i32), ('da3', _vp), ('ld_da3', _i32),
+                ('da4', _vp), ('ld_da4', _i32), ('mel', _vp), ('mel_off', _vp), ('d_aux', _vp), ('dfir', _vp),
+                ('ntaps', _i32), ('fir_kmin', _i32), ('n_utt', _i32), ('frames', _i32), ('feat', _i32), ('d', _i32),
+                ('hop', _i32), ('pad', _i32)]
+
+
 class ColreduceArgs(C.Structure):
     _fields_ = [('z', _vp), ('ldz', _i32), ('g', _vp), ('ldg', _i32), ('a', _vp), ('lda', _i32), ('act', _i32),
                 ('mean', _vp), ('rstd', _vp), ('out0', _vp), ('out1', _vp), ('dy_out', _vp), ('lddy', _i32),
@@ -101,7 +108,7 @@ SIGNATURES = {
     'estts_attention_bwd': (_i32, [C.POINTER(AttentionBwdArgs), _vp]),
     'estts_rownorm_bwd': (_i32, [C.POINTER(RownormBwdArgs), _vp]),
     'estts_colreduce': (_i32, [C.POINTER(ColreduceArgs), _vp]),
-    'estts_bn_finalize': (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'estts_bn_finalize': (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'estts_affine_act': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_bn_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'estts_dropout': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _u32, _u32, _vp]),
@@ -111,6 +118,11 @@ SIGNATURES = {
     'estts_expand_bwd': (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'estts_masked_mae_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
     'estts_adam': (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
+    'estts_gru_step_fwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    'estts_gru_step_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    'estts_wavernn_prep_bwd': (_i32, [C.POINTER(WavernnPrepBwdArgs), _vp]),
+    'estts_softmax_xent': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    'estts_mol_loss': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
 }
 
 _lib = None

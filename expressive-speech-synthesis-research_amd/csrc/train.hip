@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_ar
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* s0, const float* s1, const float* z0, int M, int C,
-                                                          float eps, float momentum, const float* gamma, const float* beta,
+                                                          float eps, float momentum, float mv_scale, const float* gamma,
+                                                          const float* beta,
                                                           float* moving_mean, float* moving_var, float* mean, float* rstd,
                                                           float* scale, float* shift) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* s0, const
     shift[c] = beta[c] - mu * sc;
     if (moving_mean) {
         moving_mean[c] = moving_mean[c] * momentum + mu * (1.0f - momentum);
-        moving_var[c] = moving_var[c] * momentum + var * (1.0f - momentum);
+        moving_var[c] = moving_var[c] * momentum + var * mv_scale * (1.0f - momentum);
     }
 }
 
@@ -621,12 +622,13 @@ extern "C" int estts_colreduce(const estts_colreduce_args* args, void* stream) {
 }
 
 extern "C" int estts_bn_finalize(const float* s0, const float* s1, const float* z0, int32_t M, int32_t C, float eps,
-                                 float momentum, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
-                                 float* mean, float* rstd, float* scale, float* shift, void* stream) {
+                                 float momentum, float moving_var_scale, const float* gamma, const float* beta,
+                                 float* moving_mean, float* moving_var, float* mean, float* rstd, float* scale, float* shift,
+                                 void* stream) {
     ESTTS_CHECK_ARG(s0 && s1 && z0 && gamma && beta && mean && rstd && scale && shift && M > 0 && C > 0, "estts_bn_finalize: bad arguments");
     ESTTS_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "estts_bn_finalize: moving statistics go together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s0, s1, z0, M, C, eps, momentum,
-                       gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift);
+                       moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift);
     ESTTS_CHECK_LAUNCH("estts_bn_finalize");
     return 0;
 }

@@ -71,8 +71,9 @@ class ParamStore:
         n = int(np.prod(shape)) if len(shape) else 1
         return buf[off:off + n].view(*shape) if len(shape) else buf[off:off + 1]
 
-    def numpy(self):
-        f, s = self.flat.cpu().numpy(), self.state.cpu().numpy()
+    def numpy(self, buf=None):
+        """Every named tensor as a host array; `buf` selects another flat buffer of the same layout (e.g. self.grad)."""
+        f, s = (self.flat if buf is None else buf).cpu().numpy(), self.state.cpu().numpy()
         out = {k: f[o:o + int(np.prod(sh) if len(sh) else 1)].reshape(sh).copy() for k, (o, sh) in self.table.items()}
         out.update({k: s[o:o + int(np.prod(sh) if len(sh) else 1)].reshape(sh).copy() for k, (o, sh) in self.state_table.items()})
         return out

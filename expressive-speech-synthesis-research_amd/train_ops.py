@@ -126,8 +126,9 @@ def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None
     check(_lib.load().estts_colreduce(r, _stream()), 'estts_colreduce')
 
 
-def bn_finalize(s0, s1, z, M, C, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, eps=1e-3, momentum=0.99):
-    check(_lib.load().estts_bn_finalize(s0.data_ptr(), s1.data_ptr(), z.data_ptr(), M, C, eps, momentum, gamma.data_ptr(),
+def bn_finalize(s0, s1, z, M, C, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, eps=1e-3, momentum=0.99,
+                moving_var_scale=1.0):
+    check(_lib.load().estts_bn_finalize(s0.data_ptr(), s1.data_ptr(), z.data_ptr(), M, C, eps, momentum, moving_var_scale, gamma.data_ptr(),
                                         beta.data_ptr(), _ptr(moving_mean), _ptr(moving_var), mean.data_ptr(), rstd.data_ptr(),
                                         scale.data_ptr(), shift.data_ptr(), _stream()), 'estts_bn_finalize')
 
@@ -197,6 +198,49 @@ def adam(p, grad, m, v, lr_t, beta1=0.9, beta2=0.98, eps=1e-9, grad_scale=1.0):
                                  _stream()), 'estts_adam')
 
 
+def gru_step_fwd(gi, gh, h_prev, h_out, x_res=None, out=None):
+    M, H = h_prev.shape
+    check(_lib.load().estts_gru_step_fwd(gi.data_ptr(), gi.stride(0), gh.data_ptr(), gh.stride(0), h_prev.data_ptr(),
+                                         h_prev.stride(0), h_out.data_ptr(), h_out.stride(0), _ptr(x_res),
+                                         0 if x_res is None else x_res.stride(0), _ptr(out), 0 if out is None else out.stride(0),
+                                         M, H, _stream()), 'estts_gru_step_fwd')
+
+
+def gru_step_bwd(gi, gh, h_prev, dh, dh_rec, dgi, dgh, dh_prev):
+    M, H = h_prev.shape
+    check(_lib.load().estts_gru_step_bwd(gi.data_ptr(), gi.stride(0), gh.data_ptr(), gh.stride(0), h_prev.data_ptr(),
+                                         h_prev.stride(0), dh.data_ptr(), dh.stride(0), _ptr(dh_rec),
+                                         0 if dh_rec is None else dh_rec.stride(0), dgi.data_ptr(), dgi.stride(0),
+                                         dgh.data_ptr(), dgh.stride(0), dh_prev.data_ptr(), dh_prev.stride(0), M, H, _stream()),
+          'estts_gru_step_bwd')
+
+
+def wavernn_prep_bwd(dxin, da2, da3, da4, mel, mel_off, d_aux, dfir, fir_kmin, n_utt, frames, feat, d, hop, pad):
+    a = _lib.WavernnPrepBwdArgs()
+    a.dxin, a.ld_dxin = dxin.data_ptr(), dxin.stride(0)
+    a.da2, a.ld_da2, a.da3, a.ld_da3, a.da4, a.ld_da4 = (da2.data_ptr(), da2.stride(0), da3.data_ptr(), da3.stride(0),
+                                                         da4.data_ptr(), da4.stride(0))
+    a.mel, a.mel_off, a.d_aux, a.dfir = mel.data_ptr(), mel_off.data_ptr(), d_aux.data_ptr(), dfir.data_ptr()
+    a.ntaps, a.fir_kmin = dfir.shape[1], fir_kmin
+    a.n_utt, a.frames, a.feat, a.d, a.hop, a.pad = n_utt, frames, feat, d, hop, pad
+    check(_lib.load().estts_wavernn_prep_bwd(a, _stream()), 'estts_wavernn_prep_bwd')
+
+
+def softmax_xent(logits, labels, loss, dlogits, scale, M=None, C=None):
+    M = logits.shape[0] if M is None else M
+    C = logits.shape[1] if C is None else C
+    if labels.dtype != torch.int32:
+        raise TypeError('labels must be int32')
+    check(_lib.load().estts_softmax_xent(logits.data_ptr(), logits.stride(0), labels.data_ptr(), loss.data_ptr(), dlogits.data_ptr(),
+                                         dlogits.stride(0), M, C, scale, _stream()), 'estts_softmax_xent')
+
+
+def mol_loss(y_hat, y, loss, d, scale, nr_mix, num_classes=65536, log_scale_min=-32.23619130191664, M=None):
+    M = y_hat.shape[0] if M is None else M
+    check(_lib.load().estts_mol_loss(y_hat.data_ptr(), y_hat.stride(0), y.data_ptr(), loss.data_ptr(), d.data_ptr(), d.stride(0), M,
+                                     nr_mix, num_classes, log_scale_min, scale, _stream()), 'estts_mol_loss')
+
+
 def _debug_wrap(fn):
     import functools
     import sys
@@ -213,5 +257,6 @@ def _debug_wrap(fn):
 
 if ops._debug_sync:      # ESTTS_DEBUG_SYNC=1: name every training launch and wait for it (fault localisation)
     for _n in ('wgrad', 'attention_bwd', 'rownorm_bwd', 'colreduce', 'bn_finalize', 'affine_act', 'bn_bwd', 'dropout', 'axpby',
-               'head_scale', 'embed_bwd', 'expand_bwd', 'masked_mae_bwd', 'adam'):
+               'head_scale', 'embed_bwd', 'expand_bwd', 'masked_mae_bwd', 'adam', 'gru_step_fwd', 'gru_step_bwd', 'wavernn_prep_bwd',
+               'softmax_xent', 'mol_loss'):
         globals()[_n] = _debug_wrap(globals()[_n])

@@ -20,6 +20,40 @@ from ._lib import WavernnPrepArgs, WavernnSampleArgs, check
 from .ops import PackedLinear
 
 
+_IMPULSE_FRAME = 6      # impulse position (frames) of the response below; margin of 6 frames on both sides
+
+
+def _composite_response(up_weights, scales):
+    """Response of the [repeat x s, Conv2d(1, 1, (1, 2 s + 1))] x 3 chain (fatchord_version.py:70-85) to a unit impulse at
+    frame _IMPULSE_FRAME, float64, length (2 * _IMPULSE_FRAME + 1) * hop."""
+    x = np.zeros(2 * _IMPULSE_FRAME + 1, dtype=np.float64)
+    x[_IMPULSE_FRAME] = 1.0
+    for s, k in zip(scales, up_weights):
+        k = np.asarray(k, dtype=np.float64).reshape(-1)
+        x = np.repeat(x, s)
+        xp = np.pad(x, (s, s))
+        x = sum(k[t] * xp[t:t + x.shape[0]] for t in range(2 * s + 1))
+    return x
+
+
+def _response_to_fir(x, hop, kmin, ntaps):
+    fir = np.zeros((hop, ntaps), dtype=np.float64)
+    d = np.arange(hop)[:, None] + (kmin + np.arange(ntaps))[None, :] * hop + _IMPULSE_FRAME * hop
+    ok = (d >= 0) & (d < x.shape[0])
+    fir[ok] = x[d[ok]]
+    return fir
+
+
+def composite_filter_support(scales):
+    """(kmin, ntaps) of the composite filter for kernels without zeros (depends on the kernel sizes only)."""
+    hop = int(np.prod(scales))
+    x = _composite_response([np.ones(2 * s + 1) for s in scales], scales)
+    nz = np.nonzero(x > 0)[0]
+    lo, hi = int(nz.min()) - _IMPULSE_FRAME * hop, int(nz.max()) - _IMPULSE_FRAME * hop
+    kmin = math.ceil((lo - hop + 1) / hop)
+    return kmin, math.floor(hi / hop) - kmin + 1
+
+
 def composite_upsample_filter(up_weights, scales):
     """Collapse the reference's [repeat x s, Conv2d(1, 1, (1, 2 s + 1))] x 3 chain (fatchord_version.py:70-85) into
     one periodic FIR over mel frames:  up[s] = sum_j fir[s % hop, j] * mel_padded[s // hop + pad - (kmin + j)].
@@ -28,28 +62,27 @@ def composite_upsample_filter(up_weights, scales):
     by whole frames, so its response to a unit impulse at one frame determines it.  Returns (fir [hop, ntaps], kmin).
     """
     hop = int(np.prod(scales))
-    c = 6                                     # impulse frame; margin of 6 frames on both sides
-    x = np.zeros(2 * c + 1, dtype=np.float64)
-    x[c] = 1.0
-    for s, k in zip(scales, up_weights):
-        k = np.asarray(k, dtype=np.float64).reshape(-1)
-        x = np.repeat(x, s)
-        xp = np.pad(x, (s, s))
-        x = sum(k[t] * xp[t:t + x.shape[0]] for t in range(2 * s + 1))
-    # R[delta] = response at output index c*hop + delta
-    nz = np.nonzero(np.abs(x) > 0)[0]
-    lo, hi = int(nz.min()) - c * hop, int(nz.max()) - c * hop
-    kmin = math.ceil((lo - hop + 1) / hop)
-    kmax = math.floor(hi / hop)
-    ntaps = kmax - kmin + 1
-    fir = np.zeros((hop, ntaps), dtype=np.float64)
-    for phase in range(hop):
-        for j in range(ntaps):
-            d = phase + (kmin + j) * hop
-            idx = c * hop + d
-            if 0 <= idx < x.shape[0]:
-                fir[phase, j] = x[idx]
-    return fir.astype(np.float32), kmin
+    kmin, ntaps = composite_filter_support(scales)
+    return _response_to_fir(_composite_response(up_weights, scales), hop, kmin, ntaps).astype(np.float32), kmin
+
+
+def composite_filter_gradients(up_weights, scales, dfir):
+    """Gradients of a loss w.r.t. the three upsampling kernels given dL/dfir [hop, ntaps]: the composite filter is linear
+    in each kernel separately, so dL/dw_i[a] = <dfir, composite with w_i replaced by the unit vector e_a>."""
+    hop = int(np.prod(scales))
+    kmin, ntaps = composite_filter_support(scales)
+    dfir = np.asarray(dfir, np.float64)
+    ws = [np.asarray(k, np.float64).reshape(-1) for k in up_weights]
+    grads = []
+    for i, w in enumerate(ws):
+        g = np.zeros_like(w)
+        for a in range(w.shape[0]):
+            e = np.zeros_like(w)
+            e[a] = 1.0
+            trial = ws[:i] + [e] + ws[i + 1:]
+            g[a] = float((_response_to_fir(_composite_response(trial, scales), hop, kmin, ntaps) * dfir).sum())
+        grads.append(g)
+    return grads
 
 
 def fold_starts(total_len, target, overlap):

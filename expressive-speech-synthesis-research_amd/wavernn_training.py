@@ -1,0 +1,484 @@
+"""WaveRNN training on MI355X: teacher-forced forward over whole windows with every GRU state kept, cross-entropy (RAW)
+or mixture-of-logistics (MOL) loss, back-propagation through time, torch-style Adam, data-parallel gradient all-reduce.
+
+Mirrors what WaveRNN/train_wavernn.py:27-42 does per batch with the reference module (models/fatchord_version.py:119-148
+in train() mode, torch.optim.Adam at :104): `train_step(x, y, mels)` = forward, loss, backward, optimizer step;
+`forward(x, mels)` returns the logits; `state_dict()` / `load_state_dict()` use the reference's key names and layouts, so a
+checkpoint moves freely between this class, estts.wavernn.WaveRNN (generation) and the reference.
+
+All arithmetic runs in libestts.so kernels.  The two recurrences are 2 x T dependent (small GEMM + gate kernel) pairs in
+each direction; buffers are allocated once per (batch, window) shape so that each loop is captured into one hipGraph and
+replayed every step.  Master weights are float32 in one flat buffer ([in, out] layout, the transpose of torch's), with
+gradients and Adam moments in buffers of the same shape.  The three upsampling kernels enter through their composite
+per-phase filter (see wavernn.composite_upsample_filter): its gradient is reduced on the device, the chain rule back to the
+three small kernels is a few hundred multiply-adds on the host.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops, parallel
+from . import train_ops as T_
+from ._lib import WavernnPrepArgs, check
+from .forward_training import ParamStore
+from .train_ops import TrainLinear
+from .wavernn import composite_filter_gradients, composite_filter_support, composite_upsample_filter
+
+
+class _Lin:
+    def __init__(self, store, name, bias_name=None, need_bwd=True, act=None):
+        self.lin = TrainLinear(store.p[name], store.p[bias_name] if bias_name else None, act=act, need_bwd=need_bwd)
+        self.dk = store.g[name]
+        self.db = store.g[bias_name] if bias_name else None
+        self.N, self.K = self.lin.N, self.lin.K
+
+
+class _BN:
+    def __init__(self, store, p):
+        self.gamma, self.beta = store.p[p + '.weight'], store.p[p + '.bias']
+        self.dgamma, self.dbeta = store.g[p + '.weight'], store.g[p + '.bias']
+        self.mm, self.mv = store.s[p + '.running_mean'], store.s[p + '.running_var']
+
+
+class WaveRNNTrainer:
+    def __init__(self, rnn_dims, fc_dims, bits, pad, upsample_factors, feat_dims, compute_dims, res_out_dims, res_blocks,
+                 hop_length, sample_rate, mode='RAW', device='cuda', precision='bf16x3', process_group=None, bucket_mb=25,
+                 use_graph=True):
+        if mode == 'RAW':
+            self.n_classes = 2 ** bits
+        elif mode == 'MOL':
+            self.n_classes = 30
+        else:
+            raise RuntimeError(f'Unknown model mode value - {mode}')
+        if int(np.prod(upsample_factors)) != hop_length:
+            raise ValueError('upsample_factors must multiply to hop_length')
+        if not torch.cuda.is_available():
+            raise RuntimeError('WaveRNN training needs a GPU: the hot path has no CPU implementation')
+        _lib.load()
+        self.mode, self.pad, self.bits = mode, pad, bits
+        self.rnn_dims, self.fc_dims = rnn_dims, fc_dims
+        self.aux_dims = res_out_dims // 4
+        self.feat_dims, self.compute_dims, self.res_out_dims, self.res_blocks = feat_dims, compute_dims, res_out_dims, res_blocks
+        self.upsample_factors = tuple(upsample_factors)
+        self.hop_length, self.sample_rate = hop_length, sample_rate
+        self.device = torch.device(device)
+        self.precision = precision
+        self.use_graph = use_graph
+        self.step = 0
+        self.lr, self.beta1, self.beta2, self.eps = 1e-4, 0.9, 0.999, 1e-8      # torch.optim.Adam defaults, hp.voc_lr
+        self.iterations = 0
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        self.n_in = 1 + feat_dims + self.aux_dims
+        self.k_in = (self.n_in + 3) // 4 * 4
+        self.nc_pad = (self.n_classes + 3) // 4 * 4
+        self.fir_kmin, self.ntaps = composite_filter_support(self.upsample_factors)
+        if self.pad - self.fir_kmin - (self.ntaps - 1) < 0 or self.pad + self.fir_kmin < 0:
+            raise ValueError('pad is too small for the upsampling filters')
+        self.store = None
+        self._ws = None
+        ops.gemm_workspace(self.device)
+
+    @classmethod
+    def from_hparams(cls, hp, **kw):
+        return cls(rnn_dims=hp['voc_rnn_dims'], fc_dims=hp['voc_fc_dims'], bits=hp['bits'], pad=hp['voc_pad'],
+                   upsample_factors=hp['voc_upsample_factors'], feat_dims=hp['num_mels'],
+                   compute_dims=hp['voc_compute_dims'], res_out_dims=hp['voc_res_out_dims'],
+                   res_blocks=hp['voc_res_blocks'], hop_length=hp['hop_length'], sample_rate=hp['sample_rate'],
+                   mode=hp['voc_mode'], **kw)
+
+    # ------------------------------------------------------------------ weights (reference key names and layouts)
+    def load_state_dict(self, sd, strict=False):
+        w = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in sd.items()}
+        if 'step' in w:
+            self.step = int(np.asarray(w['step']).reshape(-1)[0])
+        st = ParamStore(self.device)
+        p = 'upsample.resnet'
+
+        def bn(q):
+            st.add(q + '.weight', w[q + '.weight'])
+            st.add(q + '.bias', w[q + '.bias'])
+            st.add(q + '.running_mean', w[q + '.running_mean'], trainable=False)
+            st.add(q + '.running_var', w[q + '.running_var'], trainable=False)
+
+        def lin(name, pad_k=None, pad_n=None):
+            m = np.asarray(w[name + '.weight'], np.float32).T               # torch [out, in] -> master [in, out]
+            K, N = m.shape
+            full = np.zeros((pad_k or K, pad_n or N), np.float32)
+            full[:K, :N] = m
+            st.add(name + '.weight', full)
+            if name + '.bias' in w:
+                b = np.zeros(pad_n or N, np.float32)
+                b[:N] = w[name + '.bias']
+                st.add(name + '.bias', b)
+
+        wi = np.asarray(w[p + '.conv_in.weight'], np.float32)               # (C, feat, k) -> [k * feat, C], tap-major
+        self.k_conv = wi.shape[2]
+        if self.k_conv != 2 * self.pad + 1:
+            raise ValueError('conv_in kernel size does not match pad')
+        st.add(p + '.conv_in.weight', wi.transpose(2, 1, 0).reshape(-1, wi.shape[0]))
+        bn(p + '.batch_norm')
+        for i in range(self.res_blocks):
+            q = f'{p}.layers.{i}'
+            st.add(q + '.conv1.weight', np.asarray(w[q + '.conv1.weight'], np.float32)[:, :, 0].T)
+            bn(q + '.batch_norm1')
+            st.add(q + '.conv2.weight', np.asarray(w[q + '.conv2.weight'], np.float32)[:, :, 0].T)
+            bn(q + '.batch_norm2')
+        st.add(p + '.conv_out.weight', np.asarray(w[p + '.conv_out.weight'], np.float32)[:, :, 0].T)
+        st.add(p + '.conv_out.bias', w[p + '.conv_out.bias'])
+        for j in range(len(self.upsample_factors)):
+            st.add(f'upsample.up_layers.{2 * j + 1}.weight', np.asarray(w[f'upsample.up_layers.{2 * j + 1}.weight']).reshape(-1))
+        lin('I', pad_k=self.k_in)
+        for r in ('rnn1', 'rnn2'):
+            st.add(r + '.weight_ih_l0', np.asarray(w[r + '.weight_ih_l0'], np.float32).T)
+            st.add(r + '.bias_ih_l0', w[r + '.bias_ih_l0'])
+            st.add(r + '.weight_hh_l0', np.asarray(w[r + '.weight_hh_l0'], np.float32).T)
+            st.add(r + '.bias_hh_l0', w[r + '.bias_hh_l0'])
+        lin('fc1')
+        lin('fc2')
+        lin('fc3', pad_n=self.nc_pad)
+        st.build()
+        self.store = st
+        self.conv_in = _Lin(st, p + '.conv_in.weight', need_bwd=False)
+        self.bn_in = _BN(st, p + '.batch_norm')
+        self.blocks = []
+        for i in range(self.res_blocks):
+            q = f'{p}.layers.{i}'
+            self.blocks.append((_Lin(st, q + '.conv1.weight'), _BN(st, q + '.batch_norm1'),
+                                _Lin(st, q + '.conv2.weight'), _BN(st, q + '.batch_norm2')))
+        self.conv_out = _Lin(st, p + '.conv_out.weight', p + '.conv_out.bias')
+        self.I = _Lin(st, 'I.weight', 'I.bias')
+        self.ih1 = _Lin(st, 'rnn1.weight_ih_l0', 'rnn1.bias_ih_l0')
+        self.hh1 = _Lin(st, 'rnn1.weight_hh_l0', 'rnn1.bias_hh_l0')
+        self.ih2 = _Lin(st, 'rnn2.weight_ih_l0', 'rnn2.bias_ih_l0')
+        self.hh2 = _Lin(st, 'rnn2.weight_hh_l0', 'rnn2.bias_hh_l0')
+        self.fc1 = _Lin(st, 'fc1.weight', 'fc1.bias', act='relu')
+        self.fc2 = _Lin(st, 'fc2.weight', 'fc2.bias', act='relu')
+        self.fc3 = _Lin(st, 'fc3.weight', 'fc3.bias')
+        self._linears = ([self.conv_in.lin, self.conv_out.lin, self.I.lin, self.ih1.lin, self.hh1.lin, self.ih2.lin, self.hh2.lin,
+                          self.fc1.lin, self.fc2.lin, self.fc3.lin] + [b[0].lin for b in self.blocks] + [b[2].lin for b in self.blocks])
+        self._up_names = [f'upsample.up_layers.{2 * j + 1}.weight' for j in range(len(self.upsample_factors))]
+        self._up_shapes = [np.asarray(w[n]).shape for n in self._up_names]
+        self._refresh_fir()
+        self._ws = None
+        return self
+
+    def _refresh_fir(self):
+        ups = [self.store.p[n].cpu().numpy() for n in self._up_names]
+        fir, kmin = composite_upsample_filter(ups, self.upsample_factors)
+        assert kmin == self.fir_kmin and fir.shape[1] == self.ntaps
+        self._up_host = ups
+        if getattr(self, 'fir', None) is None or self.fir.shape != fir.shape:
+            self.fir = torch.from_numpy(fir).to(self.device)
+        else:
+            self.fir.copy_(torch.from_numpy(fir))
+
+    def state_dict(self):
+        out = self._export(self.store.numpy())
+        out['step'] = torch.tensor([self.step], dtype=torch.long)
+        return out
+
+    def gradients(self):
+        """The gradients of the last train_step under the reference's parameter names and layouts (summed over ranks when
+        data parallel, before the 1 / world scaling the optimizer applies)."""
+        raw = self.store.numpy(self.store.grad)
+        return {k: v for k, v in self._export(raw).items() if 'running' not in k}
+
+    def _export(self, raw):
+        sd = {}
+        p = 'upsample.resnet'
+        C, feat, k = self.compute_dims, self.feat_dims, self.k_conv
+        for name, v in raw.items():
+            if name == p + '.conv_in.weight':
+                sd[name] = v.reshape(k, feat, C).transpose(2, 1, 0).copy()
+            elif name.endswith(('.conv1.weight', '.conv2.weight', 'conv_out.weight')):
+                sd[name] = v.T.copy()[:, :, None]
+            elif 'up_layers' in name:
+                sd[name] = v.reshape(self._up_shapes[self._up_names.index(name)])
+            elif name == 'I.weight':
+                sd[name] = v[:self.n_in].T.copy()
+            elif name == 'fc3.weight':
+                sd[name] = v[:, :self.n_classes].T.copy()
+            elif name == 'fc3.bias':
+                sd[name] = v[:self.n_classes].copy()
+            elif name.endswith('.weight') and not ('batch_norm' in name) or 'weight_ih' in name or 'weight_hh' in name:
+                sd[name] = v.T.copy()
+            else:
+                sd[name] = v
+        return {k_: torch.from_numpy(np.ascontiguousarray(v)) for k_, v in sd.items()}
+
+    def get_step(self):
+        return self.step
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location='cpu', weights_only=True))
+
+    # ------------------------------------------------------------------ workspace and captured loops
+    def _workspace(self, B, Tf):
+        key = (B, Tf)
+        if self._ws is not None and self._ws['key'] == key:
+            return self._ws
+        dev, f32 = self.device, dict(dtype=torch.float32, device=self.device)
+        R, F, d, hop = self.rnn_dims, self.fc_dims, self.aux_dims, self.hop_length
+        Tm, T = Tf + 2 * self.pad, Tf * hop
+        M, Mr = B * T, B * Tf
+        i32 = dict(dtype=torch.int32, device=dev)
+        ws = {'key': key, 'B': B, 'Tf': Tf, 'T': T, 'M': M, 'Mr': Mr,
+              'mel': torch.empty(B * Tm, self.feat_dims, **f32), 'unf': torch.empty(Mr, self.k_conv * self.feat_dims, **f32),
+              'aux': torch.empty(Mr, self.res_out_dims, **f32),
+              'mel_off': torch.arange(B, **i32) * Tm, 'aux_off': torch.arange(B, **i32) * Tf,
+              'utt_samples': torch.full((B,), T, **i32),
+              'seq_utt': torch.arange(B, **i32).repeat_interleave(T).contiguous(),
+              'seq_start': torch.arange(T, **i32).repeat(B).contiguous(),
+              'step0': torch.zeros(1, **i32), 'x': torch.empty(M, **f32),
+              'xin': torch.zeros(M, self.k_in, **f32), 'xI': torch.empty(M, R, **f32),
+              'gi1': torch.empty(M, 3 * R, **f32), 'gh1': torch.empty(M, 3 * R, **f32), 'H1': torch.empty(M, R, **f32),
+              'gi2': torch.empty(M, 3 * R, **f32), 'gh2': torch.empty(M, 3 * R, **f32), 'H2': torch.empty(M, R, **f32),
+              'x1cat': torch.zeros(M, R + d, **f32), 'x2cat': torch.zeros(M, R + d, **f32),
+              'f1cat': torch.zeros(M, F + d, **f32), 'f2': torch.empty(M, F, **f32),
+              'logits': torch.zeros(M, self.nc_pad, **f32), 'dlogits': torch.zeros(M, self.nc_pad, **f32),
+              'h0': torch.zeros(B, R, **f32),
+              # backward
+              'df2': torch.empty(M, F, **f32), 'df1cat': torch.empty(M, F + d, **f32), 'dx2cat': torch.empty(M, R + d, **f32),
+              'dx1cat': torch.empty(M, R + d, **f32), 'dgi': torch.empty(M, 3 * R, **f32), 'dgh': torch.empty(M, 3 * R, **f32),
+              'dhd': torch.empty(B, R, **f32), 'dhr': torch.empty(B, R, **f32), 'dxI': torch.empty(M, R, **f32),
+              'dxin': torch.empty(M, self.k_in, **f32), 'd_aux': torch.empty(Mr, self.res_out_dims, **f32),
+              'dfir': torch.zeros(hop, self.ntaps, **f32), 'loss': torch.zeros(1, **f32),
+              'labels': torch.zeros(M, **i32), 'yf': torch.zeros(M, **f32), 'graphs': {}}
+        self._ws = ws
+        return ws
+
+    def _run(self, ws, name, fn):
+        """Runs fn() (a fixed sequence of launches on buffers of `ws`) through a hipGraph captured on first use."""
+        if not self.use_graph:
+            return fn()
+        g = ws['graphs'].get(name)
+        if g is None:
+            fn()                                      # first use: run eagerly (also warms every kernel up) ...
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=side):   # ... and record the same launches for the following steps
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            ws['graphs'][name] = g
+            return None
+        g.replay()
+
+    def _gru_fwd(self, ws, gi, gh, H, hh, x_res, out, out_cols):
+        B, T, R = ws['B'], ws['T'], self.rnn_dims
+        gi3, gh3, H3 = gi.view(B, T, 3 * R), gh.view(B, T, 3 * R), H.view(B, T, R)
+        xr3, out3 = x_res.view(B, T, -1), out.view(B, T, -1)
+        for t in range(T):
+            hp = ws['h0'] if t == 0 else H3[:, t - 1]
+            ops.gemm(hp, hh.lin.fwd, gh3[:, t], precision=self.precision)
+            T_.gru_step_fwd(gi3[:, t], gh3[:, t], hp, H3[:, t], x_res=xr3[:, t, :out_cols], out=out3[:, t, :out_cols])
+
+    def _gru_bwd(self, ws, gi, gh, H, hh, dout):
+        """dout: [M, >= R] gradient w.r.t. the layer output (columns 0..R-1); fills ws['dgi'], ws['dgh']."""
+        B, T, R = ws['B'], ws['T'], self.rnn_dims
+        gi3, gh3, H3 = gi.view(B, T, 3 * R), gh.view(B, T, 3 * R), H.view(B, T, R)
+        dgi3, dgh3 = ws['dgi'].view(B, T, 3 * R), ws['dgh'].view(B, T, 3 * R)
+        do3 = dout.view(B, T, -1)
+        for t in range(T - 1, -1, -1):
+            hp = ws['h0'] if t == 0 else H3[:, t - 1]
+            T_.gru_step_bwd(gi3[:, t], gh3[:, t], hp, do3[:, t, :R], None if t == T - 1 else ws['dhr'], dgi3[:, t], dgh3[:, t],
+                            ws['dhd'])
+            if t > 0:
+                ops.gemm(dgh3[:, t], hh.lin.bwd, ws['dhr'], precision=self.precision, residual=ws['dhd'])
+
+    # ------------------------------------------------------------------ pieces of the step
+    def _bn_train(self, z, bn, M, C):
+        sums = torch.zeros(2, C, dtype=torch.float32, device=self.device)
+        T_.colreduce(0, sums[0], sums[1], z=z, M=M, C=C)
+        st = torch.empty(4, C, dtype=torch.float32, device=self.device)
+        T_.bn_finalize(sums[0], sums[1], z, M, C, bn.gamma, bn.beta, bn.mm, bn.mv, st[0], st[1], st[2], st[3], eps=1e-5,
+                       momentum=0.9, moving_var_scale=M / max(M - 1, 1))
+        return st
+
+    def _lin_bwd(self, x, L, dy, M, dx=None, residual=None):
+        T_.wgrad(x, dy, L.dk, M=M, precision=self.precision)
+        if L.db is not None:
+            T_.colreduce(1, L.db, g=dy, M=M, C=L.N)
+        if dx is not None:
+            ops.gemm(dy, L.lin.bwd, dx, M=M, precision=self.precision, residual=residual)
+        return dx
+
+    def _resnet_fwd(self, ws, tape):
+        """MelResNet in training mode (fatchord_version.py:39-45 with BatchNorm batch statistics)."""
+        Mr, C, pr = ws['Mr'], self.compute_dims, self.precision
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)   # noqa: E731
+        z = e(Mr, C)
+        ops.gemm(ws['unf'], self.conv_in.lin.fwd, z, precision=pr)
+        st0 = self._bn_train(z, self.bn_in, Mr, C)
+        x = e(Mr, C)
+        T_.affine_act(z, x, st0[2], st0[3], 'relu')
+        saved = []
+        for c1, b1, c2, b2 in self.blocks:
+            z1 = e(Mr, C)
+            ops.gemm(x, c1.lin.fwd, z1, precision=pr)
+            s1 = self._bn_train(z1, b1, Mr, C)
+            a = e(Mr, C)
+            T_.affine_act(z1, a, s1[2], s1[3], 'relu')
+            z2 = e(Mr, C)
+            ops.gemm(a, c2.lin.fwd, z2, precision=pr)
+            s2 = self._bn_train(z2, b2, Mr, C)
+            nx = e(Mr, C)
+            T_.affine_act(z2, nx, s2[2], s2[3], None, residual=x)
+            saved.append((x, z1, s1, a, z2, s2))
+            x = nx
+        ops.gemm(x, self.conv_out.lin.fwd, ws['aux'], precision=pr)
+        x_last = x
+
+        def backward(d_aux):
+            dx = e(Mr, C)
+            self._lin_bwd(x_last, self.conv_out, d_aux, Mr, dx=dx)
+            for (c1, b1, c2, b2), (xin, z1, s1, a, z2, s2) in zip(reversed(self.blocks), reversed(saved)):
+                dz2 = e(Mr, C)
+                T_.colreduce(2, b2.dbeta, b2.dgamma, z=z2, g=dx, mean=s2[0], rstd=s2[1], M=Mr, C=C)
+                T_.bn_bwd(dx, z2, s2[0], s2[1], b2.gamma, b2.dgamma, b2.dbeta, dz2, M=Mr, C=C)
+                da = e(Mr, C)
+                self._lin_bwd(a, c2, dz2, Mr, dx=da)
+                dz1 = e(Mr, C)
+                T_.colreduce(2, b1.dbeta, b1.dgamma, z=z1, g=da, a=a, act='relu', mean=s1[0], rstd=s1[1], dy_out=dz1, M=Mr, C=C)
+                T_.bn_bwd(dz1, z1, s1[0], s1[1], b1.gamma, b1.dgamma, b1.dbeta, dz1, M=Mr, C=C)
+                ndx = e(Mr, C)
+                self._lin_bwd(xin, c1, dz1, Mr, dx=ndx, residual=dx)
+                dx = ndx
+            dz = e(Mr, C)
+            x0 = saved[0][0] if saved else x_last
+            T_.colreduce(2, self.bn_in.dbeta, self.bn_in.dgamma, z=z, g=dx, a=x0, act='relu', mean=st0[0], rstd=st0[1], dy_out=dz,
+                         M=Mr, C=C)
+            T_.bn_bwd(dz, z, st0[0], st0[1], self.bn_in.gamma, self.bn_in.dgamma, self.bn_in.dbeta, dz, M=Mr, C=C)
+            T_.wgrad(ws['unf'], dz, self.conv_in.dk, M=Mr, precision=self.precision)
+
+        tape.append(backward)
+
+    def _load_batch(self, ws, x, mels):
+        B, Tf, hop = ws['B'], ws['Tf'], self.hop_length
+        xd = torch.as_tensor(x, dtype=torch.float32, device=self.device)
+        md = torch.as_tensor(mels, dtype=torch.float32, device=self.device)
+        if tuple(xd.shape) != (B, Tf * hop) or tuple(md.shape) != (B, self.feat_dims, Tf + 2 * self.pad):
+            raise ValueError(f'expected x {(B, Tf * hop)} and mels {(B, self.feat_dims, Tf + 2 * self.pad)}, got '
+                             f'{tuple(xd.shape)} and {tuple(md.shape)}')
+        rows = md.transpose(1, 2).contiguous()                                  # [B, Tm, feat]
+        ws['mel'].copy_(rows.view(-1, self.feat_dims))
+        # valid convolution of conv_in as a dense layer over unfolded windows (pure data movement)
+        unf = rows.unfold(1, self.k_conv, 1).permute(0, 1, 3, 2).reshape(B * Tf, self.k_conv * self.feat_dims)
+        ws['unf'].copy_(unf)
+        ws['x'].copy_(xd.reshape(-1))
+
+    def _forward(self, ws, tape):
+        R, F, pr, M = self.rnn_dims, self.fc_dims, self.precision, ws['M']
+        self._resnet_fwd(ws, tape)
+        a = WavernnPrepArgs()
+        a.mel, a.mel_off, a.aux, a.aux_off = ws['mel'].data_ptr(), ws['mel_off'].data_ptr(), ws['aux'].data_ptr(), ws['aux_off'].data_ptr()
+        a.fir, a.ntaps, a.fir_kmin = self.fir.data_ptr(), self.ntaps, self.fir_kmin
+        a.seq_utt, a.seq_start, a.utt_samples = ws['seq_utt'].data_ptr(), ws['seq_start'].data_ptr(), ws['utt_samples'].data_ptr()
+        a.x_prev, a.step = ws['x'].data_ptr(), ws['step0'].data_ptr()
+        a.xin, a.ld_xin = ws['xin'].data_ptr(), ws['xin'].stride(0)
+        a.a2, a.ld_a2 = ws['x1cat'][:, R:].data_ptr(), ws['x1cat'].stride(0)
+        a.a3, a.ld_a3 = ws['x2cat'][:, R:].data_ptr(), ws['x2cat'].stride(0)
+        a.a4, a.ld_a4 = ws['f1cat'][:, F:].data_ptr(), ws['f1cat'].stride(0)
+        a.n_seq, a.feat, a.d, a.hop, a.pad = M, self.feat_dims, self.aux_dims, self.hop_length, self.pad
+        check(_lib.load().estts_wavernn_prep(a, ops._stream()), 'estts_wavernn_prep')
+        ops.gemm(ws['xin'], self.I.lin.fwd, ws['xI'], precision=pr)
+        ops.gemm(ws['xI'], self.ih1.lin.fwd, ws['gi1'], precision=pr)
+        self._run(ws, 'gru1_fwd', lambda: self._gru_fwd(ws, ws['gi1'], ws['gh1'], ws['H1'], self.hh1, ws['xI'], ws['x1cat'], R))
+        ops.gemm(ws['x1cat'], self.ih2.lin.fwd, ws['gi2'], precision=pr)
+        self._run(ws, 'gru2_fwd', lambda: self._gru_fwd(ws, ws['gi2'], ws['gh2'], ws['H2'], self.hh2, ws['x1cat'], ws['x2cat'], R))
+        ops.gemm(ws['x2cat'], self.fc1.lin.fwd, ws['f1cat'][:, :F], precision=pr)
+        ops.gemm(ws['f1cat'], self.fc2.lin.fwd, ws['f2'], precision=pr)
+        ops.gemm(ws['f2'], self.fc3.lin.fwd, ws['logits'], precision=pr)
+
+    def forward(self, x, mels):
+        """Teacher-forced logits in training mode (fatchord_version.py:119-148): [B, L, n_classes] on the device."""
+        B, Tf = int(np.shape(x)[0]), int(np.shape(mels)[2]) - 2 * self.pad
+        ws = self._workspace(B, Tf)
+        self._load_batch(ws, x, mels)
+        self._forward(ws, [])
+        self.step += 1
+        return ws['logits'].view(B, ws['T'], self.nc_pad)[:, :, :self.n_classes]
+
+    def train_step(self, x, y, mels, lr=None):
+        """One iteration of voc_train_loop (train_wavernn.py:27-42).  x [B, L] float inputs, y [B, L] targets (int class
+        labels for RAW, floats in [-1, 1] for MOL), mels [B, feat, L / hop + 2 pad].  Returns the loss (device scalar)."""
+        if lr is not None:
+            self.lr = float(lr)
+        B, Tf = int(np.shape(x)[0]), int(np.shape(mels)[2]) - 2 * self.pad
+        ws = self._workspace(B, Tf)
+        M, Mr, R, F, d, pr = ws['M'], ws['Mr'], self.rnn_dims, self.fc_dims, self.aux_dims, self.precision
+        self._load_batch(ws, x, mels)
+        st = self.store
+        st.grad.zero_()
+        ws['loss'].zero_()
+        ws['dfir'].zero_()
+        tape = []
+        self._forward(ws, tape)
+        self.step += 1
+        # ---- loss (mean over B * L) and its gradient
+        if self.mode == 'RAW':
+            ws['labels'].copy_(torch.as_tensor(y, device=self.device).reshape(-1))
+            T_.softmax_xent(ws['logits'], ws['labels'], ws['loss'], ws['dlogits'], 1.0 / M, M=M, C=self.n_classes)
+        else:
+            ws['yf'].copy_(torch.as_tensor(y, device=self.device).reshape(-1))
+            T_.mol_loss(ws['logits'], ws['yf'], ws['loss'], ws['dlogits'], 1.0 / M, self.n_classes // 3, M=M)
+        # ---- backward
+        self._lin_bwd(ws['f2'], self.fc3, ws['dlogits'], M, dx=ws['df2'])
+        T_.colreduce(1, self.fc2.db, g=ws['df2'], a=ws['f2'], act='relu', dy_out=ws['df2'], M=M, C=F)
+        T_.wgrad(ws['f1cat'], ws['df2'], self.fc2.dk, M=M, precision=pr)
+        ops.gemm(ws['df2'], self.fc2.lin.bwd, ws['df1cat'], precision=pr)
+        g1 = ws['df1cat'][:, :F]
+        T_.colreduce(1, self.fc1.db, g=g1, a=ws['f1cat'][:, :F], act='relu', dy_out=g1, M=M, C=F)
+        T_.wgrad(ws['x2cat'], g1, self.fc1.dk, M=M, precision=pr)
+        ops.gemm(g1, self.fc1.lin.bwd, ws['dx2cat'], precision=pr)
+        # x2cat[:, :R] = H2 + x1: the GRU output gradient is dx2cat[:, :R]; the residual path joins dx1cat below
+        self._run(ws, 'gru2_bwd', lambda: self._gru_bwd(ws, ws['gi2'], ws['gh2'], ws['H2'], self.hh2, ws['dx2cat']))
+        self._gru_param_grads(ws, ws['x1cat'], ws['H2'], self.ih2, self.hh2)
+        ops.gemm(ws['dgi'], self.ih2.lin.bwd, ws['dx1cat'], precision=pr)
+        T_.axpby(ws['dx2cat'][:, :R], ws['dx1cat'][:, :R], alpha=1.0, beta=1.0, M=M, D=R)
+        self._run(ws, 'gru1_bwd', lambda: self._gru_bwd(ws, ws['gi1'], ws['gh1'], ws['H1'], self.hh1, ws['dx1cat']))
+        self._gru_param_grads(ws, ws['xI'], ws['H1'], self.ih1, self.hh1)
+        ops.gemm(ws['dgi'], self.ih1.lin.bwd, ws['dxI'], precision=pr, residual=ws['dx1cat'][:, :R])
+        self._lin_bwd(ws['xin'], self.I, ws['dxI'], M, dx=ws['dxin'])
+        T_.wavernn_prep_bwd(ws['dxin'], ws['dx1cat'][:, R:], ws['dx2cat'][:, R:], ws['df1cat'][:, F:], ws['mel'], ws['mel_off'],
+                            ws['d_aux'], ws['dfir'], self.fir_kmin, ws['B'], ws['Tf'], self.feat_dims, d, self.hop_length, self.pad)
+        tape[0](ws['d_aux'])
+        # three upsampling kernels: chain rule through the composite filter on the host
+        ups = composite_filter_gradients(self._up_host, self.upsample_factors, ws['dfir'].cpu().numpy())
+        for n, g in zip(self._up_names, ups):
+            st.g[n].copy_(torch.from_numpy(g.astype(np.float32)))
+        self._apply_gradients()
+        return ws['loss'][0]
+
+    def _gru_param_grads(self, ws, x_in, H, ih, hh):
+        M, T = ws['M'], ws['T']
+        T_.wgrad(x_in, ws['dgi'], ih.dk, M=M, precision=self.precision)
+        T_.colreduce(1, ih.db, g=ws['dgi'], M=M, C=3 * self.rnn_dims)
+        # h_{t-1} is H shifted by one step inside each window: a one-tap "convolution" with one row of left padding
+        T_.wgrad(H, ws['dgh'], hh.dk, taps=1, lpad=1, M=M, seg_len=T, precision=self.precision)
+        T_.colreduce(1, hh.db, g=ws['dgh'], M=M, C=3 * self.rnn_dims)
+
+    def _apply_gradients(self):
+        st = self.store
+        if self.world > 1:
+            parallel.allreduce_buckets(st.grad, self.bucket_elems, self.pg, self._comm)
+        self.iterations += 1
+        t = self.iterations
+        bc2 = math.sqrt(1.0 - self.beta2 ** t)
+        # torch: p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)  ==  lr_t * m / (sqrt(v) + eps * sqrt(1 - b2^t))
+        T_.adam(st.flat, st.grad, st.m, st.v, self.lr * bc2 / (1.0 - self.beta1 ** t), self.beta1, self.beta2, self.eps * bc2,
+                1.0 / self.world)
+        for lin in self._linears:
+            lin.repack()
+        self._refresh_fir()
+

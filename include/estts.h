@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 6
+#define ESTTS_ABI_VERSION 7
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -368,11 +368,13 @@ typedef struct estts_colreduce_args {
 int estts_colreduce(const estts_colreduce_args* args, void* stream);
 
 /* Batch statistics from mode-0 sums:  mean = z0 + s0 / M;  var = s1 / M - (s0 / M)^2 (biased);  rstd = (var + eps)^-1/2;
- * scale = gamma * rstd;  shift = beta - mean * scale;  moving = moving * momentum + batch * (1 - momentum).
+ * scale = gamma * rstd;  shift = beta - mean * scale;  moving_mean = moving_mean * momentum + mean * (1 - momentum);
+ * moving_var = moving_var * momentum + var * moving_var_scale * (1 - momentum)   (moving_var_scale: 1 for Keras,
+ * M / (M - 1) for torch.nn.BatchNorm1d, which stores the unbiased variance).
  * z0 is row 0 of the reduced matrix (the shift used by mode 0). */
 int estts_bn_finalize(const float* s0, const float* s1, const float* z0, int32_t M, int32_t C, float eps, float momentum,
-                      const float* gamma, const float* beta, float* moving_mean, float* moving_var, float* mean,
-                      float* rstd, float* scale, float* shift, void* stream);
+                      float moving_var_scale, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                      float* mean, float* rstd, float* scale, float* shift, void* stream);
 
 /* out[m, c] = act(z[m, c] * scale[c] + shift[c]) + (R ? R[r_mod ? m % r_mod : m, c] : 0)   (scale / shift NULL = 1 / 0) */
 int estts_affine_act(const float* z, int32_t ldz, const float* scale, const float* shift, int32_t act, const float* R,
@@ -412,6 +414,57 @@ int estts_masked_mae_bwd(const float* target, int32_t ldt, const float* pred, in
  * lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) is computed by the caller. */
 int estts_adam(float* p, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
                float eps, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * WaveRNN training (WaveRNN/train_wavernn.py:27-42: teacher-forced forward, loss, backward, Adam).
+ * ------------------------------------------------------------------------------------------ */
+
+/* One GRU time step on precomputed projections (gate order r, z, n as in estts_gru_gates), previous state read from
+ * h_prev and the new one written to h_out (the training pass keeps every state):
+ *   h_out = (1 - z) n + z h_prev;   out = h_out + (x_res ? x_res : 0)   (out may be NULL)
+ * Replaces: one time step of nn.GRU, fatchord_version.py:135-142. */
+int estts_gru_step_fwd(const float* gi, int32_t ldgi, const float* gh, int32_t ldgh, const float* h_prev, int32_t ldhp,
+                       float* h_out, int32_t ldho, const float* x_res, int32_t ldx, float* out, int32_t ldo, int32_t M,
+                       int32_t H, void* stream);
+
+/* Backward of that step.  The gradient w.r.t. h_out is dh (from the layer output) + dh_rec (from the next time step,
+ * NULL at the last one); writes dgi, dgh [M, 3H] (gradients of the two projections) and dh_prev = (dh + dh_rec) * z
+ * (the direct path; the caller adds dgh W_hh with estts_gemm to obtain the next dh_rec). */
+int estts_gru_step_bwd(const float* gi, int32_t ldgi, const float* gh, int32_t ldgh, const float* h_prev, int32_t ldhp,
+                       const float* dh, int32_t lddh, const float* dh_rec, int32_t lddhr, float* dgi, int32_t lddgi,
+                       float* dgh, int32_t lddgh, float* dh_prev, int32_t lddhp, int32_t M, int32_t H, void* stream);
+
+/* Backward of estts_wavernn_prep for teacher-forced windows: every utterance has `frames` frames of `hop` samples and
+ * row (u * frames + f) * hop + ph of the gradient matrices belongs to frame f, phase ph.
+ *   d_aux[u * frames + f, q * d + c] = sum_ph dq[row, c]        dq = (dxin + 1 + feat, da2, da3, da4) for q = 0..3
+ *   dfir[ph, j] += sum_{u, f, c} dxin[row, 1 + c] * mel[mel_off[u] + f + pad - (fir_kmin + j), c]     (float atomics)
+ * Replaces: the gradients autograd sends through UpsampleNetwork.forward's repeat / Conv2d chain and the aux slicing
+ * (fatchord_version.py:79-86,126-131). */
+typedef struct estts_wavernn_prep_bwd_args {
+    const float* dxin; int32_t ld_dxin;
+    const float* da2; int32_t ld_da2;
+    const float* da3; int32_t ld_da3;
+    const float* da4; int32_t ld_da4;
+    const float* mel; const int32_t* mel_off;
+    float* d_aux;             /* [n_utt * frames, 4 d] */
+    float* dfir;              /* [hop, ntaps], zeroed by the caller */
+    int32_t ntaps, fir_kmin;
+    int32_t n_utt, frames, feat, d, hop, pad;
+} estts_wavernn_prep_bwd_args;
+
+int estts_wavernn_prep_bwd(const estts_wavernn_prep_bwd_args* args, void* stream);
+
+/* Softmax cross-entropy over the last axis, forward and backward in one pass:
+ *   loss[0] += scale * sum_m (logsumexp(logits[m, :]) - logits[m, labels[m]]);  dlogits[m, c] = scale * (softmax - onehot)
+ * (scale = 1 / M gives F.cross_entropy's mean, train_wavernn.py:39,118).  loss[0] zeroed by the caller. */
+int estts_softmax_xent(const float* logits, int32_t ld, const int32_t* labels, float* loss, float* dlogits, int32_t lddl,
+                       int32_t M, int32_t C, float scale, void* stream);
+
+/* Discretized mixture-of-logistics negative log-likelihood and its gradient (WaveRNN/utility/distribution.py:16-84,
+ * reduce=True): y_hat [M, 3 nr_mix] = (mixture logits | means | log scales), y [M] in [-1, 1].
+ *   loss[0] += scale * sum_m nll_m;  d[m, :] = scale * d nll_m / d y_hat[m, :]      nr_mix <= 16 */
+int estts_mol_loss(const float* y_hat, int32_t ld, const float* y, float* loss, float* d, int32_t ldd, int32_t M,
+                   int32_t nr_mix, int32_t num_classes, float log_scale_min, float scale, void* stream);
 
 #ifdef __cplusplus
 }

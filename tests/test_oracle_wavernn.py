@@ -58,3 +58,29 @@ def test_fold_unfold_shapes_and_mu_law():
     assert labels.tolist() == [0.0, 256.0, 511.0]
     back = W.decode_mu_law(labels, 512)
     assert abs(back[0] + 1) < 1e-9 and abs(back[2] - 1) < 1e-9 and abs(back[1]) < 1e-4
+
+
+@pytest.mark.parametrize('mode', ['RAW', 'MOL'])
+def test_training_oracle_matches_reference_goldens(mode):
+    """oracle/wavernn_train_torch.py against one training step of the reference module itself (loss, every gradient,
+    BatchNorm running statistics, parameters after torch.optim.Adam)."""
+    from estts import weights
+    from oracle import wavernn_train_torch as OT
+    from wavernn_common import small_hp
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'wavernn_train_{mode.lower()}_small.npz'))
+    hp = small_hp(mode)
+    w = weights.init_wavernn(hp, seed=int(g['seed']))
+    ref = OT.train_step(w, hp, g['x'], g['y'], g['mels'])
+    assert abs(ref['loss'] - float(g['loss'])) < 2e-6 * max(1.0, abs(float(g['loss'])))
+    assert np.abs(ref['logits'] - g['logits']).max() < 2e-5
+    names = [k[5:] for k in g.files if k.startswith('grad/')]
+    assert set(names) == set(ref['grads'])
+    for k in names:
+        scale = max(np.abs(g['grad/' + k]).max(), 1e-6)
+        assert np.abs(ref['grads'][k] - g['grad/' + k]).max() / scale < 2e-3, k       # reference runs in float32
+    for k, v in ref['new_stats'].items():
+        assert np.abs(v - g['after/' + k]).max() < 1e-5, k
+    after = OT.adam_update(w, ref['grads'], {}, float(g['lr']), 1)
+    for k in names:
+        big = np.abs(g['grad/' + k]) > 0.05 * np.abs(g['grad/' + k]).max()           # the first Adam step is lr * sign(g)
+        assert np.abs(after[k] - g['after/' + k])[big].max() < 2e-6, k
