@@ -106,15 +106,19 @@ def wavernn_pass(precision):
 
 
 def roofline_from_trace(trace, kernel_table, rank):
-    """Times every traced launch in isolation and prices the dominant kernel group against its roofline."""
-    rows = time_kernels(trace)
-    total_iso = sum(r[2] for r in rows)
+    """Groups the traced launches by kernel and shape, times one representative of every group in isolation and prices
+    the dominant group against its roofline."""
     groups = {}
-    for kind, info, t in rows:
+    for kind, info, fn in trace:
         key = (kind,) + tuple(sorted((k, v) for k, v in info.items() if k not in ('flops', 'bytes')))
-        g = groups.setdefault(key, {'kind': kind, 'info': info, 'n': 0, 't': 0.0})
+        g = groups.setdefault(key, {'kind': kind, 'info': info, 'n': 0, 'fn': fn})
         g['n'] += 1
-        g['t'] += t
+    reps = time_kernels([(g['kind'], g['info'], g['fn']) for g in groups.values()])
+    for g, (_, _, t) in zip(groups.values(), reps):
+        g['t'] = t * g['n']
+        del g['fn']
+    total_iso = sum(g['t'] for g in groups.values())
+    rows = trace
     dom = max(groups.values(), key=lambda g: g['t'])
     if kernel_table and rank == 0:
         for g in sorted(groups.values(), key=lambda g: -g['t']):
@@ -220,6 +224,82 @@ def train_bench(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def train_wavernn_bench(args, rank, world, dist):
+    """WaveRNN training step (train_wavernn.py): `--batch` windows of 5 hops per GPU, RAW 9-bit, shipped hparams
+    (hop 200, 16 kHz): teacher-forced forward, cross-entropy, BPTT, all-reduce, Adam."""
+    from estts.wavernn_training import WaveRNNTrainer
+    hp = configs.wavernn_hparams(voc_mode='RAW')
+    B, hops = args.batch, 5
+    L = hops * hp['hop_length']
+    model = WaveRNNTrainer.from_hparams(hp, precision=args.precision)
+    w = weights.init_wavernn(hp, seed=1234)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    rng = np.random.default_rng(7 + rank)
+    n_cls = 2 ** hp['bits']
+    labels = rng.integers(0, n_cls, size=(B, L + 1))
+    x = (2 * labels[:, :L] / (n_cls - 1.) - 1.).astype(np.float32)
+    y = labels[:, 1:].astype(np.int64)
+    mels = rng.uniform(0, 1, size=(B, hp['num_mels'], hops + 2 * hp['voc_pad'])).astype(np.float32)
+    xd, yd, md = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(mels).cuda()
+
+    def step():
+        return model.train_step(xd, yd, md, lr=1e-4)
+
+    ops.start_trace()
+    loss0 = float(step())                 # eager pass: every launch is traced once (the loops are captured afterwards)
+    trace = ops.stop_trace()
+    torch.cuda.synchronize()
+    roofline, launches = roofline_from_trace(trace, args.kernel_table, rank)
+    del trace
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import wavernn_train_torch as OWT
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+        bs = min(B, 4)
+        t0 = time.perf_counter()
+        OWT.train_step(w, hp, x[:bs], y[:bs], mels[:bs], dtype=torch.float32)
+        t_cpu = time.perf_counter() - t0
+        cpu = {'value': bs * L / t_cpu, 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': f'1 training step (forward + autograd backward, no optimizer) on {bs} of the {B} windows of {L} samples, '
+                         f'PyTorch CPU float32 restatement (oracle/wavernn_train_torch.py)'}
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        macs = 4_071_936                       # per sample per sequence, RAW-512 (fatchord_version.py:109-114 layer sizes)
+        line = {
+            'metric': 'samples/sec (WaveRNN training step)', 'value': world * B * L / (dt / args.steps), 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 1), 'ms_per_step': dt * 1e3 / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'WaveRNN train step (RAW 9-bit, hop 200): teacher-forced forward over {L}-sample windows, '
+                                   f'cross-entropy, BPTT through both GRUs, gradient all-reduce, Adam; batch={B} per GPU; '
+                                   f'{args.precision} MFMA operands, fp32 accumulate, fp32 master weights',
+                       'global_batch': world * B, 'parallelism': f'dp{world}', 'hip_graph': True, 'launches_per_step': launches},
+            'steps_per_s': args.steps / dt, 'algorithmic_tflops': world * 3 * 2.0 * macs * B * L / (dt / args.steps) / 1e12,
+            'loss_first_step': loss0, 'loss_last_step': float(loss), 'roofline': roofline, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -234,7 +314,7 @@ def main():
                     help='skip materialising the attention maps the reference returns')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
-    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train'],
+    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn'],
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
                          "AutoregressiveTransformer (config 3; use --batch 32); train: ForwardTransformer training step, "
                          "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
@@ -253,6 +333,8 @@ def main():
     want_attn = not args.no_attention_weights
     if args.workload == 'train':
         return train_bench(args, rank, world, dist)
+    if args.workload == 'train_wavernn':
+        return train_wavernn_bench(args, rank, world, dist)
     if args.workload == 'forward':
         cfg = configs.forward_config()
         w = weights.init_forward_transformer(cfg, seed=1234)

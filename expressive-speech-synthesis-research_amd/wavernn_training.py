@@ -267,8 +267,12 @@ class WaveRNNTrainer:
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.graph(g, stream=side):   # ... and record the same launches for the following steps
-                fn()
+            traced, ops._trace = ops._trace, None     # (a launch trace, if one is running, has seen them already)
+            try:
+                with torch.cuda.graph(g, stream=side):   # ... and record the same launches for the following steps
+                    fn()
+            finally:
+                ops._trace = traced
             torch.cuda.current_stream().wait_stream(side)
             ws['graphs'][name] = g
             return None
