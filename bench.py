@@ -134,8 +134,19 @@ def roofline_from_trace(trace, kernel_table, rank):
     else:
         roofline = {'bound': 'hbm', 'achieved': dom['info']['bytes'] / avg / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s'}
     roofline['frac'] = roofline['achieved'] / roofline['peak']
-    roofline['traffic'] = None
     roofline['kernel'] = dom['kind'] + ' ' + json.dumps({k: v for k, v in dom['info'].items() if k not in ('flops', 'bytes')})
+    # HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 --pmc on this same
+    # command); null when the dominant kernel of this run has no such measurement
+    roofline['traffic'] = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as f:
+            pmc = json.load(f).get(roofline['kernel'])
+        if pmc:
+            roofline['traffic'] = pmc['hbm_bytes']
+            roofline['traffic_source'] = pmc['source']
+            roofline['algorithmic_bytes'] = dom['info']['bytes']
+    except OSError:
+        pass
     roofline['avg_us'] = avg * 1e6
     roofline['launches_per_step'] = dom['n']
     roofline['share_of_step'] = dom['t'] / total_iso
