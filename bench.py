@@ -311,6 +311,46 @@ def train_wavernn_bench(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def predict_bench(args, rank, world, dist):
+    """AutoregressiveTransformer.predict (the call synthesize_sentences_speaker.py makes): one utterance, N tokens,
+    `--frames` mel frames (the stop class is disabled so that the length is fixed), incremental decoder vs the reference's
+    re-decode-everything loop.  `--steps` = utterances timed."""
+    from estts.autoregressive_transformer import AutoregressiveTransformer
+    cfg = configs.autoregressive_config(system_type='style_text')
+    w = weights.init_autoregressive_transformer(cfg, seed=1234)
+    w['decoder_postnet.stop_linear.bias'] = np.array([5.0, 0.0, -5.0], np.float32)
+    rng = np.random.default_rng(1234 + rank)
+    N, T = args.tokens, args.frames
+    tokens = rng.integers(1, cfg['vocab_size'], size=N)
+    ref_mel = np.clip(rng.normal(0, 1.5, size=(400, 80)), -4, 4).astype(np.float32)
+    model = AutoregressiveTransformer(w, cfg, precision=args.precision)
+    res = {}
+    for r in (10, 1):
+        model.set_constants(reduction_factor=r)
+        for cached in (True, False):
+            if not cached and r == 1 and T > 300:
+                continue                                   # the quadratic loop at r = 1 takes tens of seconds
+            model.predict(tokens, ref_mel, None, max_length=min(T, 4 * r), encode=False, verbose=False, kv_cache=cached)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = model.predict(tokens, ref_mel, None, max_length=T - r, encode=False, verbose=False, kv_cache=cached)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            res[f'r{r}_{"incremental" if cached else "full_redecode"}'] = {'frames': int(out['mel'].shape[0]), 's_per_utterance': dt,
+                                                                           'mel_frames_per_s': out['mel'].shape[0] / dt}
+    if rank == 0:
+        best = res['r10_incremental']
+        print(json.dumps({'metric': 'mel-frames/sec (AutoregressiveTransformer.predict, one utterance)', 'value': best['mel_frames_per_s'],
+                          'unit': 'mel-frames/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': 1, 'ms_per_step': best['s_per_utterance'] * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+                          'config': {'workload': f'AR predict, style_text, N={N}, {T} frames, reduction factor 10 (value) and 1; '
+                                                 f'{args.precision} MFMA operands'},
+                          'variants': res, 'roofline': None, 'cpu_baseline': None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -325,7 +365,7 @@ def main():
                     help='skip materialising the attention maps the reference returns')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
-    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn'],
+    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn', 'predict'],
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
                          "AutoregressiveTransformer (config 3; use --batch 32); train: ForwardTransformer training step, "
                          "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
@@ -346,6 +386,8 @@ def main():
         return train_bench(args, rank, world, dist)
     if args.workload == 'train_wavernn':
         return train_wavernn_bench(args, rank, world, dist)
+    if args.workload == 'predict':
+        return predict_bench(args, rank, world, dist)
     if args.workload == 'forward':
         cfg = configs.forward_config()
         w = weights.init_forward_transformer(cfg, seed=1234)

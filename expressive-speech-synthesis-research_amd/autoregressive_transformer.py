@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .blocks import (ConvBNLayer, CrossAttentionStack, SelfAttentionStack, _dev_vec, pack_dense)
+from .blocks import (ConvBNLayer, CrossAttentionStack, FFNLayer, SelfAttentionStack, _dev_vec, pack_dense)
 from .ops import PackedLinear, fold_batchnorm, same_pad
 from .text import Tokenizer, default_alphabet
 from .weights import encoder_output_dim
@@ -279,10 +279,132 @@ class AutoregressiveTransformer:
 
     __call__ = call
 
-    def predict(self, inp, targets, spk_embed, max_length=1000, encode=True, verbose=True):
-        """AutoregressiveTransformer.py:265-296: encoder once, then the decoder is re-run on the growing output (as the
-        reference does, O(T^2) decoder work) until the stop class wins.  inp: phoneme string (encode=True) or token ids;
-        targets: reference mel (T, 80) for the style encoder or None; spk_embed: (1, D) or None."""
+    # ------------------------------------------------------------------ incremental decoding
+    @staticmethod
+    def _as_dense(lin):
+        """The same packed convolution weight seen as a dense layer over a flattened window of `taps` rows."""
+        import copy
+        d = copy.copy(lin)
+        d.taps, d.lpad, d.c_per_tap = 1, 0, lin.K
+        return d
+
+    @staticmethod
+    def _windows(hist, t0, rows, k, cin):
+        """[rows, k * cin] view of a row-major history buffer [(k - 1) + T, cin] (k - 1 leading zero rows): row j is the
+        causal window that ends at time t0 + j."""
+        return torch.as_strided(hist, (rows, k * cin), (cin, 1), hist.storage_offset() + t0 * cin)
+
+    def _predict_incremental(self, inp, targets, spk_embed, max_length, encode, verbose):
+        if self.decoder_prenet_dropout != 0.0:
+            raise NotImplementedError('decoder prenet dropout > 0 is not available in the inference kernels yet')
+        dev, f32, pr = self.device, dict(dtype=torch.float32, device=self.device), self.precision
+        d, r, C = self.dd, self.r, self.mel_channels
+        if targets is not None:
+            targets = self.encode_ref(targets)
+        if spk_embed is not None:
+            spk_embed = torch.as_tensor(spk_embed, dtype=torch.float32, device=dev)[None]
+        if encode:
+            inp = self.encode_text(inp)
+        inp = torch.as_tensor(np.asarray(inp), dtype=torch.int32, device=dev)[None]
+        enc, mask, text_attn, gst_attn, gst_tokens, _, _ = self.call_encoder(inp, targets, spk_embed)
+        N = enc.shape[1]
+        enc2 = enc.reshape(N, -1)
+        enc_mask = mask.reshape(1, N).contiguous()
+        S = int(max_length // r) + 1                                  # decoder steps at most
+        if (S - 1) * r >= self.pe_dec.shape[0]:
+            raise ValueError('max_length exceeds decoder_max_position_encoding')
+        blocks = self.decoder.blocks
+        H = [ca.heads for _, ca, _ in blocks]
+        # encoder keys / values once per block; per-position caches
+        kv_enc = [torch.empty(N, 2 * d, **f32) for _ in blocks]
+        for (_, ca, _), kv in zip(blocks, kv_enc):
+            ca.project_kv(enc2, kv, pr)
+        qkv = [torch.empty(S, 3 * d, **f32) for _ in blocks]         # row i = [q | k | v] of decoder position i
+        slab = [(h * N + 3) // 4 * 4 for h in H]                       # per-step weights [1, h, 1, N], 16-byte aligned slabs
+        attn = [torch.empty(S, sl, **f32) for sl in slab]
+        conv_hist, conv_dense = [], []
+        for _, _, ff in blocks:
+            if isinstance(ff, FFNLayer):
+                conv_hist.append(None)
+                conv_dense.append(None)
+            else:
+                k = ff.layers[0].taps
+                conv_hist.append([torch.zeros(k - 1 + S, lin.c_per_tap, **f32) for lin in ff.layers])
+                conv_dense.append([self._as_dense(lin) for lin in ff.layers])
+        kp = self.postnet.layers[0].taps
+        post_hist = [torch.zeros(kp - 1 + S * r, lin.c_per_tap, **f32) for lin in self.postnet.layers]
+        post_dense = [self._as_dense(lin) for lin in self.postnet.layers]
+        final = torch.empty(S * r, C, **f32)
+        stop = torch.empty(S * r, 3, **f32)
+        dec_mask = torch.zeros(1, S, **f32)
+        xc, xc2 = torch.empty(1, 2 * d, **f32), torch.empty(1, 2 * d, **f32)
+        y, x2, q = torch.empty(1, d, **f32), torch.empty(1, d, **f32), torch.empty(1, d, **f32)
+        p1 = torch.empty(1, self.prenet1.N, **f32)
+        hid = torch.empty(1, max(self.decoder.hidden, 4), **f32)
+        lin_r = self._final_proj(r)
+        sqrt_d = math.sqrt(np.float32(d))
+        steps = 0
+        for i in range(S):
+            frame = self.start_vec if i == 0 else final[i * r - 1:i * r]
+            ops.row_zero_mask(frame, dec_mask[0, i:i + 1])
+            ops.gemm(frame, self.prenet1, p1, precision=pr)
+            ops.gemm(p1, self.prenet2, xc[:, :d], alpha=sqrt_d, residual=self.pe_dec[i * r:i * r + 1], precision=pr)
+            for b, (sa, ca, ff) in enumerate(blocks):
+                row = qkv[b][i:i + 1]
+                ops.gemm(xc[:, :d], sa.qkv, row, precision=pr)
+                ops.attention(row[:, :d], qkv[b][:i + 1, d:2 * d], qkv[b][:i + 1, 2 * d:], xc[:, d:], 1, sa.heads, 1, i + 1,
+                              d // sa.heads, key_mask=dec_mask[:, :i + 1], precision=pr)
+                ops.gemm(xc, sa.out, y, precision=pr)
+                ops.rownorm(y, xc2[:, :d], ln_a=sa.ln, residual=xc[:, :d], ln_b=sa.last_ln)
+                ops.gemm(xc2[:, :d], ca.wq, q, precision=pr)
+                ops.attention(q, kv_enc[b][:, :d], kv_enc[b][:, d:], xc2[:, d:], 1, ca.heads, 1, N, d // ca.heads,
+                              key_mask=enc_mask, attn=attn[b][i, :ca.heads * N].view(1, ca.heads, 1, N), precision=pr)
+                ops.gemm(xc2, ca.out, y, precision=pr)
+                if isinstance(ff, FFNLayer):
+                    ops.rownorm(y, x2, residual=xc2[:, :d], ln_b=ca.ln)
+                    ff.run(x2, hid, y, xc[:, :d], pr)
+                else:
+                    hist, dense = conv_hist[b], conv_dense[b]
+                    k = ff.layers[0].taps
+                    src_row = hist[0][k - 1 + i:k + i]                 # this position's row of the first history
+                    ops.rownorm(y, src_row, residual=xc2[:, :d], ln_b=ca.ln)
+                    for li, lin in enumerate(dense[:-1]):
+                        ops.gemm(self._windows(hist[li], i, 1, k, lin.K // k), lin, hist[li + 1][k - 1 + i:k + i], precision=pr)
+                    last = len(dense) - 1
+                    ops.gemm(self._windows(hist[last], i, 1, k, dense[last].K // k), dense[last], xc[:, :d], residual=src_row,
+                             precision=pr)
+            mel_rows = post_hist[0][kp - 1 + i * r:kp - 1 + (i + 1) * r]          # FinalProj writes the r new mel frames here
+            ops.gemm(xc[:, :d], lin_r, mel_rows.view(1, r * C), precision=pr)
+            ops.gemm(mel_rows, self.stop_linear, stop[i * r:(i + 1) * r], precision=pr)
+            for li, lin in enumerate(post_dense[:-1]):
+                ops.gemm(self._windows(post_hist[li], i * r, r, kp, lin.K // kp), lin,
+                         post_hist[li + 1][kp - 1 + i * r:kp - 1 + (i + 1) * r], precision=pr)
+            last = len(post_dense) - 1
+            ops.gemm(self._windows(post_hist[last], i * r, r, kp, post_dense[last].K // kp), post_dense[last],
+                     final[i * r:(i + 1) * r], residual=mel_rows, precision=pr)
+            steps = i + 1
+            stop_pred = stop[(i + 1) * r - 1].cpu()                      # host decision every step, as in the reference
+            if verbose:
+                print(f'\rpred text mel: {i} stop out: {float(stop_pred[2])}', end='')
+            if int(torch.argmax(stop_pred)) == self.stop_prob_index:
+                if verbose:
+                    print('Stopping')
+                break
+        dec_attn = {name: a[:steps, :h * N].reshape(steps, h, N).permute(1, 0, 2)[None].contiguous()
+                    for name, a, h in zip(self.decoder.names, attn, H)}
+        return {'mel': final[:steps * r].clone(), 'decoder_attention': dec_attn, 'text_encoder_attention': text_attn,
+                'gst_encoder_attention': gst_attn, 'gst_tokens': gst_tokens}
+
+    def predict(self, inp, targets, spk_embed, max_length=1000, encode=True, verbose=True, kv_cache=True):
+        """AutoregressiveTransformer.py:265-296.  inp: phoneme string (encode=True) or token ids; targets: reference mel
+        (T, 80) for the style encoder or None; spk_embed: (1, D) or None.
+
+        kv_cache=True (default) decodes incrementally: every step computes only the new decoder position against cached
+        self-attention keys / values, the once-projected encoder keys / values and the causal-convolution histories,
+        which gives the same numbers as the reference's loop (all its masks are causal) in O(T) decoder work.
+        kv_cache=False re-runs the whole decoder on the growing output each step, literally as the reference does."""
+        if kv_cache:
+            return self._predict_incremental(inp, targets, spk_embed, max_length, encode, verbose)
         dev = self.device
         if targets is not None:
             targets = self.encode_ref(targets)

@@ -132,7 +132,31 @@ def test_predict_loop_vs_oracle():
     ref_mel = np.clip(rng.normal(0, 1.5, size=(30, 80)), -4, 4).astype(np.float32)
     model = AutoregressiveTransformer(w, cfg)
     model.set_constants(reduction_factor=2)
-    out = model.predict(tokens, ref_mel, None, max_length=24, encode=False, verbose=False)
     ref = O.autoregressive_predict(w, cfg, tokens, ref_mel, None, r=2, max_length=24)
-    assert out['mel'].shape == ref['mel'].shape
-    assert np.abs(out['mel'].cpu().numpy() - ref['mel']).max() < 5e-4
+    outs = {}
+    for cached in (False, True):      # the reference's re-decode-everything loop and the incremental (KV-cached) decoder
+        out = outs[cached] = model.predict(tokens, ref_mel, None, max_length=24, encode=False, verbose=False, kv_cache=cached)
+        assert out['mel'].shape == ref['mel'].shape
+        assert np.abs(out['mel'].cpu().numpy() - ref['mel']).max() < 5e-4
+    assert np.abs(outs[True]['mel'].cpu().numpy() - outs[False]['mel'].cpu().numpy()).max() < 2e-4
+    for name, a in outs[False]['decoder_attention'].items():
+        assert outs[True]['decoder_attention'][name].shape == a.shape
+        assert np.abs(outs[True]['decoder_attention'][name].cpu().numpy() - a.cpu().numpy()).max() < 1e-3
+
+
+@pytest.mark.parametrize('system_type,r,conv_blocks', [('speaker_text', 1, True), ('text', 3, False)])
+def test_incremental_predict_matches_full_redecode(system_type, r, conv_blocks):
+    """Same mel from the O(T) cached decoder and the O(T^2) loop, with causal-conv decoder blocks and with dense ones,
+    run to max_length (the stop class never wins with this bias)."""
+    cfg = small_cfg(system_type, dense=1 if conv_blocks else 2)
+    w = weights.init_autoregressive_transformer(cfg, seed=21)
+    w['decoder_postnet.stop_linear.bias'] = np.array([0.5, 0.0, -0.5], np.float32)
+    rng = np.random.default_rng(8)
+    tokens = rng.integers(1, cfg['vocab_size'], size=11)
+    spk = rng.normal(size=(1, cfg['speaker_embed_dim'])).astype(np.float32) if 'speaker' in system_type else None
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=r)
+    a = model.predict(tokens, None, spk, max_length=6 * r, encode=False, verbose=False, kv_cache=False)
+    b = model.predict(tokens, None, spk, max_length=6 * r, encode=False, verbose=False, kv_cache=True)
+    assert a['mel'].shape == b['mel'].shape == (7 * r, 80)
+    assert np.abs(a['mel'].cpu().numpy() - b['mel'].cpu().numpy()).max() < 2e-4
