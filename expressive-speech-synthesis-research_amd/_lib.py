@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -68,6 +68,18 @@ class WavernnPrepBwdArgs(C.Structure):
                 ('hop', _i32), ('pad', _i32)]
 
 
+class RowmaskArgs(C.Structure):
+    _fields_ = [('x', _vp), ('ldx', _i32), ('mask', _vp), ('M', _i32), ('D', _i32)]
+
+
+PROG_MAX_PATCH = 8
+
+
+class ProgOp(C.Structure):
+    _fields_ = [('kind', _i32), ('n_patch', _i32), ('args', _vp), ('patch_offset', _i32 * PROG_MAX_PATCH),
+                ('patch_is_ptr', _i32 * PROG_MAX_PATCH), ('patch_stride', _i64 * PROG_MAX_PATCH)]
+
+
 class ColreduceArgs(C.Structure):
     _fields_ = [('z', _vp), ('ldz', _i32), ('g', _vp), ('ldg', _i32), ('a', _vp), ('lda', _i32), ('act', _i32),
                 ('mean', _vp), ('rstd', _vp), ('out0', _vp), ('out1', _vp), ('dy_out', _vp), ('lddy', _i32),
@@ -122,6 +134,7 @@ SIGNATURES = {
     'estts_gru_step_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_wavernn_prep_bwd': (_i32, [C.POINTER(WavernnPrepBwdArgs), _vp]),
     'estts_softmax_xent': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    'estts_run_program': (_i32, [C.POINTER(ProgOp), _i32, _i32, _vp]),
     'estts_mol_loss': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
 }
 

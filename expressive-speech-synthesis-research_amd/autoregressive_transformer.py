@@ -294,7 +294,7 @@ class AutoregressiveTransformer:
         causal window that ends at time t0 + j."""
         return torch.as_strided(hist, (rows, k * cin), (cin, 1), hist.storage_offset() + t0 * cin)
 
-    def _predict_incremental(self, inp, targets, spk_embed, max_length, encode, verbose):
+    def _predict_incremental(self, inp, targets, spk_embed, max_length, encode, verbose, program=True):
         if self.decoder_prenet_dropout != 0.0:
             raise NotImplementedError('decoder prenet dropout > 0 is not available in the inference kernels yet')
         dev, f32, pr = self.device, dict(dtype=torch.float32, device=self.device), self.precision
@@ -334,7 +334,10 @@ class AutoregressiveTransformer:
         kp = self.postnet.layers[0].taps
         post_hist = [torch.zeros(kp - 1 + S * r, lin.c_per_tap, **f32) for lin in self.postnet.layers]
         post_dense = [self._as_dense(lin) for lin in self.postnet.layers]
-        final = torch.empty(S * r, C, **f32)
+        # rows r - 1 + i r of `frames` feed step i: the start vector, then the last frame of every earlier step
+        frames = torch.empty(r + S * r, C, **f32)
+        frames[r - 1:r].copy_(self.start_vec)
+        final = frames[r:]
         stop = torch.empty(S * r, 3, **f32)
         dec_mask = torch.zeros(1, S, **f32)
         xc, xc2 = torch.empty(1, 2 * d, **f32), torch.empty(1, 2 * d, **f32)
@@ -343,9 +346,9 @@ class AutoregressiveTransformer:
         hid = torch.empty(1, max(self.decoder.hidden, 4), **f32)
         lin_r = self._final_proj(r)
         sqrt_d = math.sqrt(np.float32(d))
-        steps = 0
-        for i in range(S):
-            frame = self.start_vec if i == 0 else final[i * r - 1:i * r]
+
+        def step(i):
+            frame = frames[r - 1 + i * r:r + i * r]
             ops.row_zero_mask(frame, dec_mask[0, i:i + 1])
             ops.gemm(frame, self.prenet1, p1, precision=pr)
             ops.gemm(p1, self.prenet2, xc[:, :d], alpha=sqrt_d, residual=self.pe_dec[i * r:i * r + 1], precision=pr)
@@ -382,6 +385,15 @@ class AutoregressiveTransformer:
             last = len(post_dense) - 1
             ops.gemm(self._windows(post_hist[last], i * r, r, kp, post_dense[last].K // kp), post_dense[last],
                      final[i * r:(i + 1) * r], residual=mel_rows, precision=pr)
+
+        # every launch argument is affine in i: record steps 0 and 1 once, then issue each step from one C call
+        prog = ops.StepProgram(step) if program and S >= 2 else None
+        steps = 0
+        for i in range(S):
+            if prog is not None:
+                prog.run(i)
+            else:
+                step(i)
             steps = i + 1
             stop_pred = stop[(i + 1) * r - 1].cpu()                      # host decision every step, as in the reference
             if verbose:

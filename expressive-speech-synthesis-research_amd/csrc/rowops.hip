@@ -334,3 +334,49 @@ extern "C" int estts_masked_mae(const float* target, int32_t ldt, const float* p
     ESTTS_CHECK_LAUNCH("estts_masked_mae");
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// step programs (see estts_run_program in include/estts.h): host-side loop, no kernel of its own
+extern "C" int estts_run_program(const estts_prog_op* ops, int32_t n_ops, int32_t step, void* stream) {
+    ESTTS_CHECK_ARG(ops != nullptr && n_ops > 0 && step >= 0, "estts_run_program: bad arguments");
+    union {
+        estts_gemm_args g;
+        estts_attention_args a;
+        estts_rownorm_args r;
+        estts_rowmask_args m;
+    } blk;
+    static const size_t sizes[4] = {sizeof(estts_gemm_args), sizeof(estts_attention_args), sizeof(estts_rownorm_args),
+                                    sizeof(estts_rowmask_args)};
+    for (int i = 0; i < n_ops; ++i) {
+        const estts_prog_op& op = ops[i];
+        ESTTS_CHECK_ARG(op.kind >= 0 && op.kind < 4 && op.args && op.n_patch >= 0 && op.n_patch <= ESTTS_PROG_MAX_PATCH,
+                        "estts_run_program: op %d is malformed", i);
+        memcpy(&blk, op.args, sizes[op.kind]);
+        char* base = reinterpret_cast<char*>(&blk);
+        for (int k = 0; k < op.n_patch; ++k) {
+            const int off = op.patch_offset[k];
+            ESTTS_CHECK_ARG(off >= 0 && (size_t)off + (op.patch_is_ptr[k] ? 8 : 4) <= sizes[op.kind], "estts_run_program: op %d patch %d out of range", i, k);
+            if (op.patch_is_ptr[k]) {
+                char* ptr;
+                memcpy(&ptr, base + off, sizeof(ptr));
+                ptr += (int64_t)step * op.patch_stride[k];
+                memcpy(base + off, &ptr, sizeof(ptr));
+            } else {
+                int32_t v;
+                memcpy(&v, base + off, sizeof(v));
+                v += (int32_t)((int64_t)step * op.patch_stride[k]);
+                memcpy(base + off, &v, sizeof(v));
+            }
+        }
+        int rc = 0;
+        switch (op.kind) {
+            case 0: rc = estts_gemm(&blk.g, stream); break;
+            case 1: rc = estts_attention(&blk.a, stream); break;
+            case 2: rc = estts_rownorm(&blk.r, stream); break;
+            default: rc = estts_row_zero_mask(blk.m.x, blk.m.ldx, blk.m.mask, blk.m.M, blk.m.D, stream); break;
+        }
+        if (rc != 0) return rc;
+    }
+    return 0;
+}

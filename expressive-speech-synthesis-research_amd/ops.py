@@ -3,6 +3,7 @@
 torch is used for device memory and the current stream only; no torch op
 computes anything on the hot path.
 """
+import ctypes
 import math
 import os
 import sys
@@ -42,6 +43,56 @@ def _record(kind, info, fn, *args, keep=()):
         torch.cuda.synchronize()
     if _trace is not None:
         _trace.append((kind, info, lambda _keep=tuple(keep): fn(*args, _stream())))
+
+
+# When set to a list, gemm / attention / rownorm / row_zero_mask append (kind, argument block, tensors) instead of
+# launching: see StepProgram.
+_program = None
+
+
+class StepProgram:
+    """A fixed sequence of launches whose arguments depend affinely on a step index, issued from one C call per step
+    (estts_run_program).  Built by recording the same Python code for step 0 and step 1: every argument field that
+    differs between the two recordings becomes a patch `field += step * (value1 - value0)`."""
+
+    KINDS = {'gemm': 0, 'attention': 1, 'rownorm': 2, 'row_zero_mask': 3}
+
+    def __init__(self, record_step):
+        """record_step(i): issues the launches of step i through this module's op functions."""
+        global _program
+        recs = []
+        for i in (0, 1):
+            _program = []
+            try:
+                record_step(i)
+            finally:
+                recs.append(_program)
+                _program = None
+        r0, r1 = recs
+        if len(r0) != len(r1) or any(a[0] != b[0] for a, b in zip(r0, r1)):
+            raise RuntimeError('StepProgram: steps 0 and 1 issue different launch sequences')
+        self._keep = (r0, r1)
+        self.n = len(r0)
+        self.ops = (_lib.ProgOp * self.n)()
+        for j, ((kind, a0, _), (_, a1, _)) in enumerate(zip(r0, r1)):
+            op = self.ops[j]
+            op.kind = self.KINDS[kind]
+            op.args = ctypes.addressof(a0)
+            k = 0
+            for name, ftype in a0._fields_:
+                v0, v1 = getattr(a0, name) or 0, getattr(a1, name) or 0
+                if v0 == v1:
+                    continue
+                if ftype not in (ctypes.c_void_p, ctypes.c_int32) or k >= _lib.PROG_MAX_PATCH:
+                    raise RuntimeError(f'StepProgram: field {name} of a {kind} launch cannot be patched')
+                op.patch_offset[k] = getattr(type(a0), name).offset
+                op.patch_is_ptr[k] = int(ftype is ctypes.c_void_p)
+                op.patch_stride[k] = int(v1 - v0)
+                k += 1
+            op.n_patch = k
+
+    def run(self, step):
+        check(_lib.load().estts_run_program(self.ops, self.n, step, _stream()), 'estts_run_program')
 
 
 def _stream():
@@ -160,6 +211,9 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
         raise ValueError(f'gemm: x has {x.shape[1]} columns, weight expects K={lin.K}')
     if out.shape[1] < lin.N:
         raise ValueError(f'gemm: out has {out.shape[1]} columns, weight produces N={lin.N}')
+    if _program is not None:
+        _program.append(('gemm', a, (x, out, residual, lin)))
+        return out
     check(_lib.load().estts_gemm(a, _stream()), 'estts_gemm')
     nsplit = 2 if precision == 'bf16x3' else 1
     _record('gemm', {'M': M, 'N': lin.N, 'K': lin.K, 'taps': lin.taps, 'flops': 2.0 * M * lin.N * lin.K,
@@ -187,6 +241,9 @@ def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, at
     a.causal = int(causal)
     a.precision = PRECISION[precision]
     a.kv_shared = int(kv_shared)
+    if _program is not None:
+        _program.append(('attention', a, (q, k, v, ctx, attn, key_mask)))
+        return ctx
     check(_lib.load().estts_attention(a, _stream()), 'estts_attention')
     _record('attention', {'B': B, 'H': H, 'Lq': Lq, 'Lk': Lk, 'depth': depth, 'weights': attn is not None,
                           'flops': 4.0 * B * H * Lq * Lk * depth,
@@ -232,6 +289,9 @@ def rownorm(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=N
     """out = LNb(dropout(act(LNa(y))) + residual); ln_a / ln_b are (gamma, beta) tensor pairs or None;
     dropout = (rate, seed, site) or None."""
     a = rownorm_args(y, out, ln_a, act, residual, ln_b, eps, M, D, dot_w, dot_b, dot_scale, dot_mask, dot_out, dropout)
+    if _program is not None:
+        _program.append(('rownorm', a, a._keep))
+        return out
     check(_lib.load().estts_rownorm(a, _stream()), 'estts_rownorm')
     _record('rownorm', {'M': a.M, 'D': a.D, 'flops': 0.0,
                         'bytes': 4.0 * a.M * a.D * (1 + (residual is not None) + (out is not None))},
@@ -305,6 +365,9 @@ def gru_gates(gi, gh, h, out, x_res=None, M=None, H=None):
 def row_zero_mask(x, mask, M=None, D=None):
     M = x.shape[0] if M is None else M
     D = x.shape[1] if D is None else D
+    if _program is not None:
+        _program.append(('row_zero_mask', _lib.RowmaskArgs(x.data_ptr(), x.stride(0), mask.data_ptr(), M, D), (x, mask)))
+        return mask
     check(_lib.load().estts_row_zero_mask(x.data_ptr(), x.stride(0), mask.data_ptr(), M, D, _stream()), 'estts_row_zero_mask')
     _record('row_zero_mask', {'M': M, 'D': D, 'flops': 0.0, 'bytes': 4.0 * M * (D + 1)},
             _lib.load().estts_row_zero_mask, x.data_ptr(), x.stride(0), mask.data_ptr(), M, D, keep=(x, mask))

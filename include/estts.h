@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 7
+#define ESTTS_ABI_VERSION 8
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -465,6 +465,33 @@ int estts_softmax_xent(const float* logits, int32_t ld, const int32_t* labels, f
  *   loss[0] += scale * sum_m nll_m;  d[m, :] = scale * d nll_m / d y_hat[m, :]      nr_mix <= 16 */
 int estts_mol_loss(const float* y_hat, int32_t ld, const float* y, float* loss, float* d, int32_t ldd, int32_t M,
                    int32_t nr_mix, int32_t num_classes, float log_scale_min, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step programs: a fixed sequence of launches whose arguments depend affinely on a step index (an incremental decoder:
+ * row i of a cache, a key range of i + 1, ...).  Each op carries the argument block of step 0 and a patch list; at step s
+ * the field at byte `offset` of a copy of the block is advanced by s * stride (a pointer, in bytes, or an int32), then the
+ * op's entry point is called.  This issues a whole decoder step from one host call, without rebuilding argument blocks
+ * in the host language.  No counterpart in the reference (its loop, model/AutoregressiveTransformer.py:279-296, re-runs
+ * the whole Keras decoder every step).
+ * kind: 0 estts_gemm, 1 estts_attention, 2 estts_rownorm, 3 estts_row_zero_mask (args = estts_rowmask_args).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct estts_rowmask_args {
+    const float* x; int32_t ldx;
+    float* mask;
+    int32_t M, D;
+} estts_rowmask_args;
+
+#define ESTTS_PROG_MAX_PATCH 8
+typedef struct estts_prog_op {
+    int32_t kind;
+    int32_t n_patch;
+    const void* args;
+    int32_t patch_offset[ESTTS_PROG_MAX_PATCH];
+    int32_t patch_is_ptr[ESTTS_PROG_MAX_PATCH];
+    int64_t patch_stride[ESTTS_PROG_MAX_PATCH];
+} estts_prog_op;
+
+int estts_run_program(const estts_prog_op* ops, int32_t n_ops, int32_t step, void* stream);
 
 #ifdef __cplusplus
 }

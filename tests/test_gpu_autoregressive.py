@@ -160,3 +160,21 @@ def test_incremental_predict_matches_full_redecode(system_type, r, conv_blocks):
     b = model.predict(tokens, None, spk, max_length=6 * r, encode=False, verbose=False, kv_cache=True)
     assert a['mel'].shape == b['mel'].shape == (7 * r, 80)
     assert np.abs(a['mel'].cpu().numpy() - b['mel'].cpu().numpy()).max() < 2e-4
+
+
+def test_step_program_equals_eager_launches():
+    """The incremental decoder issued through the C step program (launch arguments patched per step) gives bit-identical
+    output to the same launches issued one by one."""
+    cfg = small_cfg('speaker_text', dense=1)
+    w = weights.init_autoregressive_transformer(cfg, seed=4)
+    w['decoder_postnet.stop_linear.bias'] = np.array([0.5, 0.0, -0.5], np.float32)
+    rng = np.random.default_rng(2)
+    tokens = rng.integers(1, cfg['vocab_size'], size=13)
+    spk = rng.normal(size=(1, cfg['speaker_embed_dim'])).astype(np.float32)
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=2)
+    outs = [model._predict_incremental(tokens, None, spk, 18, False, False, program=p) for p in (False, True)]
+    assert outs[0]['mel'].shape == outs[1]['mel'].shape == (20, 80)
+    assert torch.equal(outs[0]['mel'], outs[1]['mel'])
+    for name, a in outs[0]['decoder_attention'].items():
+        assert torch.equal(a, outs[1]['decoder_attention'][name])
