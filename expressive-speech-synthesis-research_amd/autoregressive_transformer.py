@@ -125,6 +125,9 @@ class AutoregressiveTransformer:
         self.drop_n_heads = 0
         self.stop_prob_index = 2
         self.decoder_prenet_dropout = 0.0
+        # DecoderPrenet's dropout is active at inference too (layers.py:394-402).  Masks come from the counter-based
+        # generator keyed by (seed, site, decoder position, channel); the seed advances once per decoder call.
+        self.dropout_seed = 0
         w, dev = weights, self.device
         de, dd = cfg['encoder_model_dimension'], cfg['decoder_model_dimension']
         self.de, self.dd = de, dd
@@ -227,13 +230,18 @@ class AutoregressiveTransformer:
         return (enc3, enc_mask.view(B, 1, 1, N), text_attn, gst_attn, gst_tokens, gst_out,
                 text_out.reshape(B, N, de).clone())
 
-    def call_decoder(self, encoder_output, targets, encoder_padding_mask, training=False, return_attention=True):
-        """AutoregressiveTransformer.py:161-181."""
+    def _next_dropout_seed(self):
+        self.dropout_seed = (self.dropout_seed * 1000003 + 7919) & 0xFFFFFFFF
+        return self.dropout_seed
+
+    def call_decoder(self, encoder_output, targets, encoder_padding_mask, training=False, return_attention=True,
+                     dropout_seed=None):
+        """AutoregressiveTransformer.py:161-181.  dropout_seed: seed of the prenet dropout masks (rows of the generator
+        are b * Tq + t); None draws the next one of this model's sequence."""
         if training:
             raise NotImplementedError('training runs through estts.training')
-        if self.decoder_prenet_dropout != 0.0:
-            raise NotImplementedError('decoder prenet dropout > 0 (always-on dropout, layers.py:394-402) is not available '
-                                      'in the inference kernels yet')
+        rate = self.decoder_prenet_dropout
+        seed = self._next_dropout_seed() if dropout_seed is None else int(dropout_seed) & 0xFFFFFFFF
         dev, f32, dd, r = self.device, dict(dtype=torch.float32, device=self.device), self.dd, self.r
         tg = torch.as_tensor(targets, dtype=torch.float32, device=dev).contiguous()
         B, Tq, C = tg.shape
@@ -247,10 +255,10 @@ class AutoregressiveTransformer:
         dec_mask = torch.empty(B, Tq, **f32)
         ops.row_zero_mask(tg.view(B * Tq, C), dec_mask.view(-1))
         p1 = torch.empty(B * Tq, self.prenet1.N, **f32)
-        ops.gemm(tg.view(B * Tq, C), self.prenet1, p1, precision=self.precision)
+        ops.gemm(tg.view(B * Tq, C), self.prenet1, p1, precision=self.precision, dropout=(rate, seed, 0, 0))
         pe = self.pe_dec[0:Tq * r:r].contiguous()
         ops.gemm(p1, self.prenet2, ws['xc'][:, :dd], alpha=math.sqrt(np.float32(dd)), residual=pe, r_mod=Tq,
-                 precision=self.precision)
+                 precision=self.precision, dropout=(rate, seed, 1, 0))
         attn = self.decoder.run(ws, B, Tq, N, dec_mask, enc_mask, self.precision, return_attention)
         dec_out = ws['xc'][:, :dd]
         lin = self._final_proj(r)
@@ -294,9 +302,9 @@ class AutoregressiveTransformer:
         causal window that ends at time t0 + j."""
         return torch.as_strided(hist, (rows, k * cin), (cin, 1), hist.storage_offset() + t0 * cin)
 
-    def _predict_incremental(self, inp, targets, spk_embed, max_length, encode, verbose, program=True):
-        if self.decoder_prenet_dropout != 0.0:
-            raise NotImplementedError('decoder prenet dropout > 0 is not available in the inference kernels yet')
+    def _predict_incremental(self, inp, targets, spk_embed, max_length, encode, verbose, program=True, dropout_seed=None):
+        rate = self.decoder_prenet_dropout
+        seed = self._next_dropout_seed() if dropout_seed is None else int(dropout_seed) & 0xFFFFFFFF
         dev, f32, pr = self.device, dict(dtype=torch.float32, device=self.device), self.precision
         d, r, C = self.dd, self.r, self.mel_channels
         if targets is not None:
@@ -350,8 +358,9 @@ class AutoregressiveTransformer:
         def step(i):
             frame = frames[r - 1 + i * r:r + i * r]
             ops.row_zero_mask(frame, dec_mask[0, i:i + 1])
-            ops.gemm(frame, self.prenet1, p1, precision=pr)
-            ops.gemm(p1, self.prenet2, xc[:, :d], alpha=sqrt_d, residual=self.pe_dec[i * r:i * r + 1], precision=pr)
+            ops.gemm(frame, self.prenet1, p1, precision=pr, dropout=(rate, seed, 0, i))
+            ops.gemm(p1, self.prenet2, xc[:, :d], alpha=sqrt_d, residual=self.pe_dec[i * r:i * r + 1], precision=pr,
+                     dropout=(rate, seed, 1, i))
             for b, (sa, ca, ff) in enumerate(blocks):
                 row = qkv[b][i:i + 1]
                 ops.gemm(xc[:, :d], sa.qkv, row, precision=pr)
@@ -414,7 +423,9 @@ class AutoregressiveTransformer:
         kv_cache=True (default) decodes incrementally: every step computes only the new decoder position against cached
         self-attention keys / values, the once-projected encoder keys / values and the causal-convolution histories,
         which gives the same numbers as the reference's loop (all its masks are causal) in O(T) decoder work.
-        kv_cache=False re-runs the whole decoder on the growing output each step, literally as the reference does."""
+        kv_cache=False re-runs the whole decoder on the growing output each step, literally as the reference does.
+        With decoder_prenet_dropout > 0 the two differ in distribution only: the reference (and kv_cache=False) redraws the
+        prenet dropout masks of every earlier position at each step, the cached decoder draws each position's mask once."""
         if kv_cache:
             return self._predict_incremental(inp, targets, spk_embed, max_length, encode, verbose)
         dev = self.device

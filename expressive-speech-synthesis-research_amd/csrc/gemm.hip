@@ -36,7 +36,10 @@ constexpr int BK = 64;
 __device__ __forceinline__ float epilogue_value(const estts_gemm_args& p, float acc, int row, int col, float s1,
                                                 float b1, float s2, float b2) {
     float v = acc * s1 + b1;
-    v = apply_act(v, p.act) * p.alpha;
+    v = apply_act(v, p.act);
+    if (p.drop_rate > 0.0f)
+        v = dropout_keep(p.drop_seed, p.drop_site, (uint32_t)(p.drop_row0 + row), (uint32_t)col, p.drop_rate) ? v / (1.0f - p.drop_rate) : 0.0f;
+    v *= p.alpha;
     if (p.R) {
         const int rr = p.r_mod > 0 ? row % p.r_mod : row;
         v += p.R[(long)rr * p.ldr + col];
@@ -653,6 +656,7 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
     ESTTS_CHECK_ARG(a.taps == 1 || a.lda >= a.c_per_tap, "estts_gemm: lda < c_per_tap");
     ESTTS_CHECK_ARG(!a.R || a.ldr >= a.N, "estts_gemm: ldr < N");
     ESTTS_CHECK_ARG(a.ldc >= a.N, "estts_gemm: ldc < N");
+    ESTTS_CHECK_ARG(a.drop_rate >= 0.0f && a.drop_rate < 1.0f, "estts_gemm: drop_rate must be in [0, 1)");
     hipStream_t st = (hipStream_t)stream;
 
     int tile = a.tune & 0xff;

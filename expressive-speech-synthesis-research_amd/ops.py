@@ -181,8 +181,9 @@ def gemm_workspace(device):
 
 
 def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
-         split=True, conv2d=None):
-    """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary)."""
+         split=True, conv2d=None, dropout=None):
+    """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary).
+    dropout = (rate, seed, site, row0): keep/scale after the activation, generator row = row0 + output row."""
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
     a = GemmArgs()
@@ -204,6 +205,10 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
         H, W, Ho, Wo, kw, stride, pt, pl = conv2d
         a.conv_h, a.conv_w, a.conv_wo, a.conv_howo = H, W, Wo, Ho * Wo
         a.conv_kw, a.conv_stride, a.conv_pt, a.conv_pl = kw, stride, pt, pl
+    if dropout is not None and dropout[0] > 0.0:
+        if not dropout[0] < 1.0:
+            raise ValueError('gemm: dropout rate must be below 1')
+        a.drop_rate, a.drop_seed, a.drop_site, a.drop_row0 = dropout
     if split:
         ws, cnt = gemm_workspace(x.device)
         a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()

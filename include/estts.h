@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 8
+#define ESTTS_ABI_VERSION 9
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -44,7 +44,10 @@ const char* estts_last_error(void);
  *
  *   acc[m, n] = sum_{tap, c} A[row(m) + tap - tap_lpad, c] * W[n, tap * c_per_tap + c]
  *               (rows outside [0, seg_len) of m's own segment contribute zero)
- *   v = acc * s1[n] + b1[n];  v = act(v);  v = v * alpha;
+ *   v = acc * s1[n] + b1[n];  v = act(v);
+ *   if (drop_rate > 0)  v = keep(drop_seed, drop_site, drop_row0 + m, n) ? v / (1 - drop_rate) : 0
+ *                       (estts_dropout's counter-based generator: DecoderPrenet's always-on dropout, layers.py:394-402)
+ *   v = v * alpha;
  *   if (R)  v += R[(r_mod ? m % r_mod : m), n];
  *   if (s2) v = v * s2[n] + b2[n];
  *   C[m, n] = v
@@ -103,6 +106,9 @@ typedef struct estts_gemm_args {
      * Output row m = (image, ho, wo) on a conv_howo / conv_wo grid, tap = (kh, kw) with kw fastest,
      * source pixel (ho * stride + kh - conv_pt, wo * stride + kw - conv_pl) of a conv_h x conv_w image. */
     int32_t conv_h, conv_w, conv_wo, conv_howo, conv_kw, conv_stride, conv_pt, conv_pl;
+    float drop_rate;     /* 0 = no dropout */
+    uint32_t drop_seed, drop_site;
+    int32_t drop_row0;   /* generator row of output row 0 (an incremental decoder computes row i alone) */
 } estts_gemm_args;
 
 int estts_gemm(const estts_gemm_args* args, void* stream);

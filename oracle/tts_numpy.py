@@ -231,10 +231,16 @@ def cross_attention_blocks(x, enc_output, look_ahead_mask, enc_padding_mask, w, 
     return x, attn
 
 
-def decoder_prenet(x, w, prefix):
-    """layers.py:379-402 with dropout rate 0 (its dropout is always 'training')."""
+def decoder_prenet(x, w, prefix, masks=None):
+    """layers.py:379-402.  Its dropout is always 'training'; masks = (m1, m2) are the two keep masks already scaled by
+    1 / (1 - rate) (inputs, so that a device path can be compared on identical draws); None = rate 0."""
     x = np.maximum(dense(x, w[prefix + '.d1.kernel'], w[prefix + '.d1.bias']), 0)
-    return np.maximum(dense(x, w[prefix + '.d2.kernel'], w[prefix + '.d2.bias']), 0)
+    if masks is not None:
+        x = x * masks[0]
+    x = np.maximum(dense(x, w[prefix + '.d2.kernel'], w[prefix + '.d2.bias']), 0)
+    if masks is not None:
+        x = x * masks[1]
+    return x
 
 
 def duration_predictor(x, w, prefix):
@@ -376,13 +382,13 @@ def ar_encoder(w, cfg, tokens, style_targets, spk_embed):
     return enc_output, enc_mask, text_attn, gst_attn, gst_out, text_out
 
 
-def ar_decoder(w, cfg, enc_output, enc_mask, targets, r):
-    """AutoregressiveTransformer.call_decoder (model/AutoregressiveTransformer.py:161-181), training=False,
-    decoder-prenet dropout rate 0."""
+def ar_decoder(w, cfg, enc_output, enc_mask, targets, r, prenet_masks=None):
+    """AutoregressiveTransformer.call_decoder (model/AutoregressiveTransformer.py:161-181), training=False;
+    prenet_masks: see decoder_prenet."""
     dec_pad = create_mel_padding_mask(targets).astype(targets.dtype)
     look = create_look_ahead_mask(targets.shape[1])
     combined = np.maximum(dec_pad, look)
-    dec_in = decoder_prenet(targets, w, 'decoder_prenet')
+    dec_in = decoder_prenet(targets, w, 'decoder_prenet', prenet_masks)
     dec_out, dec_attn = cross_attention_blocks(
         dec_in, enc_output, combined, enc_mask, w, 'decoder', cfg['decoder_model_dimension'],
         cfg['decoder_num_heads'], cfg['decoder_dense_blocks'], cfg['decoder_attention_conv_kernel'],
@@ -395,7 +401,7 @@ def ar_decoder(w, cfg, enc_output, enc_mask, targets, r):
     return out
 
 
-def autoregressive_call(w, cfg, tokens, targets, spk_embed=None, r=1, dtype=np.float64):
+def autoregressive_call(w, cfg, tokens, targets, spk_embed=None, r=1, dtype=np.float64, prenet_masks=None):
     """AutoregressiveTransformer.call (model/AutoregressiveTransformer.py:243-263), all training flags False.
 
     targets: (B, T/r, 80) reduced, start-vector-prefixed decoder input (also fed to the style encoder,
@@ -405,7 +411,7 @@ def autoregressive_call(w, cfg, tokens, targets, spk_embed=None, r=1, dtype=np.f
     tokens = np.asarray(tokens)
     targets = np.asarray(targets, dtype=dtype)
     enc_output, enc_mask, text_attn, gst_attn, gst_out, text_out = ar_encoder(w, cfg, tokens, targets, spk_embed)
-    out = ar_decoder(w, cfg, enc_output, enc_mask, targets, r)
+    out = ar_decoder(w, cfg, enc_output, enc_mask, targets, r, prenet_masks)
     out.update({'text_encoder_attention': text_attn, 'gst_encoder_attention': gst_attn,
                 'gst_output': gst_out, 'text_enc_output': text_out})
     return out

@@ -178,3 +178,62 @@ def test_step_program_equals_eager_launches():
     assert torch.equal(outs[0]['mel'], outs[1]['mel'])
     for name, a in outs[0]['decoder_attention'].items():
         assert torch.equal(a, outs[1]['decoder_attention'][name])
+
+
+def _prenet_masks(rate, seed, rows, widths):
+    """The scaled keep masks the device generator draws for sites 0 and 1 (rows = b * Tq + t)."""
+    from estts import train_ops
+    out = []
+    for site, n in enumerate(widths):
+        m = torch.empty(rows, n, device=DEV)
+        train_ops.dropout(torch.ones(rows, n, device=DEV), m, rate, seed, site)
+        out.append(m.cpu().numpy().astype(np.float64))
+    return out
+
+
+def test_decoder_prenet_dropout_matches_oracle_on_identical_masks():
+    """DecoderPrenet's always-on dropout (layers.py:394-402) at rate 0.5: the teacher-forced call against the oracle fed
+    the same masks; about half of the prenet activations are dropped."""
+    cfg = small_cfg('style_text')
+    w = weights.init_autoregressive_transformer(cfg, seed=13)
+    rng = np.random.default_rng(3)
+    B, N, Tq, r = 2, 9, 12, 2
+    tokens = rng.integers(1, cfg['vocab_size'], size=(B, N)).astype(np.int32)
+    targets = np.clip(rng.normal(0, 1.5, size=(B, Tq, 80)), -4, 4).astype(np.float32)
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=r, decoder_prenet_dropout=0.5)
+    enc, mask, *_ = model.call_encoder(tokens, targets, None)
+    out = model.call_decoder(enc, targets, mask, dropout_seed=77)
+    m1, m2 = _prenet_masks(0.5, 77, B * Tq, (cfg['decoder_prenet_dimension'], cfg['decoder_model_dimension']))
+    assert 0.4 < (m1 == 0).mean() < 0.6 and set(np.unique(m1)) == {0.0, 2.0}
+    ref = O.autoregressive_call(w, cfg, tokens, targets, None, r=r,
+                                prenet_masks=(m1.reshape(B, Tq, -1), m2.reshape(B, Tq, -1)))
+    assert np.abs(out['final_output'].cpu().numpy() - ref['final_output']).max() < 3e-4
+    plain = O.autoregressive_call(w, cfg, tokens, targets, None, r=r)
+    assert np.abs(plain['final_output'] - ref['final_output']).max() > 1e-2        # the masks do matter
+    again = model.call_decoder(enc, targets, mask)                                  # next seed of the model's sequence
+    assert (again['final_output'] - out['final_output']).abs().max().item() > 1e-3
+
+
+def test_incremental_predict_with_prenet_dropout_is_teacher_forced_consistent():
+    """Cached decoding with dropout draws position i's mask from generator row i: feeding its own output back through the
+    teacher-forced decoder with the same seed reproduces it."""
+    cfg = small_cfg('text')
+    w = weights.init_autoregressive_transformer(cfg, seed=17)
+    w['decoder_postnet.stop_linear.bias'] = np.array([0.5, 0.0, -0.5], np.float32)
+    rng = np.random.default_rng(6)
+    tokens = rng.integers(1, cfg['vocab_size'], size=10)
+    r = 2
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=r, decoder_prenet_dropout=0.5)
+    outs = [model._predict_incremental(tokens, None, None, 16, False, False, program=p, dropout_seed=5) for p in (True, False)]
+    assert torch.equal(outs[0]['mel'], outs[1]['mel'])
+    mel = outs[0]['mel']                                                            # (9 r, 80)
+    assert mel.shape == (9 * r, 80)
+    dec_in = torch.cat([model.start_vec, mel[r - 1::r][:-1]])[None]                # start vector + last frame of each step
+    tok = torch.as_tensor(tokens[None].astype(np.int32), device=DEV)
+    enc, mask, *_ = model.call_encoder(tok, None, None)
+    tf = model.call_decoder(enc, dec_in, mask, dropout_seed=5)
+    assert (tf['final_output'][0] - mel).abs().max().item() < 2e-4
+    other = model._predict_incremental(tokens, None, None, 16, False, False, dropout_seed=6)
+    assert (other['mel'] - mel).abs().max().item() > 1e-3
