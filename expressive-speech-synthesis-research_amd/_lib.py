@@ -135,6 +135,7 @@ SIGNATURES = {
     'estts_gru_step_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_wavernn_prep_bwd': (_i32, [C.POINTER(WavernnPrepBwdArgs), _vp]),
     'estts_softmax_xent': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    'estts_scaled_xent': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
     'estts_run_program': (_i32, [C.POINTER(ProgOp), _i32, _i32, _vp]),
     'estts_mol_loss': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
 }

@@ -70,6 +70,28 @@ __device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t site, uint3
     return (x >> 8) * (1.0f / 16777216.0f) >= rate;
 }
 
+// Tile numbering that follows the L2s.  Workgroups whose linear dispatch ids agree mod 8 are observed to share an XCD
+// and therefore a 4 MiB L2 (placement is a speed matter only: nothing here relies on it for correctness).  Every such
+// group is given one contiguous run of tile numbers (bijective for any grid size), the split-K slices of a tile are
+// adjacent in it, and a run walks the tile grid along y first (a strip of columns: all of the row operand, 1/8 of the
+// column operand per L2) or along x first (a strip of rows), whichever operand the caller says is the smaller one.
+struct TileCoord { int tx, ty, tz; };
+__device__ __forceinline__ TileCoord xcd_tile_coord(bool y_first, bool remap = true) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int nwg = gx * gy * gz;
+    int id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if (remap && nwg >= 16) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    TileCoord t;
+    t.tz = id % gz;
+    const int tile = id / gz;
+    if (y_first) { t.ty = tile % gy; t.tx = tile / gy; }
+    else         { t.tx = tile % gx; t.ty = tile / gx; }
+    return t;
+}
+
 // derivative of the activation expressed through its OUTPUT r
 __device__ __forceinline__ float act_grad_from_output(float r, int act) {
     if (act == ESTTS_ACT_RELU) return r > 0.0f ? 1.0f : 0.0f;

@@ -49,6 +49,11 @@ __device__ __forceinline__ float epilogue_value(const estts_gemm_args& p, float 
 }
 
 
+// true when the activation panel (M rows) is the smaller operand: an L2 then holds all of it plus a strip of W columns
+__device__ __forceinline__ bool gemm_y_first(const estts_gemm_args& p) {
+    return (long)p.M * p.c_per_tap * 4 <= (long)p.N * p.K * (p.precision == 3 ? 4 : 2);
+}
+
 // split-K hand-off; returns true in the workgroup that must finish the tile (all threads must call)
 __device__ __forceinline__ bool splitk_last_arriver(const estts_gemm_args& p, int tile, int splitk, int* s_ticket) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -96,8 +101,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     const int g = lane >> 4;
     const int r8 = lane >> 3;
     const int c8 = lane & 7;
-    const int m0 = blockIdx.y * 32;
-    const int n0 = blockIdx.x * 32;
+    const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)));
+    const int m0 = tc.ty * 32;
+    const int n0 = tc.tx * 32;
     const int KS = p.ldw >> 5;  // K-steps per packed row block
 
     ARow a_row[4];
@@ -114,8 +120,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
 
     const int nks_all = (p.K + 31) / 32;
     const int per = (nks_all + splitk - 1) / splitk;
-    const int ks_end = min((int)(blockIdx.z + 1) * per, nks_all);
-    int ks = blockIdx.z * per + wave;
+    const int ks_end = min((tc.tz + 1) * per, nks_all);
+    int ks = tc.tz * per + wave;
 
     auto load = [&](int k, SmallStage<NS>& st) {
         const ATap tp = make_atap(p, k * 32 + c8 * 4);
@@ -217,9 +223,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     }
 
     if (splitk > 1) {
-        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        const int tile = tc.ty * gridDim.x + tc.tx;
         const long ntiles = (long)gridDim.x * gridDim.y;
-        float* slab = p.ws + ((long)blockIdx.z * ntiles + tile) * 1024;
+        float* slab = p.ws + ((long)tc.tz * ntiles + tile) * 1024;
         if (fin) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) slab[r * 256 + tid] = out[r];
@@ -272,8 +278,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p, cons
     const int wave = tid >> 6;
     const int wm = wave / WN;
     const int wn = wave % WN;
-    const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)));
+    const int m0 = tc.ty * BM;
+    const int n0 = tc.tx * BN;
     const int KS = p.ldw >> 5;
 
     ARow a_row[A_ITERS];
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p, cons
 
     const int nk_all = (p.K + BK - 1) / BK;
     const int per = (nk_all + splitk - 1) / splitk;
-    const int kt0 = blockIdx.z * per;
+    const int kt0 = tc.tz * per;
     const int kt1 = min(kt0 + per, nk_all);
 
     const int a_base = (wm * (BM / WM) + (lane & 15)) * A_LD + (lane >> 4) * 8;
@@ -376,9 +383,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p, cons
     }
 
     if (splitk > 1) {
-        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        const int tile = tc.ty * gridDim.x + tc.tx;
         const long ntiles = (long)gridDim.x * gridDim.y;
-        float* slab = p.ws + ((long)blockIdx.z * ntiles + tile) * (BM * BN);
+        float* slab = p.ws + ((long)tc.tz * ntiles + tile) * (BM * BN);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -446,8 +453,9 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const estts_gemm_args 
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 128;
-    const int n0 = blockIdx.x * 128;
+    const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)));
+    const int m0 = tc.ty * 128;
+    const int n0 = tc.tx * 128;
     const int KS = p.ldw >> 5;
 
     const int nb_end = ((p.N + 63) / 64) * 4;  // 16-column blocks present in W
@@ -588,9 +596,13 @@ int launch_small_nw(const estts_gemm_args& a, dim3 grid, hipStream_t st) {
 int launch_small(const estts_gemm_args& a, int splitk, int nw, hipStream_t st) {
     dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, splitk);
     if (splitk > 1 && !splitk_fits(a, grid, 1024)) return -1;
-    if (nw == 0) {  // measured on MI355X: 8 waves from 16 K-steps up, 16 waves never (register spills at 128 VGPRs)
+    if (nw == 0) {
+        // measured on MI355X: 8 waves pay from about 12 K-steps up, but only while the launch has fewer workgroups than
+        // the chip has CUs (beyond that 4-wave workgroups fill the SIMDs better: 832 x 1536 x 512 runs 19 vs 22 us);
+        // 16 waves never (register spills at 128 VGPRs)
         const int nks = ((a.K + 31) / 32 + splitk - 1) / splitk;
-        nw = nks >= 16 ? 8 : 4;
+        const long wgs = (long)grid.x * grid.y * grid.z;
+        nw = (nks >= 12 && wgs < 256) ? 8 : 4;
     }
     switch (nw) {
         case 4: return launch_small_nw<4>(a, grid, st);

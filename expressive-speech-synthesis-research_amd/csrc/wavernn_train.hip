@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256) void wavernn_prep_bwd_kernel(const estts_waver
 }
 
 // one wave per row
+// weight of row m: 1, or with weighted != 0: (label != 0) + (label == w_index) * (w_scaling - 1)
 __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* logits, int ld, const int32_t* labels, float* loss,
-                                                           float* d, int ldd, int M, int C, float scale) {
+                                                           float* d, int ldd, int M, int C, float scale, int weighted,
+                                                           int w_index, float w_scaling) {
     __shared__ float part[4];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -143,8 +145,10 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float* logits, 
         s = wave_sum(s);
         const float lse = mx + logf(s);
         const int y = min(max(labels[row], 0), C - 1);   // a label outside [0, C) must not become an address
-        for (int c = lane; c < C; c += 64) d[(long)row * ldd + c] = scale * (expf(l[c] - lse) - (c == y ? 1.0f : 0.0f));
-        mine = lse - l[y];
+        const float w = weighted ? (y != 0 ? 1.0f : 0.0f) + (y == w_index ? w_scaling - 1.0f : 0.0f) : 1.0f;
+        if (d)
+            for (int c = lane; c < C; c += 64) d[(long)row * ldd + c] = scale * w * (expf(l[c] - lse) - (c == y ? 1.0f : 0.0f));
+        mine = w * (lse - l[y]);
     }
     if (lane == 0) part[wv] = mine;
     __syncthreads();
@@ -281,8 +285,17 @@ extern "C" int estts_softmax_xent(const float* logits, int32_t ld, const int32_t
                                   int32_t M, int32_t C, float scale, void* stream) {
     ESTTS_CHECK_ARG(logits && labels && loss && dlogits && M > 0 && C > 0 && ld >= C && lddl >= C, "estts_softmax_xent: bad arguments");
     hipLaunchKernelGGL(softmax_xent_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss, dlogits,
-                       lddl, M, C, scale);
+                       lddl, M, C, scale, 0, 0, 1.0f);
     ESTTS_CHECK_LAUNCH("estts_softmax_xent");
+    return 0;
+}
+
+extern "C" int estts_scaled_xent(const float* logits, int32_t ld, const int32_t* labels, float* loss, float* dlogits, int32_t lddl,
+                                 int32_t M, int32_t C, int32_t index, float scaling, float scale, void* stream) {
+    ESTTS_CHECK_ARG(logits && labels && loss && M > 0 && C > 0 && ld >= C && (!dlogits || lddl >= C), "estts_scaled_xent: bad arguments");
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss, dlogits,
+                       lddl, M, C, scale, 1, index, scaling);
+    ESTTS_CHECK_LAUNCH("estts_scaled_xent");
     return 0;
 }
 

@@ -260,3 +260,18 @@ if ops._debug_sync:      # ESTTS_DEBUG_SYNC=1: name every training launch and wa
                'head_scale', 'embed_bwd', 'expand_bwd', 'masked_mae_bwd', 'adam', 'gru_step_fwd', 'gru_step_bwd', 'wavernn_prep_bwd',
                'softmax_xent', 'mol_loss'):
         globals()[_n] = _debug_wrap(globals()[_n])
+
+
+def scaled_xent(logits, labels, loss, dlogits=None, index=2, scaling=1.0, scale=None, M=None, C=None):
+    """new_scaled_crossentropy (utils/losses.py:4-21): loss[0] += scale * sum_m w[m] ce[m], w = (label != 0) + (label == index)
+    (scaling - 1); scale defaults to 1 / M (Keras SUM_OVER_BATCH_SIZE).  dlogits: optional gradient output."""
+    M = logits.shape[0] if M is None else M
+    C = logits.shape[1] if C is None else C
+    if labels.dtype != torch.int32:
+        raise TypeError('scaled_xent: labels must be int32')
+    scale = 1.0 / M if scale is None else scale
+    check(_lib.load().estts_scaled_xent(logits.data_ptr(), logits.stride(0), labels.data_ptr(), loss.data_ptr(),
+                                        dlogits.data_ptr() if dlogits is not None else None,
+                                        dlogits.stride(0) if dlogits is not None else 0, M, C, index, scaling, scale, _stream()),
+          'estts_scaled_xent')
+    return loss

@@ -466,6 +466,14 @@ int estts_wavernn_prep_bwd(const estts_wavernn_prep_bwd_args* args, void* stream
 int estts_softmax_xent(const float* logits, int32_t ld, const int32_t* labels, float* loss, float* dlogits, int32_t lddl,
                        int32_t M, int32_t C, float scale, void* stream);
 
+/* Stop-token loss of the autoregressive model: new_scaled_crossentropy / masked_crossentropy (TransformerTTS/utils/losses.py:4-29),
+ * SparseCategoricalCrossentropy(from_logits) with sample weights w[m] = (label != 0) + (label == index) * (scaling - 1):
+ *   loss[0] += scale * sum_m w[m] * ce[m];  dlogits[m, c] = scale * w[m] * (softmax - onehot)   (dlogits may be NULL)
+ * scale = 1 / M reproduces Keras' SUM_OVER_BATCH_SIZE (padded positions count in the denominator); scaling = 1 is
+ * masked_crossentropy.  loss[0] zeroed by the caller. */
+int estts_scaled_xent(const float* logits, int32_t ld, const int32_t* labels, float* loss, float* dlogits, int32_t lddl,
+                      int32_t M, int32_t C, int32_t index, float scaling, float scale, void* stream);
+
 /* Discretized mixture-of-logistics negative log-likelihood and its gradient (WaveRNN/utility/distribution.py:16-84,
  * reduce=True): y_hat [M, 3 nr_mix] = (mixture logits | means | log scales), y [M] in [-1, 1].
  *   loss[0] += scale * sum_m nll_m;  d[m, :] = scale * d nll_m / d y_hat[m, :]      nr_mix <= 16 */

@@ -120,7 +120,8 @@ def test_full_size_model_properties():
     d2 = np.stack([d[0], np.full(N, 4.0)])
     out2 = model.call(tok2, target_durations=d2)
     assert tuple(out2['mel'].shape) == (2, T, 80)
-    assert np.abs(out['mel'][0].cpu().numpy() - out2['mel'][0].cpu().numpy()).max() < 1e-5
+    # (not bit-identical: the GEMM picks its workgroup shape, and with it the summation order over K, from the row count)
+    assert np.abs(out['mel'][0].cpu().numpy() - out2['mel'][0].cpu().numpy()).max() < 1e-4
     assert out2['expanded_mask'][1, 0, 0, 400:].min().item() == 1.0 and out2['expanded_mask'][0].max().item() == 0.0
     l1_bf16 = np.abs(ForwardTransformer(w, cfg, precision='bf16').call(tokens, target_durations=d)['mel'].cpu().numpy()
                      - ref['mel']).mean()

@@ -330,3 +330,30 @@ def test_expand_embed_loss_adam_axpby_headscale(T):
     T.head_scale(xd, dev(sc.reshape(-1)), B2, L, H, dep)
     ref = (x.reshape(B2, L, H, dep) * sc[:, None, :, None]).reshape(B2 * L, H * dep)
     assert rel_err(xd, ref) < 1e-6
+
+
+def test_scaled_crossentropy_reference_known_answers_and_gradient(T):
+    """The stop-token loss against the constants of the reference's own test (TransformerTTS/tests/test_loss.py:10-24), then
+    loss and gradient against the oracle / autograd on random logits with padding and stop labels."""
+    from oracle import tts_numpy as O
+    logits = dev([[.3, .2, .1], [.3, .2, .1], [.3, .2, .1]])
+    labels = dev([0, 1, 2], torch.int32)
+    for scaling, want in ((5.0, 2.3705523014068604), (1.0, 0.7679619193077087)):
+        loss = torch.zeros(1, device='cuda')
+        T.scaled_xent(logits, labels, loss, index=2, scaling=scaling)
+        assert abs(loss.item() - want) < 1e-6
+    rng = np.random.default_rng(0)
+    B, L, C = 3, 37, 3
+    lg = rng.normal(size=(B, L, C)).astype(np.float32) * 2
+    tg = rng.integers(0, 3, size=(B, L)).astype(np.int32)
+    loss = torch.zeros(1, device='cuda')
+    d = torch.empty(B * L, C, device='cuda')
+    T.scaled_xent(dev(lg).view(B * L, C), dev(tg, torch.int32).view(-1), loss, d, index=2, scaling=8.0)
+    assert abs(loss.item() - O.new_scaled_crossentropy(2, 8.0)(tg, lg)) < 1e-5
+    x = torch.tensor(lg, dtype=torch.float64, requires_grad=True)
+    t = torch.tensor(tg).long()
+    w = (t != 0).double() + (t == 2).double() * 7.0
+    ref = (F.cross_entropy(x.view(-1, C), t.view(-1), reduction='none') * w.view(-1)).sum() / (B * L)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5
+    assert rel_err(d, x.grad.view(-1, C)) < 1e-5

@@ -62,12 +62,14 @@ def compare_grads(model, ref):
 
     The graph has kinks (ReLU gates, the sign() of the MAE loss).  The device works with ~1e-5 relative arithmetic
     noise, the oracle in float64, so in every step a few of the ~1e5 gated elements sit close enough to their kink to
-    take the other branch on the device.  The oracle shows the size of that effect: perturbing its weights by 2e-6
-    (relative) moves single BatchNorm-beta gradients by 10 % and everything upstream of the flipped gate by ~1 %, while
-    below the first flip the response is linear with a factor ~30.  Hence: every tensor must agree to 35 % of its
-    largest entry (a layout, sign or scale error gives >= 100 %), the tensors not reached by a flip (at least a
-    third of them) to 2e-3, and the whole gradient vector to a cosine of 0.995.  Each backward kernel on its own is
-    held to ~1e-4 against autograd in tests/test_gpu_train_ops.py."""
+    take the other branch on the device (which ones depends on the summation order inside the GEMMs).  A flipped gate
+    changes the gradients of its own layer and of everything that precedes it in the forward pass, and nothing after
+    it.  The oracle shows the size of the effect: perturbing its weights by 2e-6 (relative) moves single
+    BatchNorm-beta gradients by 10 % and everything upstream of the flipped gate by ~1 %.  Hence: the tensors that
+    follow the last ReLU (the mel projection and the tanh postnet) must agree to 5e-4 of their largest entry, every
+    tensor to 35 % (a layout, sign or scale error gives >= 100 %), the median tensor to 2e-2, and the whole gradient
+    vector to a cosine of 0.995.  Each backward kernel on its own is held to ~1e-4 against autograd in
+    tests/test_gpu_train_ops.py."""
     mine = grads_by_name(model)
     errs, dot, n1, n2 = [], 0.0, 0.0, 0.0
     for k, r in ref['grads'].items():
@@ -83,10 +85,12 @@ def compare_grads(model, ref):
         errs.append((float(np.abs(a - r).max() / scale), k))
     errs.sort(reverse=True)
     cosine = dot / np.sqrt(n1 * n2)
-    tight = sum(e < 2e-3 for e, _ in errs) / len(errs)
-    print(f'gradient check: cosine {cosine:.6f}, worst {errs[0]}, tensors within 2e-3: {tight:.0%}')
+    median = errs[len(errs) // 2][0]
+    after_last_gate = [(e, k) for e, k in errs if k.startswith(('decoder_postnet.', 'out.'))]
+    print(f'gradient check: cosine {cosine:.6f}, worst {errs[0]}, median {median:.1e}, after the last gate {after_last_gate[0]}')
     assert errs[0][0] < 0.35, errs[:5]
-    assert tight >= 1 / 3, errs[:5]
+    assert median < 2e-2, median
+    assert after_last_gate and after_last_gate[0][0] < 5e-4, after_last_gate[:3]
     assert cosine > 0.995, cosine
     return errs[0]
 

@@ -50,8 +50,10 @@ def main():
         out = torch.empty(M, N, device='cuda')
         ref = None
         res = []
-        for tile, sk in itertools.product((1, 2, 3), (1, 2, 4, 8)):
-            tune = tile | (sk << 8)
+        cands = [(t, sk, 0) for t, sk in itertools.product((1, 3), (1, 4))] + \
+                [(4, sk, wv) for sk, wv in itertools.product((1, 2, 4), (4, 8))]
+        for tile, sk, wv in cands:
+            tune = tile | (sk << 8) | (wv << 16)
             try:
                 ops.gemm(x, lin, out, seg_len=M, precision=prec, tune=tune)
             except Exception as e:  # noqa
@@ -60,11 +62,11 @@ def main():
                 ref = out.clone()
             err = (out - ref).abs().max().item()
             t = timeit(lambda: ops.gemm(x, lin, out, seg_len=M, precision=prec, tune=tune))
-            res.append((t, tile, sk, err))
+            res.append((t, tile * 100 + wv, sk, err))
         ops.gemm(x, lin, out, seg_len=M, precision=prec)
         t_auto = timeit(lambda: ops.gemm(x, lin, out, seg_len=M, precision=prec))
         res.sort()
-        best = ' '.join(f'[t{tile} k{sk}: {t:5.1f}us e{err:.0e}]' for t, tile, sk, err in res[:4])
+        best = ' '.join(f'[t{tile} k{sk}: {t:5.1f}us e{err:.0e}]' for t, tile, sk, err in res[:6])
         print(f'M={M:4d} N={N:4d} K={K:4d} taps={taps} auto {t_auto:5.1f}us  {2e-6 * M * N * K / t_auto:6.1f} TF/s | best {best}', flush=True)
 
 
