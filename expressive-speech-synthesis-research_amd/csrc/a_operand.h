@@ -43,10 +43,27 @@ __device__ __forceinline__ ATap make_atap(const estts_gemm_args& p, int kk) {
     return t;
 }
 
-__device__ __forceinline__ float4 load_a(const estts_gemm_args& p, const ARow& r, const ATap& t) {
+// The load is unconditional (a padded position reads element 0, which exists) and the caller zeroes the value where it
+// USES it (zero_unless): a load under a condition becomes a branch around it, and a select right behind the load makes
+// the wave wait for the data at the point of issue; either way the K loop would run at memory latency.
+__device__ __forceinline__ float4 load_a_raw(const estts_gemm_args& p, const ARow& r, const ATap& t, bool& ok) {
     const int hi = r.h0 + t.dh;
     const int wi = r.w0 + t.dw;
-    const bool ok = r.ok && t.ok && hi >= 0 && hi < p.conv_h && wi >= 0 && wi < p.conv_w;
-    const float* ap = p.A + (long)(r.pix0 + hi * p.conv_w + wi) * p.lda + t.c;
-    return ok ? *reinterpret_cast<const float4*>(ap) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ok = r.ok && t.ok && hi >= 0 && hi < p.conv_h && wi >= 0 && wi < p.conv_w;
+    const long idx = ok ? (long)(r.pix0 + hi * p.conv_w + wi) * p.lda + t.c : 0L;
+    return *reinterpret_cast<const float4*>(p.A + idx);
+}
+
+__device__ __forceinline__ float4 zero_unless(bool ok, float4 v) {
+    v.x = ok ? v.x : 0.0f;
+    v.y = ok ? v.y : 0.0f;
+    v.z = ok ? v.z : 0.0f;
+    v.w = ok ? v.w : 0.0f;
+    return v;
+}
+
+__device__ __forceinline__ float4 load_a(const estts_gemm_args& p, const ARow& r, const ATap& t) {
+    bool ok;
+    const float4 v = load_a_raw(p, r, t, ok);
+    return zero_unless(ok, v);
 }

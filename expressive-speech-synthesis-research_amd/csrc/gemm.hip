@@ -83,6 +83,7 @@ constexpr int SM_WAVE_ELEMS = 2 * 32 * SM_LD;  // hi + lo image per wave
 template <int NS>
 struct SmallStage {
     float4 a[4];
+    bool ok[4];
     uint4 w[NS][2];
 };
 
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     auto load = [&](int k, SmallStage<NS>& st) {
         const ATap tp = make_atap(p, k * 32 + c8 * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st.a[j] = load_a(p, a_row[j], tp);
+        for (int j = 0; j < 4; ++j) st.a[j] = load_a_raw(p, a_row[j], tp, st.ok[j]);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             st.w[0][i] = *reinterpret_cast<const uint4*>(whp[i] + (long)k * 512);
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     auto compute = [&](const SmallStage<NS>& st) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float v[4] = {st.a[j].x, st.a[j].y, st.a[j].z, st.a[j].w};
+            const float4 az = zero_unless(st.ok[j], st.a[j]);
+            const float v[4] = {az.x, az.y, az.z, az.w};
             bf16x4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -442,11 +444,15 @@ constexpr int BG_LD = 40;  // bf16 per staged A row (32 + 8 pad = 80 B)
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int NSPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const estts_gemm_args p) {
+// TM x TN = 32 x 32 MFMA tiles per wave: the workgroup tile is (64 TM) x (64 TN).  2 x 2 is the kernel described above;
+// 1 x 1, 2 x 1 and 1 x 2 keep its main loop for launches whose 128 x 128 tiles would leave most CUs idle.
+template <int NSPLIT, int TM, int TN, int OCC, int PF>
+__global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_args p) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][128 * BG_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][NS][8 * 512];  // eight 16-column blocks of one 32-wide K-step
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int AI = 2 * TM;   // float4 loads of A per thread and K-step
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][BM * BG_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ws[2][NS][4 * TN * 512];  // 16-column blocks of one 32-wide K-step
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -454,38 +460,50 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const estts_gemm_args 
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)));
-    const int m0 = tc.ty * 128;
-    const int n0 = tc.tx * 128;
+    const int m0 = tc.ty * BM;
+    const int n0 = tc.tx * BN;
     const int KS = p.ldw >> 5;
 
     const int nb_end = ((p.N + 63) / 64) * 4;  // 16-column blocks present in W
     const int a_ch = tid & 7;    // float4 chunk of the 32-wide K slice
     const int a_r0 = tid >> 3;   // rows a_r0 + 32 i
-    ARow a_row[4];
+    ARow a_row[AI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a_row[i] = make_arow(p, m0 + a_r0 + 32 * i);
+    for (int i = 0; i < AI; ++i) a_row[i] = make_arow(p, m0 + a_r0 + 32 * i);
 
-    float4 a_reg[4];
-    uint4 w_reg[NS][2];
+    // PF register sets: the loads of K-step kt + PF are issued while step kt is being multiplied
+    float4 a_reg[AI];
+    bool a_ok[AI];
+    static_assert(TN == 1 || TN == 2, "one or two 16-byte W units per thread");
+    uint4 wh0, wh1, wl0, wl1;
+    static_assert(PF == 1, "one register set");
     auto load_tiles = [&](int kt) {
         const ATap tp = make_atap(p, kt * 32 + a_ch * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_reg[i] = load_a(p, a_row[i], tp);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AI; ++i) a_reg[i] = load_a_raw(p, a_row[i], tp, a_ok[i]);
+        // (named registers, not an array: with an array of two the compiler keeps the fragments in scratch memory)
+        auto w_off = [&](int i) {
+            // W holds ceil(N / 64) * 64 rows, so the last tile may reach past it: read the last block again instead
+            // (those columns are >= N and never stored); no load sits under a condition (see load_a_raw)
             const int idx = tid + i * 256;  // 16-byte unit: block idx >> 6, lane slot idx & 63
-            const int nb = (n0 >> 4) + (idx >> 6);
-            const long off = ((long)nb * KS + kt) * 512 + (idx & 63) * 8;
-            const bool ok = nb < nb_end;   // W holds ceil(N / 64) * 64 rows: the last 128-wide tile may be half empty
-            w_reg[0][i] = ok ? *reinterpret_cast<const uint4*>(p.W_hi + off) : make_uint4(0, 0, 0, 0);
-            if (NS == 2) w_reg[NS - 1][i] = ok ? *reinterpret_cast<const uint4*>(p.W_lo + off) : make_uint4(0, 0, 0, 0);
+            const int nb = min((n0 >> 4) + (idx >> 6), nb_end - 1);
+            return ((long)nb * KS + kt) * 512 + (idx & 63) * 8;
+        };
+        const long o0 = w_off(0);
+        wh0 = *reinterpret_cast<const uint4*>(p.W_hi + o0);
+        if (NS == 2) wl0 = *reinterpret_cast<const uint4*>(p.W_lo + o0);
+        if (TN == 2) {
+            const long o1 = w_off(1);
+            wh1 = *reinterpret_cast<const uint4*>(p.W_hi + o1);
+            if (NS == 2) wl1 = *reinterpret_cast<const uint4*>(p.W_lo + o1);
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AI; ++i) {
             const int o = (a_r0 + 32 * i) * BG_LD + a_ch * 4;
-            const float v[4] = {a_reg[i].x, a_reg[i].y, a_reg[i].z, a_reg[i].w};
+            const float4 az = zero_unless(a_ok[i], a_reg[i]);
+            const float v[4] = {az.x, az.y, az.z, az.w};
             bf16x4 hi, lo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -497,76 +515,81 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const estts_gemm_args 
             *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = hi;
             if (NS == 2) *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = lo;
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int o = (tid + i * 256) * 8;
-            *reinterpret_cast<uint4*>(&Ws[buf][0][o]) = w_reg[0][i];
-            if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][o]) = w_reg[NS - 1][i];
+        *reinterpret_cast<uint4*>(&Ws[buf][0][tid * 8]) = wh0;
+        if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][tid * 8]) = wl0;
+        if (TN == 2) {
+            *reinterpret_cast<uint4*>(&Ws[buf][0][(tid + 256) * 8]) = wh1;
+            if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][(tid + 256) * 8]) = wl1;
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int nk = (p.K + 31) / 32;
-    const int a_base = (wm * 64 + r) * BG_LD + 8 * h;
-    const int w_base = (wn * 4 + (r >> 4)) * 512 + ((r & 15) + 16 * h) * 8;
+    const int a_base = (wm * 32 * TM + r) * BG_LD + 8 * h;
+    const int w_base = (wn * 2 * TN + (r >> 4)) * 512 + ((r & 15) + 16 * h) * 8;
 
-    load_tiles(0);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        store_tiles(buf);
-        __syncthreads();
-        if (kt + 1 < nk) load_tiles(kt + 1);
+    auto multiply = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            bf16x8 af[NS][2], wf[NS][2];
+            bf16x8 af[NS][TM], wf[NS][TN];
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
+            for (int s = 0; s < NS; ++s) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < TM; ++i)
                     af[s][i] = *reinterpret_cast<const bf16x8*>(&As[buf][s][a_base + i * 32 * BG_LD + q * 16]);
-                    wf[s][i] = *reinterpret_cast<const bf16x8*>(&Ws[buf][s][w_base + i * 2 * 512 + q * 32 * 8]);
-                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    wf[s][j] = *reinterpret_cast<const bf16x8*>(&Ws[buf][s][w_base + j * 2 * 512 + q * 32 * 8]);
+            }
             if (NS == 2) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NS - 1][i], wf[0][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], wf[NS - 1][j], acc[i][j], 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], wf[0][j], acc[i][j], 0, 0, 0);
         }
-        buf ^= 1;
+    };
+
+    load_tiles(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        store_tiles(buf);
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        multiply(buf);
     }
 
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + j * 32 + r;
         if (col >= p.N) continue;
         const float s1 = p.s1 ? p.s1[col] : 1.0f;
         const float b1 = p.b1 ? p.b1[col] : 0.0f;
         const float s2 = p.s2 ? p.s2[col] : 1.0f;
         const float b2 = p.s2 ? p.b2[col] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value(p, acc[i][j][e], row, col, s1, b1, s2, b2);
             }
         }
@@ -624,12 +647,13 @@ int launch(const estts_gemm_args& a, int splitk, hipStream_t st) {
     return 0;
 }
 
+template <int TM, int TN, int OCC, int PF>
 int launch_big(const estts_gemm_args& a, hipStream_t st) {
-    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, 1);
+    dim3 grid((a.N + 64 * TN - 1) / (64 * TN), (a.M + 64 * TM - 1) / (64 * TM), 1);
     if (a.precision == 3)
-        hipLaunchKernelGGL((gemm_big_kernel<3>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_big_kernel<3, TM, TN, OCC, PF>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((gemm_big_kernel<1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_big_kernel<1, TM, TN, OCC, PF>), grid, dim3(256), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_gemm");
     return 0;
 }
@@ -674,10 +698,13 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
     int tile = a.tune & 0xff;
     int splitk = (a.tune >> 8) & 0xff;
     if (tile == 0) {
-        // measured on MI355X (tools/tune_gemm_big.py): the 128 x 128 kernel wins once its tiles fill most of the chip,
-        // below that the barrier-free 32 x 32 kernel does; the 64 x 64 kernels are kept for explicit selection only
-        const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-        tile = (t128 >= 192 && a.N >= 128) ? 5 : 4;
+        // measured on MI355X (tools/tune_gemm_big.py, tools/tune_wavernn_gemm.py): the LDS-staged kernel wins once its
+        // workgroups fill the chip -- as 64 x 128 tiles when there are enough of those, else as 64 x 64 tiles -- and
+        // below that the barrier-free 32 x 32 kernel does.  The 128 x 128 and 128 x 64 shapes and the older 64 x 64
+        // kernels (ids 1-3) never win at these sizes and are kept for explicit selection only.
+        const long mt = (a.M + 63) / 64;
+        const long n8 = mt * ((a.N + 127) / 128), n6 = mt * ((a.N + 63) / 64);
+        tile = (a.N >= 128 && n8 >= 384) ? 8 : (n6 >= 288 ? 6 : 4);
     }
     long tiles;
     int nk;  // K units that one split must keep at least two of
@@ -686,7 +713,11 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         case 2: tiles = (long)((a.M + 31) / 32) * ((a.N + 63) / 64); nk = (a.K + BK - 1) / BK; break;
         case 3: tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32); nk = (a.K + BK - 1) / BK; break;
         case 4: tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32); nk = (a.K + 31) / 32 / 8; break;
-        case 5: return launch_big(a, st);
+        case 5: return launch_big<2, 2, 2, 1>(a, st);
+        case 6: return launch_big<1, 1, 4, 1>(a, st);
+        case 7: return launch_big<2, 1, 2, 1>(a, st);
+        case 8: return launch_big<1, 2, 3, 1>(a, st);
+
         default: estts_set_error("estts_gemm: unknown tile id %d", tile); return -1;
     }
     if (nk < 1) nk = 1;

@@ -48,23 +48,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     const int ncol = n0 + chunk * 4;
     const bool ycol_ok = ncol < ga.N;
 
+    // loads are unconditional and zeroed where they are used (see load_a_raw)
     float4 a_reg[2], y_reg[2];
+    bool a_ok[2], y_ok[2];
     auto load = [&](int m0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = m0 + r0 + 16 * i;
             const ARow ar = make_arow(ga, row);
-            a_reg[i] = load_a(ga, ar, tp);
-            y_reg[i] = (row < ga.M && ycol_ok) ? *reinterpret_cast<const float4*>(dY + (long)row * lddy + ncol)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            a_reg[i] = load_a_raw(ga, ar, tp, a_ok[i]);
+            y_ok[i] = row < ga.M && ycol_ok;
+            y_reg[i] = *reinterpret_cast<const float4*>(dY + (y_ok[i] ? (long)row * lddy + ncol : 0L));
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int o = (r0 + 16 * i) * LD + chunk * 4;
-            const float av[4] = {a_reg[i].x, a_reg[i].y, a_reg[i].z, a_reg[i].w};
-            const float yv[4] = {y_reg[i].x, y_reg[i].y, y_reg[i].z, y_reg[i].w};
+            const float4 az = zero_unless(a_ok[i], a_reg[i]);
+            const float4 yz = zero_unless(y_ok[i], y_reg[i]);
+            const float av[4] = {az.x, az.y, az.z, az.w};
+            const float yv[4] = {yz.x, yz.y, yz.z, yz.w};
             bf16x4 ah, al, yh, yl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -26,7 +26,7 @@ def main():
         out = torch.empty(M, N, device='cuda')
         res = []
         cands = [(t, sk, 0) for t, sk in itertools.product((1, 2, 3), (1, 2, 4))] + \
-                [(4, sk, wv) for sk, wv in itertools.product((1, 2), (4, 8, 16))] + [(5, 1, 0)]
+                [(4, sk, wv) for sk, wv in itertools.product((1, 2), (4, 8))] + [(5, 1, 0), (6, 1, 0), (7, 1, 0), (8, 1, 0)]
         for tile, sk, wv in cands:
             tune = tile | (sk << 8) | (wv << 16) | flags
             try:
