@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -33,7 +33,7 @@ class AttentionArgs(C.Structure):
     _fields_ = [('q', _vp), ('ldq', _i32), ('k', _vp), ('ldk', _i32), ('v', _vp), ('ldv', _i32),
                 ('ctx', _vp), ('ldo', _i32), ('attn', _vp), ('key_mask', _vp),
                 ('B', _i32), ('H', _i32), ('Lq', _i32), ('Lk', _i32), ('depth', _i32),
-                ('causal', _i32), ('precision', _i32), ('kv_shared', _i32)]
+                ('causal', _i32), ('precision', _i32), ('kv_shared', _i32), ('variant', _i32)]
 
 
 class RownormArgs(C.Structure):

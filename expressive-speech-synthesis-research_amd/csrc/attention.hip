@@ -320,6 +320,233 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     }
 }
 
+
+// ======================================================================================================
+// Batched variant: a workgroup owns 64 query rows of one (batch, head), 16 per wave, and all four waves share every
+// staged K / V tile (32 keys, loaded and split once per workgroup instead of once per 16 queries: a quarter of the
+// L2 traffic and of the conversion work of the kernel above, which is what bounds it at batch 32).  Each wave keeps
+// the whole softmax state of its own queries, so nothing is merged at the end.  Used when the launch has enough
+// (batch, head, 64-query) workgroups to fill the chip.
+//   * no weights wanted: one sweep with the online softmax; a causal launch stops at the last key tile any of the
+//     workgroup's queries may see -- unless one of them has only masked keys there (its row is then uniform over ALL
+//     keys, future ones included, exactly as softmax(-1e9 everywhere) is), in which case the sweep goes on to the end;
+//   * weights wanted: a first sweep over K finds m and l, a second one over K and V writes exp(s - m) / l and
+//     accumulates the normalised output.
+// ======================================================================================================
+template <int DH, int NS>
+__global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attention_args p) {
+    constexpr int KS = DH / 32;
+    constexpr int NT = DH / 16;
+    constexpr int LD = DH + 8;
+    constexpr int IMG = 32 * LD;
+    constexpr int LPR = DH / 4;        // threads per tile row (one float4 each)
+    constexpr int RPP = 256 / LPR;     // tile rows per pass of the workgroup
+    constexpr int NLD = 32 / RPP;      // passes per 32-key tile
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2][2][NS][IMG];   // [buffer][K, V][hi, lo]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int g = lane >> 4;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int qi = blockIdx.x * 64 + wave * 16 + i;
+    const int qrow = min(qi, p.Lq - 1);
+    const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * DH + 8 * g;
+    const long kvb = p.kv_shared ? 0 : b;
+    const float* kbase = p.k + kvb * p.Lk * p.ldk + h * DH;
+    const float* vbase = p.v + kvb * p.Lk * p.ldv + h * DH;
+    const float* mask = p.key_mask ? p.key_mask + (long)b * p.Lk : nullptr;
+    const float scale = 1.0f / sqrtf((float)DH);
+
+    Frag<NS> qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float t[8];
+        *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(qp + ks * 32);
+        *reinterpret_cast<float4*>(t + 4) = *reinterpret_cast<const float4*>(qp + ks * 32 + 4);
+        qf[ks] = make_frag<NS>(t);
+    }
+
+    const int ld_row = tid / LPR;
+    const int ld_col = (tid % LPR) * 4;
+    auto load_tile = [&](const float* base, int ld, int kt, float4 (&x)[NLD]) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int key = min(kt * 32 + j * RPP + ld_row, p.Lk - 1);
+            x[j] = *reinterpret_cast<const float4*>(base + (long)key * ld + ld_col);
+        }
+    };
+    auto stage_tile = [&](const float4 (&x)[NLD], __bf16* dst) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const float v[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 hh, ll;
+                split_bf16(v[e], hh, ll);
+                hi[e] = hh;
+                lo[e] = ll;
+            }
+            const int o = (j * RPP + ld_row) * LD + ld_col;
+            *reinterpret_cast<bf16x4*>(dst + o) = hi;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(dst + IMG + o) = lo;
+        }
+    };
+    // scores of a staged K tile for this lane's query: s[sub * 4 + j] <-> key kt*32 + sub*16 + 4g + j
+    auto scores = [&](int kt, const __bf16* kimg, float (&s)[8]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<NS> kf;
+                const int o = (sub * 16 + i) * LD + ks * 32 + g * 8;
+                kf.v[0] = *reinterpret_cast<const bf16x8*>(kimg + o);
+                if (NS == 2) kf.v[NS - 1] = *reinterpret_cast<const bf16x8*>(kimg + IMG + o);
+                acc = mfma_split<NS>(kf, qf[ks], acc);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = kt * 32 + sub * 16 + 4 * g + j;
+                float v = acc[j] * scale;
+                if (key >= p.Lk) {
+                    v = -INFINITY;
+                } else {
+                    float mk = mask ? mask[key] : 0.0f;
+                    if (p.causal && key > qi) mk = 1.0f;
+                    v += mk * -1e9f;
+                }
+                s[sub * 4 + j] = v;
+            }
+        }
+    };
+    auto times_v = [&](const float (&pv)[8], const __bf16* vimg, f32x4 (&o)[NT]) {
+        const Frag<NS> pf = make_frag<NS>(pv);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            Frag<NS> vf;
+            const int o0 = (4 * g + (i >> 2)) * LD + nt * 16 + 4 * (i & 3);
+            vf.v[0] = tr_read_pair(vimg + o0, vimg + o0 + 16 * LD);
+            if (NS == 2) vf.v[NS - 1] = tr_read_pair(vimg + IMG + o0, vimg + IMG + o0 + 16 * LD);
+            o[nt] = mfma_split<NS>(vf, pf, o[nt]);
+        }
+    };
+
+    f32x4 o[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const int nkt = (p.Lk + 31) / 32;
+    float4 kx[NLD], vx[NLD];
+    int par = 0;   // staging buffer of the next tile (uniform over the workgroup)
+
+    // one sweep over key tiles [t0, t1): WITH_V also stages V; the body gets the tile number and the two images
+    auto sweep = [&](int t0, int t1, bool with_v, auto&& body) {
+        if (t0 >= t1) return;
+        load_tile(kbase, p.ldk, t0, kx);
+        if (with_v) load_tile(vbase, p.ldv, t0, vx);
+        for (int kt = t0; kt < t1; ++kt) {
+            __bf16* kimg = &smem[par][0][0][0];
+            __bf16* vimg = &smem[par][1][0][0];
+            stage_tile(kx, kimg);
+            if (with_v) stage_tile(vx, vimg);
+            __syncthreads();   // also: every wave is done with the other buffer, which the next tile will overwrite
+            if (kt + 1 < t1) {
+                load_tile(kbase, p.ldk, kt + 1, kx);
+                if (with_v) load_tile(vbase, p.ldv, kt + 1, vx);
+            }
+            body(kt, kimg, vimg);
+            par ^= 1;
+        }
+    };
+    auto online = [&](int kt, const __bf16* kimg, const __bf16* vimg, bool with_v) {
+        float s[8];
+        scores(kt, kimg, s);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tmax = fmaxf(tmax, s[e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        float pv[8], psum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pv[e] = expf(s[e] - m_new);
+            psum += pv[e];
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (with_v) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) o[nt] = o[nt] * alpha;
+            times_v(pv, vimg, o);
+        }
+    };
+
+    float inv_l;
+    if (!p.attn) {
+        const int last_q = min(blockIdx.x * 64 + 63, p.Lq - 1);
+        const int nlim = p.causal ? min(nkt, last_q / 32 + 1) : nkt;
+        sweep(0, nlim, true, [&](int kt, const __bf16* kimg, const __bf16* vimg) { online(kt, kimg, vimg, true); });
+        if (nlim < nkt) {
+            // a query whose visible keys are all masked has every score at -1e9, the future keys' included
+            const int all_masked = __syncthreads_or(qi < p.Lq && m_run < -5e8f);
+            if (all_masked)
+                sweep(nlim, nkt, true, [&](int kt, const __bf16* kimg, const __bf16* vimg) { online(kt, kimg, vimg, true); });
+        }
+        inv_l = 1.0f / l_run;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = o[nt] * inv_l;
+    } else {
+        sweep(0, nkt, false, [&](int kt, const __bf16* kimg, const __bf16* vimg) { online(kt, kimg, vimg, false); });
+        inv_l = 1.0f / l_run;
+        float* ap = p.attn + (((long)b * p.H + h) * p.Lq + qrow) * p.Lk;
+        const bool vec = (p.Lk & 3) == 0;
+        sweep(0, nkt, true, [&](int kt, const __bf16* kimg, const __bf16* vimg) {
+            float s[8], pv[8];
+            scores(kt, kimg, s);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = expf(s[e] - m_run) * inv_l;
+            if (qi < p.Lq) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int key0 = kt * 32 + sub * 16 + 4 * g;
+                    if (vec && key0 + 3 < p.Lk) {
+                        *reinterpret_cast<float4*>(ap + key0) = make_float4(pv[sub * 4], pv[sub * 4 + 1], pv[sub * 4 + 2], pv[sub * 4 + 3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (key0 + j < p.Lk) ap[key0 + j] = pv[sub * 4 + j];
+                    }
+                }
+            }
+            times_v(pv, vimg, o);
+        });
+    }
+    if (qi < p.Lq) {
+        float* op = p.ctx + ((long)b * p.Lq + qi) * p.ldo + h * DH + 4 * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(op + nt * 16) = make_float4(o[nt][0], o[nt][1], o[nt][2], o[nt][3]);
+    }
+}
+
+template <int DH>
+int launch_wide(const estts_attention_args& a, hipStream_t st) {
+    dim3 grid((a.Lq + 63) / 64, a.H, a.B);
+    if (a.precision == 3)
+        hipLaunchKernelGGL((attention_wide_kernel<DH, 2>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((attention_wide_kernel<DH, 1>), grid, dim3(256), 0, st, a);
+    ESTTS_CHECK_LAUNCH("estts_attention");
+    return 0;
+}
+
 template <int DH, int MAXT>
 int launch_t(const estts_attention_args& a, hipStream_t st) {
     dim3 grid((a.Lq + 15) / 16, a.H, a.B);
@@ -333,6 +560,9 @@ int launch_t(const estts_attention_args& a, hipStream_t st) {
 
 template <int DH>
 int launch(const estts_attention_args& a, hipStream_t st) {
+    // variant: 0 = by launch size, 1 = 16-query workgroups, 2 = 64-query workgroups
+    const long wide_wgs = (long)((a.Lq + 63) / 64) * a.H * a.B;
+    if (a.variant == 2 || (a.variant == 0 && wide_wgs >= 512 && a.Lk >= 64)) return launch_wide<DH>(a, st);
     const int per_wave = ((a.Lk + 31) / 32 + 3) / 4;   // key tiles each wave sweeps
     if (a.attn && per_wave <= 2) return launch_t<DH, 2>(a, st);
     if (a.attn && per_wave <= 5) return launch_t<DH, 5>(a, st);

@@ -228,7 +228,7 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
 
 
 def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, attn=None, precision='bf16x3',
-              kv_shared=False):
+              kv_shared=False, variant=0):
     """q: [B*Lq, >=H*depth] view, k/v: [B*Lk, ...] views, ctx: [B*Lq, ...] view; attn: [B,H,Lq,Lk] or None."""
     for t, n in ((q, 'q'), (k, 'k'), (v, 'v'), (ctx, 'ctx')):
         _check_f32(t, n)
@@ -246,6 +246,7 @@ def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, at
     a.causal = int(causal)
     a.precision = PRECISION[precision]
     a.kv_shared = int(kv_shared)
+    a.variant = variant
     if _program is not None:
         _program.append(('attention', a, (q, k, v, ctx, attn, key_mask)))
         return ctx

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 9
+#define ESTTS_ABI_VERSION 10
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -138,6 +138,8 @@ typedef struct estts_attention_args {
     int32_t causal;
     int32_t precision;       /* 1 or 3, as in estts_gemm */
     int32_t kv_shared;       /* 1 = k / v hold Lk rows used by every batch entry (style tokens) */
+    int32_t variant;         /* 0 = choose by launch size; 1 = 16-query workgroups whose waves split the keys (few
+                                queries: batch 1); 2 = 64-query workgroups sharing each staged K / V tile (batches) */
 } estts_attention_args;
 
 int estts_attention(const estts_attention_args* args, void* stream);

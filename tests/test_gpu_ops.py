@@ -170,6 +170,51 @@ def test_attention(B, H, Lq, Lk, dh, causal, masked, precision, tol):
     assert torch.equal(ctx2, ctx[:, :d])
 
 
+@pytest.mark.parametrize('B,H,Lq,Lk,dh,causal,masked,first_masked', [
+    (2, 2, 150, 150, 64, False, True, False), (2, 2, 150, 150, 64, True, True, False), (1, 2, 130, 130, 64, True, False, True),
+    (2, 1, 70, 45, 32, False, True, False), (1, 2, 65, 201, 128, False, False, False), (2, 2, 200, 200, 32, True, False, True)])
+@pytest.mark.parametrize('with_weights', [False, True])
+def test_attention_64_query_variant(B, H, Lq, Lk, dh, causal, masked, first_masked, with_weights):
+    """The batched kernel (64 queries per workgroup, shared K / V tiles), forced with variant=2: ragged Lq / Lk, key
+    masks, the causal early stop, and a query whose visible keys are all masked (key 0 masked under a causal mask):
+    float32 absorbs every score into -1e9 there, so that row is uniform over ALL keys, as in the reference."""
+    d = H * dh
+    q, k, v = _rand(B * Lq, d, seed=11), _rand(B * Lk, d, seed=12), _rand(B * Lk, d, seed=13)
+    mask = None
+    if masked or first_masked:
+        mask = torch.zeros(B, Lk)
+        if masked:
+            for b in range(B):
+                mask[b, Lk - 1 - 3 * b:] = 1.0
+        if first_masked:
+            mask[:, 0] = 1.0
+    ctx = torch.full((B * Lq, d + 4), float('nan'), device=DEV)
+    attn = torch.full((B, H, Lq, Lk), float('nan'), device=DEV) if with_weights else None
+    ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), ctx[:, :d], B, H, Lq, Lk, dh,
+                  key_mask=None if mask is None else mask.to(DEV), causal=causal, attn=attn, variant=2)
+    split = lambda t, L: t.double().view(B, L, H, dh).permute(0, 2, 1, 3)
+    qs, ks, vs = split(q, Lq), split(k, Lk), split(v, Lk)
+    m = torch.zeros(B, 1, Lq, Lk, dtype=torch.float64)
+    if mask is not None:
+        m = torch.maximum(m, mask[:, None, None, :].double())
+    if causal:
+        m = torch.maximum(m, torch.triu(torch.ones(Lq, Lk, dtype=torch.float64), diagonal=1))
+    logits = ((qs @ ks.transpose(-1, -2)) / math.sqrt(dh)).float() + (m * -1e9).float()      # the float32 sum, as computed
+    pref = torch.softmax(logits.double(), dim=-1)
+    ref = (pref @ vs).permute(0, 2, 1, 3).reshape(B * Lq, d)
+    if first_masked:
+        assert abs(pref[0, 0, 0].max().item() - 1.0 / Lk) < 1e-12      # the uniform row is really in the case
+    assert (ctx[:, :d].cpu().double() - ref).abs().max().item() < 3e-5
+    assert torch.isnan(ctx[:, d:]).all()
+    if with_weights:
+        assert (attn.cpu().double() - pref).abs().max().item() < 3e-5
+    # and the 16-query kernel gives the same numbers
+    ctx1 = torch.empty(B * Lq, d, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), ctx1, B, H, Lq, Lk, dh,
+                  key_mask=None if mask is None else mask.to(DEV), causal=causal, variant=1)
+    assert (ctx1 - ctx[:, :d]).abs().max().item() < 3e-5
+
+
 def test_attention_online_softmax_rescale_branch():
     # one key far above the rest, late in the sequence: forces the running-max rescale at a chosen tile
     B, H, L, dh = 1, 1, 96, 32
