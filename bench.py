@@ -105,9 +105,14 @@ def wavernn_pass(precision):
                         'host cross-fade / mu-law expansion'}
 
 
+NO_ROOFLINE = False
+
+
 def roofline_from_trace(trace, kernel_table, rank):
     """Groups the traced launches by kernel and shape, times one representative of every group in isolation and prices
     the dominant group against its roofline."""
+    if NO_ROOFLINE:
+        return None, len(trace)
     groups = {}
     for kind, info, fn in trace:
         key = (kind,) + tuple(sorted((k, v) for k, v in info.items() if k not in ('flops', 'bytes')))
@@ -364,6 +369,8 @@ def main():
     ap.add_argument('--no-attention-weights', action='store_true',
                     help='skip materialising the attention maps the reference returns')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true',
+                    help='skip the per-kernel timing pass (clean kernel statistics under rocprofv3); roofline is then null')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
     ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn', 'predict'],
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
@@ -371,6 +378,8 @@ def main():
                          "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
     ap.add_argument('--no-wavernn', action='store_true', help='skip the WaveRNN (config 4) pass reported under "wavernn"')
     args = ap.parse_args()
+    global NO_ROOFLINE
+    NO_ROOFLINE = args.no_roofline
 
     from estts import parallel
     rank, world, local_rank = parallel.env_ranks()

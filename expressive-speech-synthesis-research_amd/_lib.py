@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -84,7 +84,7 @@ class ProgOp(C.Structure):
 class ColreduceArgs(C.Structure):
     _fields_ = [('z', _vp), ('ldz', _i32), ('g', _vp), ('ldg', _i32), ('a', _vp), ('lda', _i32), ('act', _i32),
                 ('mean', _vp), ('rstd', _vp), ('out0', _vp), ('out1', _vp), ('dy_out', _vp), ('lddy', _i32),
-                ('M', _i32), ('C', _i32), ('mode', _i32), ('scale', _vp), ('shift', _vp)]
+                ('M', _i32), ('C', _i32), ('mode', _i32), ('scale', _vp), ('shift', _vp), ('ws', _vp), ('ws_bytes', _i64)]
 
 
 class WavernnPrepArgs(C.Structure):

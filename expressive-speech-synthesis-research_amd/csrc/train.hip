@@ -1,6 +1,7 @@
 // Training-side HBM-bound kernels: weight re-packing, LayerNorm-combo backward, BatchNorm batch statistics and
 // backward, dropout, gradient plumbing (embedding, length regulator, loss) and Adam.
 // (see the "Training" block of include/estts.h)
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -191,6 +192,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* grad, 
 }
 
 // ------------------------------------------------------------------------------------------
+constexpr int COLREDUCE_SLOTS = 16;
+
 // column reductions: a workgroup covers 256 columns (64 float4 chunks) x 4 row lanes; gridDim.y splits the rows
 __global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_args p) {
     __shared__ float4 red[2][4][64];
@@ -245,13 +248,44 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_ar
             a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
             b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
         }
-        atomic_add_f32(p.out0 + c, a.x); atomic_add_f32(p.out0 + c + 1, a.y);
-        atomic_add_f32(p.out0 + c + 2, a.z); atomic_add_f32(p.out0 + c + 3, a.w);
+        // Float atomics on one address from hundreds of workgroups serialise at ~0.1 us each: with a workspace the row
+        // splits are spread over COLREDUCE_SLOTS copies of the sums, which colreduce_finish_kernel adds up.
+        float* o0 = p.out0;
+        float* o1 = p.out1;
+        if (p.ws) {
+            const long cp = (long)gridDim.x * 256;
+            o0 = p.ws + (long)(blockIdx.y % COLREDUCE_SLOTS) * 2 * cp;
+            o1 = o0 + cp;
+        }
+        atomic_add_f32(o0 + c, a.x); atomic_add_f32(o0 + c + 1, a.y);
+        atomic_add_f32(o0 + c + 2, a.z); atomic_add_f32(o0 + c + 3, a.w);
         if (p.mode != 1) {
-            atomic_add_f32(p.out1 + c, b.x); atomic_add_f32(p.out1 + c + 1, b.y);
-            atomic_add_f32(p.out1 + c + 2, b.z); atomic_add_f32(p.out1 + c + 3, b.w);
+            atomic_add_f32(o1 + c, b.x); atomic_add_f32(o1 + c + 1, b.y);
+            atomic_add_f32(o1 + c + 2, b.z); atomic_add_f32(o1 + c + 3, b.w);
         }
     }
+}
+
+// adds the slots to out0 / out1 and leaves the workspace zero for the next call
+__global__ __launch_bounds__(256) void colreduce_finish_kernel(float* ws, long cp, int C, float* out0, float* out1) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float v0[COLREDUCE_SLOTS], v1[COLREDUCE_SLOTS];
+#pragma unroll
+    for (int k = 0; k < COLREDUCE_SLOTS; ++k) {
+        v0[k] = ws[(long)k * 2 * cp + c];
+        v1[k] = out1 ? ws[(long)k * 2 * cp + cp + c] : 0.0f;
+    }
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < COLREDUCE_SLOTS; ++k) {
+        s0 += v0[k];
+        s1 += v1[k];
+        ws[(long)k * 2 * cp + c] = 0.0f;
+        if (out1) ws[(long)k * 2 * cp + cp + c] = 0.0f;
+    }
+    out0[c] += s0;
+    if (out1) out1[c] += s1;
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* s0, const float* s1, const float* z0, int M, int C,
@@ -613,10 +647,25 @@ extern "C" int estts_colreduce(const estts_colreduce_args* args, void* stream) {
         ESTTS_CHECK_ARG((a.scale == nullptr) == (a.shift == nullptr), "estts_colreduce: scale and shift go together");
         ESTTS_CHECK_ARG(!a.scale || a.a || (a.z && (a.ldz & 3) == 0), "estts_colreduce: recomputing the activation needs z");
     }
-    int ysplit = (a.M + 63) / 64;
-    if (ysplit > 128) ysplit = 128;
-    dim3 grid((a.C + 255) / 256, ysplit);
-    hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    // enough workgroups to keep every CU's memory pipeline busy (the row loop is a chain of dependent loads), at least 16
+    // rows per workgroup (about 512 workgroups measured best; ESTTS_COLREDUCE_WGS overrides it for measurements); without a
+    // workspace all row splits meet on the same addresses, which caps their useful number
+    static const int target = [] { const char* e = getenv("ESTTS_COLREDUCE_WGS"); return e ? atoi(e) : 512; }();
+    const int gx = (a.C + 255) / 256;
+    const long cp = (long)gx * 256;
+    estts_colreduce_args k = a;
+    if (k.ws && k.ws_bytes < (int64_t)COLREDUCE_SLOTS * 2 * cp * 4) k.ws = nullptr;
+    int ysplit = (a.M + 15) / 16;
+    const int cap = k.ws ? (target + gx - 1) / gx : 128;
+    if (ysplit > cap) ysplit = cap;
+    if (ysplit <= 32) k.ws = nullptr;
+    dim3 grid(gx, ysplit);
+    hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+    if (k.ws) {
+        ESTTS_CHECK_LAUNCH("estts_colreduce");
+        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, k.ws, cp, a.C, a.out0,
+                           a.mode != 1 ? a.out1 : nullptr);
+    }
     ESTTS_CHECK_LAUNCH("estts_colreduce");
     return 0;
 }

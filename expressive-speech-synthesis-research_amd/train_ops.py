@@ -104,6 +104,18 @@ def rownorm_bwd(fwd_args, dout=None, ddot=None, dy=None, dx=None, dx_accumulate=
     check(_lib.load().estts_rownorm_bwd(a, _stream()), 'estts_rownorm_bwd')
 
 
+_colreduce_ws = {}
+
+
+def colreduce_workspace(device):
+    """Per-device scratch over which colreduce spreads its atomics (zero between calls; calls on one stream may share it)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _colreduce_ws.get(key)
+    if ws is None:
+        ws = _colreduce_ws[key] = torch.zeros(16 * 2 * 8192, dtype=torch.float32, device=torch.device('cuda', key))
+    return ws
+
+
 def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None, rstd=None, dy_out=None, M=None, C=None,
               scale=None, shift=None):
     r = ColreduceArgs()
@@ -123,6 +135,8 @@ def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None
         r.dy_out, r.lddy = dy_out.data_ptr(), dy_out.stride(0)
     r.mode = mode
     r.scale, r.shift = _ptr(scale), _ptr(shift)
+    ws = colreduce_workspace(out0.device)
+    r.ws, r.ws_bytes = ws.data_ptr(), ws.numel() * 4
     check(_lib.load().estts_colreduce(r, _stream()), 'estts_colreduce')
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 10
+#define ESTTS_ABI_VERSION 11
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -371,6 +371,9 @@ typedef struct estts_colreduce_args {
     float* dy_out; int32_t lddy;
     int32_t M, C, mode;
     const float* scale; const float* shift;
+    float* ws; int64_t ws_bytes;   /* optional scratch, ZERO before the first call (every call leaves it zero): 16 copies of
+                                      the two sums, 128 * ceil(C / 256) * 256 bytes, over which the row splits spread their
+                                      float atomics; NULL = all splits add into out0 / out1 directly */
 } estts_colreduce_args;
 
 int estts_colreduce(const estts_colreduce_args* args, void* stream);
