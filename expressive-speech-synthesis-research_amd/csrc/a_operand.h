@@ -29,18 +29,48 @@ __device__ __forceinline__ ARow make_arow(const estts_gemm_args& p, int m) {
     return r;
 }
 
-__device__ __forceinline__ ATap make_atap(const estts_gemm_args& p, int kk) {
+__device__ __forceinline__ ATap atap_from(const estts_gemm_args& p, int kk, int tap, int c) {
     ATap t;
     t.ok = kk < p.K;
-    int tap = 0;
-    t.c = kk;
+    t.c = c;
+    if (p.taps > p.conv_kw) {   // 2-D kernel: tap = (kh, kw)
+        t.dh = tap / p.conv_kw;
+        t.dw = tap - t.dh * p.conv_kw;
+    } else {                    // dense layer or 1-D convolution: one kernel row
+        t.dh = 0;
+        t.dw = tap;
+    }
+    return t;
+}
+
+__device__ __forceinline__ ATap make_atap(const estts_gemm_args& p, int kk) {
+    int tap = 0, c = kk;
     if (p.taps > 1) {
         tap = kk / p.c_per_tap;
-        t.c = kk - tap * p.c_per_tap;
+        c = kk - tap * p.c_per_tap;
     }
-    t.dh = tap / p.conv_kw;
-    t.dw = tap - t.dh * p.conv_kw;
-    return t;
+    return atap_from(p, kk, tap, c);
+}
+
+// (tap, channel) of a K index that only ever advances by a fixed step: one division at the start, none in the K loop
+struct KCursor {
+    int kk, tap, c;
+};
+__device__ __forceinline__ KCursor make_kcursor(const estts_gemm_args& p, int kk) {
+    KCursor k;
+    k.kk = kk;
+    k.tap = p.taps > 1 ? kk / p.c_per_tap : 0;
+    k.c = kk - k.tap * p.c_per_tap;
+    return k;
+}
+__device__ __forceinline__ void advance(const estts_gemm_args& p, KCursor& k, int step) {
+    k.kk += step;
+    k.c += step;
+    if (p.taps > 1)
+        while (k.c >= p.c_per_tap) {
+            k.c -= p.c_per_tap;
+            ++k.tap;
+        }
 }
 
 // The load is unconditional (a padded position reads element 0, which exists) and the caller zeroes the value where it

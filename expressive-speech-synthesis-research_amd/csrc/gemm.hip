@@ -477,8 +477,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
     static_assert(TN == 1 || TN == 2, "one or two 16-byte W units per thread");
     uint4 wh0, wh1, wl0, wl1;
     static_assert(PF == 1, "one register set");
+    KCursor kcur = make_kcursor(p, a_ch * 4);   // load_tiles is called for kt = 0, 1, 2, ... in order
     auto load_tiles = [&](int kt) {
-        const ATap tp = make_atap(p, kt * 32 + a_ch * 4);
+        const ATap tp = atap_from(p, kcur.kk, kcur.tap, kcur.c);
+        advance(p, kcur, 32);
 #pragma unroll
         for (int i = 0; i < AI; ++i) a_reg[i] = load_a_raw(p, a_row[i], tp, a_ok[i]);
         // (named registers, not an array: with an array of two the compiler keeps the fragments in scratch memory)

@@ -51,11 +51,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     // loads are unconditional and zeroed where they are used (see load_a_raw)
     float4 a_reg[2], y_reg[2];
     bool a_ok[2], y_ok[2];
-    auto load = [&](int m0) {
+    // Rows only ever advance by 32: for dense layers and 1-D convolutions (one output row per image) the position of a
+    // row inside its sequence is carried along instead of being divided out again at every step.
+    const bool one_d = ga.conv_howo == ga.conv_wo;
+    int seq[2], pos[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m_begin + r0 + 16 * i;
+        seq[i] = row / ga.conv_howo;
+        pos[i] = row - seq[i] * ga.conv_howo;
+    }
+    auto load = [&](int m0) {   // called for m0 = m_begin, m_begin + 32, ... in order
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = m0 + r0 + 16 * i;
-            const ARow ar = make_arow(ga, row);
+            ARow ar;
+            if (one_d) {
+                ar.ok = row < ga.M;
+                ar.pix0 = seq[i] * ga.conv_h * ga.conv_w;
+                ar.h0 = -ga.conv_pt;
+                ar.w0 = pos[i] * ga.conv_stride - ga.conv_pl;
+                pos[i] += 32;
+                while (pos[i] >= ga.conv_howo) {
+                    pos[i] -= ga.conv_howo;
+                    ++seq[i];
+                }
+            } else {
+                ar = make_arow(ga, row);
+            }
             a_reg[i] = load_a_raw(ga, ar, tp, a_ok[i]);
             y_ok[i] = row < ga.M && ycol_ok;
             y_reg[i] = *reinterpret_cast<const float4*>(dY + (y_ok[i] ? (long)row * lddy + ncol : 0L));
