@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -46,13 +46,13 @@ class RownormArgs(C.Structure):
 class RownormBwdArgs(C.Structure):
     _fields_ = [('f', RownormArgs), ('dout', _vp), ('lddout', _i32), ('ddot', _vp), ('dy', _vp), ('lddy', _i32),
                 ('dx', _vp), ('lddx', _i32), ('dx_accumulate', _i32), ('dga', _vp), ('dba', _vp), ('dgb', _vp), ('dbb', _vp),
-                ('ddot_w', _vp), ('ddot_b', _vp)]
+                ('ddot_w', _vp), ('ddot_b', _vp), ('ws', _vp), ('ws_bytes', _i64)]
 
 
 class WgradArgs(C.Structure):
     _fields_ = [('A', _vp), ('lda', _i32), ('seg_len', _i32), ('taps', _i32), ('c_per_tap', _i32), ('tap_lpad', _i32),
                 ('dY', _vp), ('lddy', _i32), ('M', _i32), ('N', _i32), ('K', _i32), ('dW', _vp), ('lddw', _i32),
-                ('precision', _i32), ('splits', _i32)]
+                ('precision', _i32), ('splits', _i32), ('db', _vp)]
 
 
 class AttentionBwdArgs(C.Structure):

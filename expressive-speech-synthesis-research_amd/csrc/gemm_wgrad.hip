@@ -28,7 +28,7 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const __bf16* p0, const __bf16* p
 
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, const float* dY, const int lddy, float* dW,
-                                                    const int lddw, const int rows_per_split) {
+                                                    const int lddw, const int rows_per_split, float* db) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][32 * LD];
     __shared__ __attribute__((aligned(16))) __bf16 Ys[2][NS][32 * LD];
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     // loads are unconditional and zeroed where they are used (see load_a_raw)
     float4 a_reg[2], y_reg[2];
     bool a_ok[2], y_ok[2];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of this thread's dY values (the bias gradient)
     // Rows only ever advance by 32: for dense layers and 1-D convolutions (one output row per image) the position of a
     // row inside its sequence is carried along instead of being divided out again at every step.
     const bool one_d = ga.conv_howo == ga.conv_wo;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
             const int o = (r0 + 16 * i) * LD + chunk * 4;
             const float4 az = zero_unless(a_ok[i], a_reg[i]);
             const float4 yz = zero_unless(y_ok[i], y_reg[i]);
+            bsum.x += yz.x; bsum.y += yz.y; bsum.z += yz.z; bsum.w += yz.w;
             const float av[4] = {az.x, az.y, az.z, az.w};
             const float yv[4] = {yz.x, yz.y, yz.z, yz.w};
             bf16x4 ah, al, yh, yl;
@@ -155,6 +157,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
         buf ^= 1;
     }
 
+    // bias gradient: the workgroups of the first K tile add up the dY rows they staged anyway
+    if (db != nullptr && blockIdx.x == 0) {   // uniform over the workgroup
+        __syncthreads();                      // the staging buffers are dead
+        float* red = reinterpret_cast<float*>(&As[0][0][0]);   // [16 row lanes][64 columns]
+        *reinterpret_cast<float4*>(red + r0 * 64 + chunk * 4) = bsum;
+        __syncthreads();
+        if (tid < 64 && n0 + tid < ga.N) {
+            float t = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * 64 + tid];
+            atomic_add_f32(db + n0 + tid, t);
+        }
+    }
+
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -215,9 +231,9 @@ extern "C" int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream) {
     splits = (a.M + rows_per_split - 1) / rows_per_split;
     dim3 grid((a.K + 63) / 64, (a.N + 63) / 64, splits);
     if (a.precision == 3)
-        hipLaunchKernelGGL((wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split);
+        hipLaunchKernelGGL((wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db);
     else
-        hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split);
+        hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db);
     ESTTS_CHECK_LAUNCH("estts_gemm_wgrad");
     return 0;
 }

@@ -361,6 +361,8 @@ __device__ __forceinline__ void ln_bwd_row(float4 (&g)[4], const float4 (&xh)[4]
         if (i < nch && lane + 64 * i < dq) F4_OP(g[i], rstd * (f4e(g[i], e) - a - f4e(xh[i], e) * b));
 }
 
+constexpr int ROWNORM_SLOTS = 16;
+
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bwd_args p) {
     __shared__ float red[4][1024];
     const estts_rownorm_args& f = p.f;
@@ -497,9 +499,13 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
         }
     }
 
-    // ---- parameter gradients: sum the four waves through LDS, then one atomic per column and workgroup
-    auto flush = [&](const float4 (&acc)[4], float* dst) {
+    // ---- parameter gradients: sum the four waves through LDS, then one atomic per column and workgroup -- into one of
+    // ROWNORM_SLOTS copies in the workspace when there is one (hundreds of workgroups adding to one address serialise at
+    // ~0.1 us each); rownorm_bwd_finish_kernel adds the copies up
+    const int slot = blockIdx.x % ROWNORM_SLOTS;
+    auto flush = [&](const float4 (&acc)[4], float* dst, int which) {
         if (dst == nullptr) return;  // uniform across the workgroup
+        if (p.ws) dst = p.ws + ((long)slot * 6 + which) * 1024;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -507,17 +513,38 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
         __syncthreads();
         for (int c = threadIdx.x; c < f.D; c += 256) atomic_add_f32(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
     };
-    flush(acc_ga, f.ga ? p.dga : nullptr);
-    flush(acc_ba, f.ga ? p.dba : nullptr);
-    flush(acc_gb, f.gb ? p.dgb : nullptr);
-    flush(acc_bb, f.gb ? p.dbb : nullptr);
-    flush(acc_dw, p.ddot ? p.ddot_w : nullptr);
+    flush(acc_ga, f.ga ? p.dga : nullptr, 0);
+    flush(acc_ba, f.ga ? p.dba : nullptr, 1);
+    flush(acc_gb, f.gb ? p.dgb : nullptr, 2);
+    flush(acc_bb, f.gb ? p.dbb : nullptr, 3);
+    flush(acc_dw, p.ddot ? p.ddot_w : nullptr, 4);
     if (p.ddot && p.ddot_b) {
         __syncthreads();
         if (lane == 0) red[0][wave] = acc_db;
         __syncthreads();
-        if (threadIdx.x == 0) atomic_add_f32(p.ddot_b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        if (threadIdx.x == 0)
+            atomic_add_f32(p.ws ? p.ws + ((long)slot * 6 + 5) * 1024 : p.ddot_b, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
     }
+}
+
+// adds the workspace copies to the gradient vectors and leaves the workspace zero; blockIdx.y = which vector
+__global__ __launch_bounds__(256) void rownorm_bwd_finish_kernel(const estts_rownorm_bwd_args p) {
+    float* dsts[6] = {p.f.ga ? p.dga : nullptr, p.f.ga ? p.dba : nullptr, p.f.gb ? p.dgb : nullptr, p.f.gb ? p.dbb : nullptr,
+                      p.ddot ? p.ddot_w : nullptr, p.ddot ? p.ddot_b : nullptr};
+    const int which = blockIdx.y;
+    float* dst = dsts[which];
+    if (dst == nullptr) return;
+    const int n = which == 5 ? 1 : p.f.D;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < ROWNORM_SLOTS; ++k) {
+        float* w = p.ws + ((long)k * 6 + which) * 1024 + c;
+        s += *w;
+        *w = 0.0f;
+    }
+    dst[c] += s;
 }
 
 int ew_grid(long total4) {
@@ -695,7 +722,13 @@ extern "C" int estts_rownorm_bwd(const estts_rownorm_bwd_args* args, void* strea
     ESTTS_CHECK_ARG(!a.dx || f.x, "estts_rownorm_bwd: dx without a residual input");
     int grid = (f.M + 3) / 4;
     if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    estts_rownorm_bwd_args k = a;
+    if (k.ws && (k.ws_bytes < (int64_t)ROWNORM_SLOTS * 6 * 1024 * 4 || grid <= 32)) k.ws = nullptr;
+    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    if (k.ws) {
+        ESTTS_CHECK_LAUNCH("estts_rownorm_bwd");
+        hipLaunchKernelGGL(rownorm_bwd_finish_kernel, dim3((f.D + 255) / 256, 6), dim3(256), 0, (hipStream_t)stream, k);
+    }
     ESTTS_CHECK_LAUNCH("estts_rownorm_bwd");
     return 0;
 }

@@ -279,8 +279,7 @@ class ForwardTransformerTrainer:
         """Kernel and bias gradients of layer L (input x, output gradient dy); optionally the input gradient into dx
         (added to dx when accumulate, or to `residual`)."""
         sl = seg if L.taps > 1 else 0
-        T.wgrad(x, dy, L.dk, taps=L.taps, lpad=L.lpad, M=M, seg_len=sl, precision=self.precision)
-        T.colreduce(1, L.db, g=dy, M=M, C=L.N)
+        T.wgrad(x, dy, L.dk, taps=L.taps, lpad=L.lpad, M=M, seg_len=sl, precision=self.precision, db=L.db)
         if dx is not None:
             ops.gemm(dy, L.lin.bwd, dx, M=M, seg_len=sl, precision=self.precision, residual=dx if accumulate else residual)
         return dx

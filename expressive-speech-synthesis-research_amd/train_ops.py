@@ -52,8 +52,9 @@ class TrainLinear:
                                             pk.w_lo.data_ptr(), _stream()), 'estts_pack_weight')
 
 
-def wgrad(x, dy, dw, taps=1, lpad=0, M=None, seg_len=0, precision='bf16x3', splits=0):
-    """dw[K, N] += conv-unfolded(x)^T dy (float atomics; dw must be zero or hold a partial sum)."""
+def wgrad(x, dy, dw, taps=1, lpad=0, M=None, seg_len=0, precision='bf16x3', splits=0, db=None):
+    """dw[K, N] += conv-unfolded(x)^T dy (float atomics; dw must be zero or hold a partial sum); db[N] += column sums
+    of dy (the bias gradient) when given."""
     a = WgradArgs()
     a.A, a.lda = x.data_ptr(), x.stride(0)
     K, N = dw.shape
@@ -62,10 +63,11 @@ def wgrad(x, dy, dw, taps=1, lpad=0, M=None, seg_len=0, precision='bf16x3', spli
     a.M, a.N, a.K = (x.shape[0] if M is None else M), N, K
     a.dW, a.lddw = dw.data_ptr(), dw.stride(0)
     a.precision, a.splits = PRECISION[precision], splits
+    a.db = _ptr(db)
     check(_lib.load().estts_gemm_wgrad(a, _stream()), 'estts_gemm_wgrad')
     ops._record('wgrad', {'M': a.M, 'N': N, 'K': K, 'taps': taps, 'flops': 2.0 * a.M * N * K,
                           'bytes': 4.0 * a.M * (K / taps + N) + 4.0 * N * K},
-                _lib.load().estts_gemm_wgrad, a, keep=(x, dy, dw))
+                _lib.load().estts_gemm_wgrad, a, keep=(x, dy, dw, db))
 
 
 def attention_bwd(q, k, v, ctx, dctx, attn, delta, dq, dk, dv, B, H, Lq, Lk, depth, precision='bf16x3'):
@@ -101,6 +103,8 @@ def rownorm_bwd(fwd_args, dout=None, ddot=None, dy=None, dx=None, dx_accumulate=
     if dln_b is not None:
         a.dgb, a.dbb = dln_b[0].data_ptr(), dln_b[1].data_ptr()
     a.ddot_w, a.ddot_b = _ptr(ddot_w), _ptr(ddot_b)
+    ws = colreduce_workspace(fwd_args._keep[0].device)      # both kernels leave it zero, calls on one stream may share it
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel() * 4
     check(_lib.load().estts_rownorm_bwd(a, _stream()), 'estts_rownorm_bwd')
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 11
+#define ESTTS_ABI_VERSION 12
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -311,6 +311,8 @@ typedef struct estts_wgrad_args {
     float* dW; int32_t lddw;
     int32_t precision;
     int32_t splits;
+    float* db;           /* optional: db[n] += sum_m dY[m, n], the bias gradient, from the rows the kernel stages anyway
+                            (zeroed by the caller like dW); NULL = not wanted */
 } estts_wgrad_args;
 
 int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream);
@@ -348,6 +350,9 @@ typedef struct estts_rownorm_bwd_args {
     float* dx; int32_t lddx; int32_t dx_accumulate;
     float* dga; float* dba; float* dgb; float* dbb;
     float* ddot_w; float* ddot_b;
+    float* ws; int64_t ws_bytes;   /* optional scratch, ZERO before the first call (every call leaves it zero), 16 * 6 * 1024
+                                      floats: the workgroups spread the float atomics of the parameter gradients over 16
+                                      copies; NULL = every workgroup adds into the gradient vectors directly */
 } estts_rownorm_bwd_args;
 
 int estts_rownorm_bwd(const estts_rownorm_bwd_args* args, void* stream);

@@ -70,6 +70,10 @@ def test_linear_forward_dgrad_wgrad(T, taps, lpad, cin, N, B, seg):
     db = torch.zeros(N, device='cuda')
     T.colreduce(1, db, g=dyd)
     assert rel_err(db, bt.grad) < 1e-5
+    # the bias gradient as a by-product of the weight-gradient kernel
+    db2 = torch.zeros(N, device='cuda')
+    T.wgrad(xd, dyd, torch.zeros(K, N, device='cuda'), taps=taps, lpad=lpad, seg_len=seg if taps > 1 else 0, splits=3, db=db2)
+    assert rel_err(db2, bt.grad) < 1e-5
 
 
 def test_wgrad_large_rows_many_splits(T):
