@@ -434,9 +434,9 @@ class ForwardTransformerTrainer:
     def set_constants(self, decoder_prenet_dropout=None, learning_rate=None, drop_n_heads=None, **kwargs):
         """models.py:458-465."""
         if decoder_prenet_dropout is not None:
-            if float(decoder_prenet_dropout) != 0.0:
-                raise NotImplementedError('decoder prenet dropout > 0 (the shipped forward schedule keeps it at 0)')
-            self.decoder_prenet_dropout = 0.0
+            if not 0.0 <= float(decoder_prenet_dropout) < 1.0:
+                raise ValueError('decoder_prenet_dropout must be in [0, 1)')
+            self.decoder_prenet_dropout = float(decoder_prenet_dropout)
         if learning_rate is not None:
             self.learning_rate = float(learning_rate)
         if drop_n_heads is not None:
@@ -542,10 +542,15 @@ class ForwardTransformerTrainer:
         mels_in = self._empty(Md, de)
         frame_mask = self._empty(B, Tm)
         ops.expand(enc_out, cum, mels_in, frame_mask, B, N, Tm, de)
+        # DecoderPrenet (layers.py:394-402): relu -> dropout after each dense layer, in the GEMM epilogue (sites 1000 / 1001
+        # of the step's generator, apart from the numbered sites of the regular dropouts).  p1 / p2 hold the dropped
+        # outputs, so `output > 0` is mask * relu' and the backward pass only adds the 1 / (1 - rate) factor.
+        rp = self.decoder_prenet_dropout
+        inv_keep = 1.0 / (1.0 - rp)
         p1 = self._empty(Md, self.prenet1.N)
-        self._lin_fwd(mels_in, self.prenet1, p1, Md)
+        self._lin_fwd(mels_in, self.prenet1, p1, Md, dropout=(rp, self._seed_now, 1000, 0))
         p2 = self._empty(Md, dd)
-        self._lin_fwd(p1, self.prenet2, p2, Md)
+        self._lin_fwd(p1, self.prenet2, p2, Md, dropout=(rp, self._seed_now, 1001, 0))
         dcat0 = self._empty(Md, 2 * dd)
         y0 = dcat0[:, :dd]
         T.affine_act(p2, y0, self.dec_scale, self.dec_shift, None, residual=self.pe_dec, r_mod=Tm, M=Md, C=dd)
@@ -554,11 +559,11 @@ class ForwardTransformerTrainer:
 
         def prenet_backward(dy0):
             T.dropout(dy0, dy0, self.dropout_rate, self._seed_now, site1, M=Md, D=dd)
-            T.axpby(dy0, dy0, alpha=math.sqrt(np.float32(dd)), beta=0.0, M=Md, D=dd)
+            T.axpby(dy0, dy0, alpha=math.sqrt(np.float32(dd)) * inv_keep, beta=0.0, M=Md, D=dd)
             T.colreduce(1, self.prenet2.db, g=dy0, a=p2, act='relu', dy_out=dy0, M=Md, C=dd)
             T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.precision)
             dp1 = self._empty(Md, self.prenet1.N)
-            ops.gemm(dy0, self.prenet2.lin.bwd, dp1, M=Md, precision=self.precision)
+            ops.gemm(dy0, self.prenet2.lin.bwd, dp1, M=Md, precision=self.precision, alpha=inv_keep)
             T.colreduce(1, self.prenet1.db, g=dp1, a=p1, act='relu', dy_out=dp1, M=Md, C=self.prenet1.N)
             T.wgrad(mels_in, dp1, self.prenet1.dk, M=Md, precision=self.precision)
             dmels = self._empty(Md, de)

@@ -110,7 +110,7 @@ def masked_mae(targets, pred):
     return per.sum() / per.numel()
 
 
-def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=None, dtype=torch.float64):
+def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=None, dtype=torch.float64, prenet_masks=None):
     """One forward + backward.  Returns dict(loss, mel_loss, dur_loss, mel, duration, grads {name: ndarray},
     new_stats {moving statistic name: ndarray}); weights are NOT updated (see adam_update)."""
     dt = dtype
@@ -138,8 +138,13 @@ def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=Non
         rows.append(F.pad(e, (0, 0, 0, T - e.shape[0])))
     mels = torch.stack(rows)
     emask = (mels.detach().abs().sum(-1) == 0).to(dt)[:, None, None, :]
+    # DecoderPrenet (layers.py:394-402): dropout after each relu, always on; prenet_masks = two scaled keep masks or None
     y = torch.relu(F.linear(mels, wt['decoder_prenet.d1.kernel'].t(), wt['decoder_prenet.d1.bias']))
+    if prenet_masks is not None:
+        y = y * torch.as_tensor(np.asarray(prenet_masks[0]), dtype=dt).reshape(y.shape)
     y = torch.relu(F.linear(y, wt['decoder_prenet.d2.kernel'].t(), wt['decoder_prenet.d2.bias']))
+    if prenet_masks is not None:
+        y = y * torch.as_tensor(np.asarray(prenet_masks[1]), dtype=dt).reshape(y.shape)
     y, dec_attn = _sa_blocks(y, emask, wt, 'decoder', cfg['decoder_model_dimension'], cfg['decoder_num_heads'],
                              cfg['decoder_dense_blocks'], cfg['decoder_max_position_encoding'], c)
     y = F.linear(y, wt['out.kernel'].t(), wt['out.bias'])
