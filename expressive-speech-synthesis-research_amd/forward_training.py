@@ -210,6 +210,7 @@ class ForwardTransformerTrainer:
         self.mel_channels = cfg['mel_channels']
         self.dropout_rate = float(cfg.get('dropout_rate', 0.1))
         self.decoder_prenet_dropout = 0.0
+        self._offsets = {}
         self.drop_n_heads = 0
         self.learning_rate = 1e-4
         self.loss_weights = [3., 1.]
@@ -266,6 +267,13 @@ class ForwardTransformerTrainer:
 
     def _empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def _first_offset(self, prefix):
+        """Lowest offset in the flat parameter / gradient buffer of the variables whose names start with `prefix`."""
+        o = self._offsets.get(prefix)
+        if o is None:
+            o = self._offsets[prefix] = min(off for name, (off, _) in self.store.table.items() if name.startswith(prefix))
+        return o
 
     def _next_site(self):
         self._site += 1
@@ -591,13 +599,21 @@ class ForwardTransformerTrainer:
         T.masked_mae_bwd(mel_t2, mel, dmel, self.loss_weights[0])
         ddur = self._empty(Me)
         T.masked_mae_bwd(td.view(Me, 1), dur.view(Me, 1), ddur.view(Me, 1), self.loss_weights[1])
+        # the gradient buffer is in forward order: every finished stage hands its tail to the all-reduce, which runs on
+        # the communication stream beside the rest of the backward pass
+        overlap = parallel.GradientOverlap(self.store.grad, self.bucket_elems, self.pg, self._comm)
         g = post_tape[0](dmel)
         d_dec = self._empty(Md, dd)
         self._lin_bwd(dec_out, self.out, g, Md, dx=d_dec)
+        overlap.ready(self._first_offset('out.'))
         g = d_dec
-        for bw in reversed(dec_tape):
+        for j, bw in enumerate(reversed(dec_tape)):
             g = bw(g)
+            idx = len(dec_tape) - 1 - j            # dec_tape = [attention 0, tail 0, attention 1, tail 1, ...]
+            if idx % 2 == 0:
+                overlap.ready(self._first_offset(f'decoder.block{idx // 2}.'))
         d_enc = prenet_backward(g)
+        overlap.ready(self._first_offset('decoder_prenet.'))
         # duration branch adds into d_enc
         dz1 = self._empty(Me, de)
         T.rownorm_bwd(fa1, ddot=ddur, dy=dz1, dx=d_enc, dx_accumulate=True, dln_a=D.norms[1].dpair, dln_b=D.norms[2].dpair,
@@ -607,10 +623,14 @@ class ForwardTransformerTrainer:
         dz0 = self._empty(Me, de)
         T.rownorm_bwd(fa0, dout=da0, dy=dz0, dln_a=D.norms[0].dpair)
         self._lin_bwd(enc_out, D.convs[0], dz0, Me, N, dx=d_enc, accumulate=True)
+        overlap.ready(self._first_offset('dur_pred.'))
         g = d_enc
-        for bw in reversed(tape):
+        for j, bw in enumerate(reversed(tape)):
             g = bw(g)
-
+            idx = len(tape) - 1 - j                # tape = [embedding, attention 0, tail 0, attention 1, tail 1, ...]
+            if idx >= 1 and (idx - 1) % 2 == 0:
+                overlap.ready(self._first_offset(f'encoder.block{(idx - 1) // 2}.'))
+        overlap.finish()
         self._apply_gradients()
         loss = losses[0] * self.loss_weights[0] + losses[1] * self.loss_weights[1]
         return {'mel': mel.view(B, Tm, mc), 'duration': dur.view(B, N, 1), 'expanded_mask': frame_mask.view(B, 1, 1, Tm),
@@ -619,9 +639,7 @@ class ForwardTransformerTrainer:
 
     def _apply_gradients(self):
         """Gradient exchange (sum over ranks, bucketed) and the Adam update (optimizer.apply_gradients, models.py:403)."""
-        st = self.store
-        if self.world > 1:
-            parallel.allreduce_buckets(st.grad, self.bucket_elems, self.pg, self._comm)
+        st = self.store                      # (gradients were summed over the ranks during the backward pass)
         self.iterations += 1
         t = self.iterations
         lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)

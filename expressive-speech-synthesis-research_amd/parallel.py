@@ -92,3 +92,51 @@ def allreduce_buckets(flat, bucket_elems, group=None, comm_stream=None):
         works = [dist.all_reduce(flat[a:b], group=group, async_op=True) for a, b in ranges]
         for w in works:
             w.wait()
+
+
+class GradientOverlap:
+    """Sums a flat gradient buffer over all ranks while the backward pass is still running.
+
+    The buffer is laid out in forward order, so the backward pass finishes it from the tail towards the head: after
+    every stage the caller reports the lowest offset that is final (`ready(lo)`), and the finished tail is all-reduced in
+    buckets on the communication stream (ordered behind the kernels issued so far) while the compute stream goes on with
+    the earlier layers.  `finish()` sends what is left and makes the current stream wait for every collective.
+    Tails smaller than `min_elems` are held back until more is ready (xGMI rings are per-link bound: few, large calls).
+    Every rank must report the same offsets in the same order.  No-op when not distributed."""
+
+    def __init__(self, flat, bucket_elems, group=None, comm_stream=None, min_elems=None):
+        self.flat, self.bucket, self.group, self.comm = flat, bucket_elems, group, comm_stream
+        self.min_elems = bucket_elems // 4 if min_elems is None else min_elems
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.hi = flat.numel()
+        self.works = []
+        self.calls = []          # (lo, hi) of every collective issued, for tests
+
+    def ready(self, lo):
+        lo = max(0, min(int(lo), self.hi))
+        if not self.active or lo >= self.hi or (lo > 0 and self.hi - lo < self.min_elems):
+            return
+        ranges = [(lo + a, lo + b) for a, b in bucket_ranges(self.hi - lo, self.bucket)]
+        if self.flat.is_cuda and self.comm is not None:
+            self.comm.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.comm):
+                self.works += [dist.all_reduce(self.flat[a:b], group=self.group, async_op=True) for a, b in ranges]
+        else:
+            self.works += [dist.all_reduce(self.flat[a:b], group=self.group, async_op=True) for a, b in ranges]
+        self.calls += ranges
+        self.hi = lo
+
+    def finish(self):
+        if not self.active:
+            return
+        self.min_elems = 0
+        self.ready(0)
+        if self.flat.is_cuda and self.comm is not None:
+            with torch.cuda.stream(self.comm):
+                for w in self.works:
+                    w.wait()
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm)
+        else:
+            for w in self.works:
+                w.wait()
+        self.works = []

@@ -33,6 +33,16 @@ def _worker(rank, world, port, q):
     g = torch.arange(1003, dtype=torch.float32) * (r + 1)
     par.allreduce_buckets(g, 250)
     ok = bool(torch.equal(g, torch.arange(1003, dtype=torch.float32) * 3))
+    # the same exchange overlapped with a backward pass: tails reported as they become final, every element summed once
+    g2 = torch.arange(1003, dtype=torch.float32) * (r + 1)
+    ov = par.GradientOverlap(g2, 250, min_elems=100)
+    for lo in (990, 900, 700, 650, 120):     # 990 and 650 are held back (fewer than 100 new elements)
+        ov.ready(lo)
+    ov.finish()
+    ok = ok and bool(torch.equal(g2, torch.arange(1003, dtype=torch.float32) * 3))
+    covered = sorted(ov.calls)
+    ok = ok and covered[0][0] == 0 and covered[-1][1] == 1003 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    ok = ok and all(b - a <= 250 for a, b in covered) and (990, 1003) not in covered
     if r == 0:
         q.put((t, got, ok))
     torch.distributed.destroy_process_group()
