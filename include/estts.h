@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 12
+#define ESTTS_ABI_VERSION 13
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -516,6 +516,28 @@ typedef struct estts_prog_op {
 } estts_prog_op;
 
 int estts_run_program(const estts_prog_op* ops, int32_t n_ops, int32_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Mel front-end (what turns a reference wav into the mel the style encoder / vocoder training read).
+ * Replaces librosa.stft + librosa.feature.melspectrogram + the normalisers at TransformerTTS/utils/audio.py:20-40,87-119,
+ * WaveRNN/utility/dsp.py:40-80 and gst_tacotron/util/audio.py:27-53,118-148.
+ *
+ * estts_gemm_f32:  C[m, n] = sum_k A[m, k] * W[n, k] in exact float32 on the matrix cores (row strides in floats; A rows may
+ *   overlap: frame m of a signal is A + m * hop, so lda = hop_length).  K % 16 == 0, lda / ldw % 4 == 0.  With W = the
+ *   window-weighted DFT matrix (rows [0, nb): w[k] cos(2 pi f k / n_fft); rows [nb, 2 nb): -w[k] sin(...)) this is the STFT;
+ *   with W = the mel filterbank it is linear_to_mel.
+ * estts_spec_magnitude:  mag[m, c] = hypot(x[m, c], x[m, nb + c])                                    c < nb
+ * estts_mel_normalize:   v = max(x, 1e-5);
+ *   mode 0: out = clip((20 log10 v - ref_level_db - min_level_db) / -min_level_db, 0, 1) * scale + shift
+ *           (vocoder mels: ref 0, min -100, scale 1, shift 0; the TTS "WaveRNN" normaliser: scale 8, shift -4;
+ *            gst_tacotron: ref 20)
+ *   mode 1: out = log v   (the "MelGAN" normaliser)
+ * ------------------------------------------------------------------------------------------ */
+int estts_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                   void* stream);
+int estts_spec_magnitude(const float* reim, int64_t ld, int32_t nb, float* mag, int64_t ldm, int32_t M, void* stream);
+int estts_mel_normalize(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t M, int32_t C, int32_t mode, float ref_level_db,
+                        float min_level_db, float scale, float shift, void* stream);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,7 @@ synthesize_sentences_speaker.py (model.predict, the (mel.T + 4) / 8 hand-off, Sy
 between the two models.
 
   python scripts/synthesize_sentences.py --config /path/to/config/wavernn --model forward --text "h@loU w3:ld" \
-      [--tts-weights ckpt-5.npz] [--vocoder-weights latest_weights.pyt] [--ref-mel ref.npy] --out out.npy
+      [--tts-weights ckpt-5.npz] [--vocoder-weights latest_weights.pyt] [--ref-mel ref.npy | --ref-wav ref.wav] --out out.npy
 
 Text must already be phonemes (the phonemizer is an external program).  Without weight files both models run on seeded
 random weights, which exercises the pipeline but produces noise.
@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--tts-weights')
     ap.add_argument('--vocoder-weights')
     ap.add_argument('--ref-mel', help='.npy reference mel (T, 80) for the style encoder (autoregressive model)')
+    ap.add_argument('--ref-wav', help='16-bit PCM mono .wav reference at the data config\'s sampling rate: its mel is computed on the GPU '
+                                      '(estts.audio.Audio, the reference\'s Audio.mel_spectrogram)')
     ap.add_argument('--out', default='out.npy')
     args = ap.parse_args()
     cm = ConfigManager(args.config, args.model)
@@ -41,6 +43,14 @@ def main():
         out = model.predict(args.text)
     else:
         ref = np.load(args.ref_mel) if args.ref_mel else None
+        if args.ref_wav:
+            import wave
+            from estts.audio import Audio
+            with wave.open(args.ref_wav, 'rb') as f:
+                if f.getsampwidth() != 2 or f.getnchannels() != 1 or f.getframerate() != cm.config['sampling_rate']:
+                    raise SystemExit(f'--ref-wav must be 16-bit mono at {cm.config["sampling_rate"]} Hz')
+                pcm = np.frombuffer(f.readframes(f.getnframes()), dtype='<i2').astype(np.float32) / 32768.0
+            ref = Audio(cm.config).mel_spectrogram(pcm).t().contiguous()           # (T, 80), stays on the device
         out = model.predict(args.text, ref, None, verbose=False)
     mel = out['mel']
     hp = configs.wavernn_hparams()
