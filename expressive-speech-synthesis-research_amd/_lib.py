@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -81,6 +81,11 @@ class ProgOp(C.Structure):
                 ('patch_is_ptr', _i32 * PROG_MAX_PATCH), ('patch_stride', _i64 * PROG_MAX_PATCH)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [('src', _vp), ('hi', _vp), ('lo', _vp), ('first_unit', _i64), ('ld_src', _i32), ('K', _i32), ('N', _i32),
+                ('taps', _i32), ('mode', _i32), ('pad_', _i32)]
+
+
 class ColreduceArgs(C.Structure):
     _fields_ = [('z', _vp), ('ldz', _i32), ('g', _vp), ('ldg', _i32), ('a', _vp), ('lda', _i32), ('act', _i32),
                 ('mean', _vp), ('rstd', _vp), ('out0', _vp), ('out1', _vp), ('dy_out', _vp), ('lddy', _i32),
@@ -139,6 +144,7 @@ SIGNATURES = {
     'estts_gemm_f32': (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     'estts_spec_magnitude': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     'estts_mel_normalize': (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
+    'estts_pack_weights': (_i32, [_vp, _i32, _i64, _vp]),
     'estts_run_program': (_i32, [C.POINTER(ProgOp), _i32, _i32, _vp]),
     'estts_mol_loss': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
 }

@@ -8,37 +8,57 @@ namespace {
 
 // ------------------------------------------------------------------------------------------
 // master float32 [K][ld] -> bf16 hi/lo fragment-major.  One thread per (16-row block, 32-column step, lane): 8 values.
+__device__ __forceinline__ void pack_unit(const float* src, int ld, int K, int N, int taps, int mode, uint16_t* hi, uint16_t* lo,
+                                          int rows, int cols, int KS, long idx) {
+    const int cin = K / taps;
+    const int l = (int)(idx & 63);
+    const long blk = idx >> 6;
+    const int ks = (int)(blk % KS);
+    const int nb = (int)(blk / KS);
+    const int r = nb * 16 + (l & 15);          // destination row
+    const int c0 = ks * 32 + (l >> 4) * 8;     // first destination column
+    bf16x8 h, lw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        float v = 0.0f;
+        if (r < rows && c < cols) {
+            if (mode == 0) {
+                v = src[(long)c * ld + r];
+            } else {
+                const int tp = c / N;
+                const int n = c - tp * N;
+                v = src[(long)((taps - 1 - tp) * cin + r) * ld + n];
+            }
+        }
+        __bf16 a, b;
+        split_bf16(v, a, b);
+        h[j] = a;
+        lw[j] = b;
+    }
+    *reinterpret_cast<bf16x8*>(hi + idx * 8) = h;
+    *reinterpret_cast<bf16x8*>(lo + idx * 8) = lw;
+}
+
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, int ld, int K, int N, int taps, int mode,
                                                           uint16_t* hi, uint16_t* lo, int rows, int cols, int KS, long total) {
-    const int cin = K / taps;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int l = (int)(idx & 63);
-        const long blk = idx >> 6;
-        const int ks = (int)(blk % KS);
-        const int nb = (int)(blk / KS);
-        const int r = nb * 16 + (l & 15);          // destination row
-        const int c0 = ks * 32 + (l >> 4) * 8;     // first destination column
-        bf16x8 h, lw;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j;
-            float v = 0.0f;
-            if (r < rows && c < cols) {
-                if (mode == 0) {
-                    v = src[(long)c * ld + r];
-                } else {
-                    const int tp = c / N;
-                    const int n = c - tp * N;
-                    v = src[(long)((taps - 1 - tp) * cin + r) * ld + n];
-                }
-            }
-            __bf16 a, b;
-            split_bf16(v, a, b);
-            h[j] = a;
-            lw[j] = b;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256)
+        pack_unit(src, ld, K, N, taps, mode, hi, lo, rows, cols, KS, idx);
+}
+
+// every weight of a model in one launch: unit u belongs to the job with first_unit <= u < next job's first_unit
+__global__ __launch_bounds__(256) void pack_weights_kernel(const estts_pack_job* jobs, int n_jobs, long total) {
+    for (long u = (long)blockIdx.x * 256 + threadIdx.x; u < total; u += (long)gridDim.x * 256) {
+        int lo = 0, hi = n_jobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first_unit <= u) lo = mid; else hi = mid - 1;
         }
-        *reinterpret_cast<bf16x8*>(hi + idx * 8) = h;
-        *reinterpret_cast<bf16x8*>(lo + idx * 8) = lw;
+        const estts_pack_job j = jobs[lo];
+        const int rows = j.mode == 0 ? j.N : j.K / j.taps;
+        const int cols = j.mode == 0 ? j.K : j.taps * j.N;
+        const int cp = (cols + 63) / 64 * 64;
+        pack_unit(j.src, j.ld_src, j.K, j.N, j.taps, j.mode, j.hi, j.lo, rows, cols, cp / 32, u - j.first_unit);
     }
 }
 
@@ -566,6 +586,13 @@ extern "C" int estts_pack_weight(const float* src, int32_t ld_src, int32_t K, in
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, ld_src, K, N, taps,
                        mode, hi, lo, rows, cols, cp / 32, total);
     ESTTS_CHECK_LAUNCH("estts_pack_weight");
+    return 0;
+}
+
+extern "C" int estts_pack_weights(const estts_pack_job* jobs, int32_t n_jobs, int64_t total_units, void* stream) {
+    ESTTS_CHECK_ARG(jobs && n_jobs > 0 && total_units > 0, "estts_pack_weights: bad arguments");
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total_units)), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs, (long)total_units);
+    ESTTS_CHECK_LAUNCH("estts_pack_weights");
     return 0;
 }
 

@@ -211,6 +211,7 @@ class ForwardTransformerTrainer:
         self.dropout_rate = float(cfg.get('dropout_rate', 0.1))
         self.decoder_prenet_dropout = 0.0
         self._offsets = {}
+        self._pack_plan = None
         self.drop_n_heads = 0
         self.learning_rate = 1e-4
         self.loss_weights = [3., 1.]
@@ -644,8 +645,9 @@ class ForwardTransformerTrainer:
         t = self.iterations
         lr_t = self.learning_rate * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
         T.adam(st.flat, st.grad, st.m, st.v, lr_t, self.beta1, self.beta2, self.eps, 1.0 / self.world)
-        for lin in self._linears:
-            lin.repack()
+        if self._pack_plan is None:
+            self._pack_plan = T.PackPlan(self._linears, self.device)
+        self._pack_plan.run()
 
     def val_step(self, input_sequence, target_sequence, target_durations):
         """models.py:413-425: forward with training=False (moving statistics, no dropout) and the same losses."""

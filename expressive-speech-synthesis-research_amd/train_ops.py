@@ -52,6 +52,33 @@ class TrainLinear:
                                             pk.w_lo.data_ptr(), _stream()), 'estts_pack_weight')
 
 
+class PackPlan:
+    """Re-packs every operand of a list of TrainLinear layers with one launch (estts_pack_weights): the job table is
+    built once and lives on the device; the master weights and the packed buffers must not be re-allocated afterwards."""
+
+    def __init__(self, linears, device):
+        import ctypes
+        jobs, unit = [], 0
+        for lin in linears:
+            for mode, pk in ((0, lin.fwd), (1, lin.bwd)):
+                if pk is None:
+                    continue
+                rows = lin.N if mode == 0 else lin.K // lin.taps
+                cols = lin.K if mode == 0 else lin.taps * lin.N
+                j = _lib.PackJob(lin.kernel.data_ptr(), pk.w_hi.data_ptr(), pk.w_lo.data_ptr(), unit, lin.kernel.stride(0), lin.K,
+                                 lin.N, lin.taps, mode, 0)
+                jobs.append(j)
+                unit += (_ceil(rows, 64) // 16) * (_ceil(cols, 64) // 32) * 64
+        self.n, self.total = len(jobs), unit
+        arr = (_lib.PackJob * self.n)(*jobs)
+        host = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(arr), ctypes.sizeof(arr))), dtype=torch.uint8)
+        self.table = host.to(device)
+        self._keep = linears
+
+    def run(self):
+        check(_lib.load().estts_pack_weights(self.table.data_ptr(), self.n, self.total, _stream()), 'estts_pack_weights')
+
+
 def wgrad(x, dy, dw, taps=1, lpad=0, M=None, seg_len=0, precision='bf16x3', splits=0, db=None):
     """dw[K, N] += conv-unfolded(x)^T dy (float atomics; dw must be zero or hold a partial sum); db[N] += column sums
     of dy (the bias gradient) when given."""

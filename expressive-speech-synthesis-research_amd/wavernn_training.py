@@ -466,11 +466,9 @@ class WaveRNNTrainer:
 
     def _gru_param_grads(self, ws, x_in, H, ih, hh):
         M, T = ws['M'], ws['T']
-        T_.wgrad(x_in, ws['dgi'], ih.dk, M=M, precision=self.precision)
-        T_.colreduce(1, ih.db, g=ws['dgi'], M=M, C=3 * self.rnn_dims)
+        T_.wgrad(x_in, ws['dgi'], ih.dk, M=M, precision=self.precision, db=ih.db)
         # h_{t-1} is H shifted by one step inside each window: a one-tap "convolution" with one row of left padding
-        T_.wgrad(H, ws['dgh'], hh.dk, taps=1, lpad=1, M=M, seg_len=T, precision=self.precision)
-        T_.colreduce(1, hh.db, g=ws['dgh'], M=M, C=3 * self.rnn_dims)
+        T_.wgrad(H, ws['dgh'], hh.dk, taps=1, lpad=1, M=M, seg_len=T, precision=self.precision, db=hh.db)
 
     def _apply_gradients(self):
         st = self.store
@@ -482,7 +480,8 @@ class WaveRNNTrainer:
         # torch: p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)  ==  lr_t * m / (sqrt(v) + eps * sqrt(1 - b2^t))
         T_.adam(st.flat, st.grad, st.m, st.v, self.lr * bc2 / (1.0 - self.beta1 ** t), self.beta1, self.beta2, self.eps * bc2,
                 1.0 / self.world)
-        for lin in self._linears:
-            lin.repack()
+        if getattr(self, '_pack_plan', None) is None:
+            self._pack_plan = T_.PackPlan(self._linears, self.device)
+        self._pack_plan.run()
         self._refresh_fir()
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 13
+#define ESTTS_ABI_VERSION 14
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -297,6 +297,20 @@ int estts_wavernn_sample(const estts_wavernn_sample_args* args, void* stream);
  * ceil64(rows) * ceil64(cols) uint16). */
 int estts_pack_weight(const float* src, int32_t ld_src, int32_t K, int32_t N, int32_t taps, int32_t mode,
                       uint16_t* hi, uint16_t* lo, void* stream);
+
+/* The same for many weights in one launch (after an optimizer step every operand of the model is re-packed).
+ * `jobs` is a DEVICE array sorted by first_unit; a unit is 8 consecutive destination values, job j owns units
+ * [first_unit, first_unit + ceil64(rows) / 16 * ceil64(cols) / 32 * 64) with rows / cols as in estts_pack_weight, and
+ * total_units is the end of the last job.  Nothing is validated on the device: the caller builds the table once. */
+typedef struct estts_pack_job {
+    const float* src;
+    uint16_t* hi;
+    uint16_t* lo;
+    int64_t first_unit;
+    int32_t ld_src, K, N, taps, mode, pad_;
+} estts_pack_job;
+
+int estts_pack_weights(const estts_pack_job* jobs, int32_t n_jobs, int64_t total_units, void* stream);
 
 /* Weight gradient of a dense / 1-D conv layer on the matrix cores:
  *   dW[tap * c_per_tap + c, n] += sum_m A[row(m) + tap - tap_lpad, c] * dY[m, n]

@@ -45,7 +45,7 @@ def test_struct_sizes_match_header_layout(tmp_path):
              'estts_wavernn_sample_args': _lib.WavernnSampleArgs, 'estts_wgrad_args': _lib.WgradArgs,
              'estts_attention_bwd_args': _lib.AttentionBwdArgs, 'estts_rownorm_bwd_args': _lib.RownormBwdArgs,
              'estts_colreduce_args': _lib.ColreduceArgs, 'estts_wavernn_prep_bwd_args': _lib.WavernnPrepBwdArgs, 'estts_rowmask_args': _lib.RowmaskArgs,
-             'estts_prog_op': _lib.ProgOp}
+             'estts_prog_op': _lib.ProgOp, 'estts_pack_job': _lib.PackJob}
     src = tmp_path / 'sizes.c'
     src.write_text('#include <stdio.h>\n#include "estts.h"\nint main(void) {\n' +
                    ''.join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + '  return 0;\n}\n')
