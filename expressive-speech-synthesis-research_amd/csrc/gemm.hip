@@ -87,7 +87,14 @@ struct SmallStage {
     uint4 w[NS][2];
 };
 
-template <int NSPLIT, int NW>
+// KIND selects the A-operand addressing.  The K loop of these kernels is bound by vector instructions at small sizes
+// (address arithmetic + operand split), so the common layer shapes get short forms of their own:
+//   1 (dense layer: one tap, output row m reads input row m): the address is a per-row base pointer plus the K index and
+//     only K itself is bounds-checked;
+//   2 (1-D convolution over rows of seg_len pixels): base pointer + (tap - lpad) rows + channel, valid while the shifted
+//     position stays inside the row's own sequence; (tap, channel) is carried by a cursor, not divided out per step;
+//   0: the general 2-D geometry (a_operand.h).
+template <int NSPLIT, int NW, int KIND>
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_args p, const int splitk) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
     constexpr int STAGE_BYTES = NW * SM_WAVE_ELEMS * 2;
@@ -108,8 +115,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     const int KS = p.ldw >> 5;  // K-steps per packed row block
 
     ARow a_row[4];
+    const float* a_ptr[4];   // KIND 1 / 2: start of the row (rows past M re-read the last one; their results are never stored)
+    int a_pos[4];            // KIND 2: position of the row inside its sequence
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a_row[j] = make_arow(p, m0 + r8 + 8 * j);
+    for (int j = 0; j < 4; ++j) {
+        const int row = min(m0 + r8 + 8 * j, p.M - 1);
+        if (KIND == 1) a_ptr[j] = p.A + (long)row * p.lda + c8 * 4;
+        else if (KIND == 2) { a_ptr[j] = p.A + (long)row * p.lda; a_pos[j] = row % p.conv_w; }
+        else a_row[j] = make_arow(p, m0 + r8 + 8 * j);
+    }
     const uint16_t* whp[2];
     const uint16_t* wlp[2];
 #pragma unroll
@@ -125,9 +139,30 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     int ks = tc.tz * per + wave;
 
     auto load = [&](int k, SmallStage<NS>& st) {
-        const ATap tp = make_atap(p, k * 32 + c8 * 4);
+        if (KIND == 1) {
+            const bool ok = k * 32 + c8 * 4 < p.K;     // K % 4 == 0: a float4 is inside or outside as a whole
 #pragma unroll
-        for (int j = 0; j < 4; ++j) st.a[j] = load_a_raw(p, a_row[j], tp, st.ok[j]);
+            for (int j = 0; j < 4; ++j) {
+                st.a[j] = *reinterpret_cast<const float4*>(a_ptr[j] + (ok ? k * 32 : -c8 * 4));
+                st.ok[j] = ok;
+            }
+        } else if (KIND == 2) {
+            const int kk = k * 32 + c8 * 4;
+            const int tap = kk / p.c_per_tap;          // (the waves take interleaved K-steps: no cursor here)
+            const int dw = tap - p.conv_pl;
+            const long off = (long)dw * p.lda + (kk - tap * p.c_per_tap);
+            const bool kok = kk < p.K;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = kok && (unsigned)(a_pos[j] + dw) < (unsigned)p.conv_w;
+                st.a[j] = *reinterpret_cast<const float4*>(a_ptr[j] + (ok ? off : 0L));
+                st.ok[j] = ok;
+            }
+        } else {
+            const ATap tp = make_atap(p, k * 32 + c8 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st.a[j] = load_a_raw(p, a_row[j], tp, st.ok[j]);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             st.w[0][i] = *reinterpret_cast<const uint4*>(whp[i] + (long)k * 512);
@@ -189,16 +224,23 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], wf[0][j], acc[i][j], 0, 0, 0);
     };
 
-    SmallStage<NS> sa, sb;
+    // three register stages: the loads of the wave's next two K-steps are in flight while one is multiplied (a K-step costs
+    // a full L2 round trip otherwise: measured ~0.9 us per step and wave at batch 1)
+    SmallStage<NS> sa, sb, sc;
     if (ks < ks_end) {
         load(ks, sa);
+        if (ks + NW < ks_end) load(ks + NW, sb);
         while (true) {
-            if (ks + NW < ks_end) load(ks + NW, sb);
+            if (ks + 2 * NW < ks_end) load(ks + 2 * NW, sc);
             compute(sa);
             ks += NW;
             if (ks >= ks_end) break;
-            if (ks + NW < ks_end) load(ks + NW, sa);
+            if (ks + 2 * NW < ks_end) load(ks + 2 * NW, sa);
             compute(sb);
+            ks += NW;
+            if (ks >= ks_end) break;
+            if (ks + 2 * NW < ks_end) load(ks + 2 * NW, sb);
+            compute(sc);
             ks += NW;
             if (ks >= ks_end) break;
         }
@@ -446,7 +488,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // TM x TN = 32 x 32 MFMA tiles per wave: the workgroup tile is (64 TM) x (64 TN).  2 x 2 is the kernel described above;
 // 1 x 1, 2 x 1 and 1 x 2 keep its main loop for launches whose 128 x 128 tiles would leave most CUs idle.
-template <int NSPLIT, int TM, int TN, int OCC, int PF>
+template <int NSPLIT, int TM, int TN, int OCC, int KIND>
 __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_args p) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -468,21 +510,47 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
     const int a_ch = tid & 7;    // float4 chunk of the 32-wide K slice
     const int a_r0 = tid >> 3;   // rows a_r0 + 32 i
     ARow a_row[AI];
+    const float* a_ptr[AI];   // KIND 1 / 2: start of the row (rows past M re-read the last one; their results are never stored)
+    int a_pos[AI];            // KIND 2: position of the row inside its sequence
 #pragma unroll
-    for (int i = 0; i < AI; ++i) a_row[i] = make_arow(p, m0 + a_r0 + 32 * i);
+    for (int i = 0; i < AI; ++i) {
+        const int row = min(m0 + a_r0 + 32 * i, p.M - 1);
+        if (KIND == 1) a_ptr[i] = p.A + (long)row * p.lda + a_ch * 4;
+        else if (KIND == 2) { a_ptr[i] = p.A + (long)row * p.lda; a_pos[i] = row % p.conv_w; }
+        else a_row[i] = make_arow(p, m0 + a_r0 + 32 * i);
+    }
 
-    // PF register sets: the loads of K-step kt + PF are issued while step kt is being multiplied
+    // one register set: the loads of K-step kt + 1 are issued while step kt is being multiplied
     float4 a_reg[AI];
     bool a_ok[AI];
     static_assert(TN == 1 || TN == 2, "one or two 16-byte W units per thread");
     uint4 wh0, wh1, wl0, wl1;
-    static_assert(PF == 1, "one register set");
     KCursor kcur = make_kcursor(p, a_ch * 4);   // load_tiles is called for kt = 0, 1, 2, ... in order
     auto load_tiles = [&](int kt) {
-        const ATap tp = atap_from(p, kcur.kk, kcur.tap, kcur.c);
-        advance(p, kcur, 32);
+        if (KIND == 1) {
+            const bool ok = kt * 32 + a_ch * 4 < p.K;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) a_reg[i] = load_a_raw(p, a_row[i], tp, a_ok[i]);
+            for (int i = 0; i < AI; ++i) {
+                a_reg[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? kt * 32 : -a_ch * 4));
+                a_ok[i] = ok;
+            }
+        } else if (KIND == 2) {
+            const int dw = kcur.tap - p.conv_pl;
+            const long off = (long)dw * p.lda + kcur.c;
+            const bool kok = kcur.kk < p.K;
+            advance(p, kcur, 32);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const bool ok = kok && (unsigned)(a_pos[i] + dw) < (unsigned)p.conv_w;
+                a_reg[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? off : 0L));
+                a_ok[i] = ok;
+            }
+        } else {
+            const ATap tp = atap_from(p, kcur.kk, kcur.tap, kcur.c);
+            advance(p, kcur, 32);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) a_reg[i] = load_a_raw(p, a_row[i], tp, a_ok[i]);
+        }
         // (named registers, not an array: with an array of two the compiler keeps the fragments in scratch memory)
         auto w_off = [&](int i) {
             // W holds ceil(N / 64) * 64 rows, so the last tile may reach past it: read the last block again instead
@@ -608,12 +676,21 @@ bool splitk_fits(const estts_gemm_args& a, dim3 grid, long tile_elems) {
     return true;
 }
 
-template <int NW>
+// 1: dense layer, 2: 1-D convolution (the geometry estts_gemm fills in for both: rows of conv_w pixels, one kernel row,
+// no stride), 0: anything else
+int operand_kind(const estts_gemm_args& a) {
+    const bool one_d = a.conv_h == 1 && a.conv_stride == 1 && a.conv_pt == 0 && a.conv_kw == a.taps && a.conv_wo == a.conv_w &&
+                       a.conv_howo == a.conv_w;
+    if (!one_d) return 0;
+    return (a.taps == 1 && a.conv_pl == 0) ? 1 : 2;
+}
+
+template <int NW, int KIND>
 int launch_small_nw(const estts_gemm_args& a, dim3 grid, hipStream_t st) {
     if (a.precision == 3)
-        hipLaunchKernelGGL((gemm_small_kernel<3, NW>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
+        hipLaunchKernelGGL((gemm_small_kernel<3, NW, KIND>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
     else
-        hipLaunchKernelGGL((gemm_small_kernel<1, NW>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
+        hipLaunchKernelGGL((gemm_small_kernel<1, NW, KIND>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
     ESTTS_CHECK_LAUNCH("estts_gemm");
     return 0;
 }
@@ -629,10 +706,11 @@ int launch_small(const estts_gemm_args& a, int splitk, int nw, hipStream_t st) {
         const long wgs = (long)grid.x * grid.y * grid.z;
         nw = (nks >= 12 && wgs < 256) ? 8 : 4;
     }
+    const int kind = operand_kind(a);
     switch (nw) {
-        case 4: return launch_small_nw<4>(a, grid, st);
-        case 8: return launch_small_nw<8>(a, grid, st);
-        case 16: return launch_small_nw<16>(a, grid, st);
+        case 4: return kind == 1 ? launch_small_nw<4, 1>(a, grid, st) : kind == 2 ? launch_small_nw<4, 2>(a, grid, st) : launch_small_nw<4, 0>(a, grid, st);
+        case 8: return kind == 1 ? launch_small_nw<8, 1>(a, grid, st) : kind == 2 ? launch_small_nw<8, 2>(a, grid, st) : launch_small_nw<8, 0>(a, grid, st);
+        case 16: return launch_small_nw<16, 0>(a, grid, st);
         default: estts_set_error("estts_gemm: waves per workgroup must be 4, 8 or 16"); return -1;
     }
 }
@@ -649,15 +727,21 @@ int launch(const estts_gemm_args& a, int splitk, hipStream_t st) {
     return 0;
 }
 
-template <int TM, int TN, int OCC, int PF>
-int launch_big(const estts_gemm_args& a, hipStream_t st) {
+template <int TM, int TN, int OCC, int KIND>
+int launch_big_d(const estts_gemm_args& a, hipStream_t st) {
     dim3 grid((a.N + 64 * TN - 1) / (64 * TN), (a.M + 64 * TM - 1) / (64 * TM), 1);
     if (a.precision == 3)
-        hipLaunchKernelGGL((gemm_big_kernel<3, TM, TN, OCC, PF>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_big_kernel<3, TM, TN, OCC, KIND>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((gemm_big_kernel<1, TM, TN, OCC, PF>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemm_big_kernel<1, TM, TN, OCC, KIND>), grid, dim3(256), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_gemm");
     return 0;
+}
+
+template <int TM, int TN, int OCC>
+int launch_big(const estts_gemm_args& a, hipStream_t st) {
+    const int kind = operand_kind(a);
+    return kind == 1 ? launch_big_d<TM, TN, OCC, 1>(a, st) : kind == 2 ? launch_big_d<TM, TN, OCC, 2>(a, st) : launch_big_d<TM, TN, OCC, 0>(a, st);
 }
 
 }  // namespace
@@ -715,10 +799,10 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         case 2: tiles = (long)((a.M + 31) / 32) * ((a.N + 63) / 64); nk = (a.K + BK - 1) / BK; break;
         case 3: tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32); nk = (a.K + BK - 1) / BK; break;
         case 4: tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32); nk = (a.K + 31) / 32 / 8; break;
-        case 5: return launch_big<2, 2, 2, 1>(a, st);
-        case 6: return launch_big<1, 1, 4, 1>(a, st);
-        case 7: return launch_big<2, 1, 2, 1>(a, st);
-        case 8: return launch_big<1, 2, 3, 1>(a, st);
+        case 5: return launch_big<2, 2, 2>(a, st);
+        case 6: return launch_big<1, 1, 4>(a, st);
+        case 7: return launch_big<2, 1, 2>(a, st);
+        case 8: return launch_big<1, 2, 3>(a, st);
 
         default: estts_set_error("estts_gemm: unknown tile id %d", tile); return -1;
     }
