@@ -138,15 +138,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const estts_attentio
     auto stage_tile = [&](const float4 (&x)[NLD]) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const float v[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
             bf16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 hh, ll;
-                split_bf16(v[e], hh, ll);
-                hi[e] = hh;
-                lo[e] = ll;
-            }
+            split_bf16x4(x[j], hi, lo);
             const int o = (j * RPI + ld_row) * LD + ld_col;
             *reinterpret_cast<bf16x4*>(stage + o) = hi;
             if (NS == 2) *reinterpret_cast<bf16x4*>(stage + IMG + o) = lo;

@@ -57,6 +57,18 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
     lo = (__bf16)(x - (float)hi);
 }
 
+// the same for four values at once, with the conversions issued in pairs (one v_cvt_pk_bf16_f32 per two values)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ void split_bf16x4(float4 x, bf16x4& hi, bf16x4& lo) {
+    const f32x2_t a = {x.x, x.y}, b = {x.z, x.w};
+    const bf16x2_t ha = __builtin_convertvector(a, bf16x2_t), hb = __builtin_convertvector(b, bf16x2_t);
+    const f32x2_t ra = a - __builtin_convertvector(ha, f32x2_t), rb = b - __builtin_convertvector(hb, f32x2_t);
+    const bf16x2_t la = __builtin_convertvector(ra, bf16x2_t), lb = __builtin_convertvector(rb, bf16x2_t);
+    hi = (bf16x4){ha[0], ha[1], hb[0], hb[1]};
+    lo = (bf16x4){la[0], la[1], lb[0], lb[1]};
+}
+
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;

@@ -181,16 +181,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     auto compute = [&](const SmallStage<NS>& st) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 az = zero_unless(st.ok[j], st.a[j]);
-            const float v[4] = {az.x, az.y, az.z, az.w};
+            // KIND 1 needs no zeroing: a K index past the end re-reads valid data of the row, and W is zero-padded there
+            const float4 az = KIND == 1 ? st.a[j] : zero_unless(st.ok[j], st.a[j]);
             bf16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 h, l;
-                split_bf16(v[e], h, l);
-                hi[e] = h;
-                lo[e] = l;
-            }
+            split_bf16x4(az, hi, lo);
             const int o = (r8 + 8 * j) * SM_LD + c8 * 4;
             *reinterpret_cast<bf16x4*>(stage + o) = hi;
             if (NS == 2) *reinterpret_cast<bf16x4*>(stage + 32 * SM_LD + o) = lo;
@@ -572,16 +566,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int o = (a_r0 + 32 * i) * BG_LD + a_ch * 4;
-            const float4 az = zero_unless(a_ok[i], a_reg[i]);
-            const float v[4] = {az.x, az.y, az.z, az.w};
+            // KIND 1 needs no zeroing: a K index past the end re-reads valid data of the row, and W is zero-padded there
+            const float4 az = KIND == 1 ? a_reg[i] : zero_unless(a_ok[i], a_reg[i]);
             bf16x4 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __bf16 hh, ll;
-                split_bf16(v[j], hh, ll);
-                hi[j] = hh;
-                lo[j] = ll;
-            }
+            split_bf16x4(az, hi, lo);
             *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = hi;
             if (NS == 2) *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = lo;
         }

@@ -92,19 +92,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
             const float4 az = zero_unless(a_ok[i], a_reg[i]);
             const float4 yz = zero_unless(y_ok[i], y_reg[i]);
             bsum.x += yz.x; bsum.y += yz.y; bsum.z += yz.z; bsum.w += yz.w;
-            const float av[4] = {az.x, az.y, az.z, az.w};
-            const float yv[4] = {yz.x, yz.y, yz.z, yz.w};
             bf16x4 ah, al, yh, yl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                __bf16 h, l;
-                split_bf16(av[e], h, l);
-                ah[e] = h;
-                al[e] = l;
-                split_bf16(yv[e], h, l);
-                yh[e] = h;
-                yl[e] = l;
-            }
+            split_bf16x4(az, ah, al);
+            split_bf16x4(yz, yh, yl);
             *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = ah;
             *reinterpret_cast<bf16x4*>(&Ys[buf][0][o]) = yh;
             if (NS == 2) {
