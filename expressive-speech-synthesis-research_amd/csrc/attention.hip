@@ -122,6 +122,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
 
     // scores of the staged K tile for this lane's query: s[sub][j] <-> key kt*32 + sub*16 + 4g + j
     auto scores = [&](int kt, float (&s)[2][4]) {
+        // key-mask values of this lane's eight keys, loaded up front and without conditions (a load under a per-element
+        // condition becomes a branch with its own wait: eight serialised round trips per tile)
+        float mk[2][4];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mk[sub][j] = mask ? mask[min(kt * 32 + sub * 16 + 4 * g + j, p.Lk - 1)] : 0.0f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -136,15 +143,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int key = kt * 32 + sub * 16 + 4 * g + j;
-                float v = acc[j] * scale;
-                if (key >= p.Lk) {
-                    v = -INFINITY;
-                } else {
-                    float mk = mask ? mask[key] : 0.0f;
-                    if (p.causal && key > qi) mk = 1.0f;
-                    v += mk * -1e9f;
-                }
-                s[sub][j] = v;
+                const float m = (p.causal && key > qi) ? 1.0f : mk[sub][j];
+                const float v = acc[j] * scale + m * -1e9f;
+                s[sub][j] = key >= p.Lk ? -INFINITY : v;
             }
         }
     };
@@ -383,6 +384,9 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
     };
     // scores of a staged K tile for this lane's query: s[sub * 4 + j] <-> key kt*32 + sub*16 + 4g + j
     auto scores = [&](int kt, const __bf16* kimg, float (&s)[8]) {
+        float mk[8];     // loaded up front and without conditions: see the kernel above
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mk[e] = mask ? mask[min(kt * 32 + (e >> 2) * 16 + 4 * g + (e & 3), p.Lk - 1)] : 0.0f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -397,15 +401,9 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int key = kt * 32 + sub * 16 + 4 * g + j;
-                float v = acc[j] * scale;
-                if (key >= p.Lk) {
-                    v = -INFINITY;
-                } else {
-                    float mk = mask ? mask[key] : 0.0f;
-                    if (p.causal && key > qi) mk = 1.0f;
-                    v += mk * -1e9f;
-                }
-                s[sub * 4 + j] = v;
+                const float m = (p.causal && key > qi) ? 1.0f : mk[sub * 4 + j];
+                const float v = acc[j] * scale + m * -1e9f;
+                s[sub * 4 + j] = key >= p.Lk ? -INFINITY : v;
             }
         }
     };
@@ -548,7 +546,9 @@ template <int DH>
 int launch(const estts_attention_args& a, hipStream_t st) {
     // variant: 0 = by launch size, 1 = 16-query workgroups, 2 = 64-query workgroups
     const long wide_wgs = (long)((a.Lq + 63) / 64) * a.H * a.B;
-    if (a.variant == 2 || (a.variant == 0 && wide_wgs >= 512 && a.Lk >= 64)) return launch_wide<DH>(a, st);
+    // (at depth 128 the 16-query kernel needs more than 256 registers, one workgroup per CU: the shared-tile kernel wins earlier)
+    const long wide_min = DH >= 128 ? 192 : 512;
+    if (a.variant == 2 || (a.variant == 0 && wide_wgs >= wide_min && a.Lk >= 64)) return launch_wide<DH>(a, st);
     const int per_wave = ((a.Lk + 31) / 32 + 3) / 4;   // key tiles each wave sweeps
     if (a.attn && per_wave <= 2) return launch_t<DH, 2>(a, st);
     if (a.attn && per_wave <= 5) return launch_t<DH, 5>(a, st);
