@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -26,7 +26,9 @@ class GemmArgs(C.Structure):
                 ('ws', _vp), ('ws_bytes', C.c_int64), ('counters', _vp), ('n_counters', _i32), ('tune', _i32),
                 ('conv_h', _i32), ('conv_w', _i32), ('conv_wo', _i32), ('conv_howo', _i32), ('conv_kw', _i32),
                 ('conv_stride', _i32), ('conv_pt', _i32), ('conv_pl', _i32),
-                ('drop_rate', _f32), ('drop_seed', _u32), ('drop_site', _u32), ('drop_row0', _i32)]
+                ('drop_rate', _f32), ('drop_seed', _u32), ('drop_site', _u32), ('drop_row0', _i32),
+                ('batch', _i32), ('batch_stride_a', _i64), ('batch_stride_w', _i64), ('batch_stride_c', _i64),
+                ('batch_stride_v', _i64)]
 
 
 class AttentionArgs(C.Structure):

@@ -483,7 +483,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // TM x TN = 32 x 32 MFMA tiles per wave: the workgroup tile is (64 TM) x (64 TN).  2 x 2 is the kernel described above;
 // 1 x 1, 2 x 1 and 1 x 2 keep its main loop for launches whose 128 x 128 tiles would leave most CUs idle.
 template <int NSPLIT, int TM, int TN, int OCC, int KIND>
-__global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_args p) {
+__global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_args p_in) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int AI = 2 * TM;   // float4 loads of A per thread and K-step
@@ -495,7 +495,19 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)));
+    const TileCoord tc = xcd_tile_coord((p_in.tune & (1 << 25)) ? false : gemm_y_first(p_in), !(p_in.tune & (1 << 24)));
+    estts_gemm_args p = p_in;
+    if (p.batch > 1) {   // gridDim.z = batch: product tc.tz of the launch
+        const long z = tc.tz;
+        p.A += z * p.batch_stride_a;
+        p.W_hi += z * p.batch_stride_w;
+        if (p.W_lo) p.W_lo += z * p.batch_stride_w;
+        p.C += z * p.batch_stride_c;
+        if (p.R) p.R += z * p.batch_stride_c;
+        if (p.s1) p.s1 += z * p.batch_stride_v;
+        if (p.b1) p.b1 += z * p.batch_stride_v;
+        if (p.s2) { p.s2 += z * p.batch_stride_v; p.b2 += z * p.batch_stride_v; }
+    }
     const int m0 = tc.ty * BM;
     const int n0 = tc.tx * BN;
     const int KS = p.ldw >> 5;
@@ -717,7 +729,7 @@ int launch(const estts_gemm_args& a, int splitk, hipStream_t st) {
 
 template <int TM, int TN, int OCC, int KIND>
 int launch_big_d(const estts_gemm_args& a, hipStream_t st) {
-    dim3 grid((a.N + 64 * TN - 1) / (64 * TN), (a.M + 64 * TM - 1) / (64 * TM), 1);
+    dim3 grid((a.N + 64 * TN - 1) / (64 * TN), (a.M + 64 * TM - 1) / (64 * TM), a.batch > 1 ? a.batch : 1);
     if (a.precision == 3)
         hipLaunchKernelGGL((gemm_big_kernel<3, TM, TN, OCC, KIND>), grid, dim3(256), 0, st, a);
     else
@@ -776,10 +788,12 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         // workgroups fill the chip -- as 64 x 128 tiles when there are enough of those, else as 64 x 64 tiles -- and
         // below that the barrier-free 32 x 32 kernel does.  The 128 x 128 and 128 x 64 shapes and the older 64 x 64
         // kernels (ids 1-3) never win at these sizes and are kept for explicit selection only.
-        const long mt = (a.M + 63) / 64;
+        const long mt = (long)((a.M + 63) / 64) * (a.batch > 1 ? a.batch : 1);
         const long n8 = mt * ((a.N + 127) / 128), n6 = mt * ((a.N + 63) / 64);
-        tile = (a.N >= 128 && n8 >= 384) ? 8 : (n6 >= 288 ? 6 : 4);
+        tile = (a.N >= 128 && n8 >= 384) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
     }
+    ESTTS_CHECK_ARG(a.batch <= 1 || (tile >= 5 && tile <= 8), "estts_gemm: batch > 1 needs an LDS-staged tile (tune 0 or 5..8)");
+    ESTTS_CHECK_ARG(a.batch <= 65535, "estts_gemm: batch exceeds the grid limit");
     long tiles;
     int nk;  // K units that one split must keep at least two of
     switch (tile) {

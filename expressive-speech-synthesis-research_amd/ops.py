@@ -181,9 +181,11 @@ def gemm_workspace(device):
 
 
 def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
-         split=True, conv2d=None, dropout=None):
+         split=True, conv2d=None, dropout=None, batch=None):
     """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary).
-    dropout = (rate, seed, site, row0): keep/scale after the activation, generator row = row0 + output row."""
+    dropout = (rate, seed, site, row0): keep/scale after the activation, generator row = row0 + output row.
+    batch = (count, stride_a, stride_w, stride_c, stride_v): that many products of this shape in one launch; x / lin / out
+    describe product 0 and the strides (elements) lead to the others (see estts_gemm_args.batch)."""
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
     a = GemmArgs()
@@ -209,6 +211,8 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
         if not dropout[0] < 1.0:
             raise ValueError('gemm: dropout rate must be below 1')
         a.drop_rate, a.drop_seed, a.drop_site, a.drop_row0 = dropout
+    if batch is not None:
+        a.batch, a.batch_stride_a, a.batch_stride_w, a.batch_stride_c, a.batch_stride_v = batch
     if split:
         ws, cnt = gemm_workspace(x.device)
         a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()

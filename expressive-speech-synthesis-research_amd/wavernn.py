@@ -153,7 +153,6 @@ class WaveRNN:
         self.step = 0
         self._sd = None
         self.steps_per_graph = 50
-        self.branch_streams = False
         ops.gemm_workspace(self.device)
 
     @classmethod
@@ -198,17 +197,20 @@ class WaveRNN:
         self.k_in = (n_in + 3) // 4 * 4
         wI = np.zeros((self.rnn_dims, self.k_in), np.float32)
         wI[:, :n_in] = w['I.weight']
-        self.I = PackedLinear(wI, bias=w['I.bias'], device=dev)
-        self.ih1 = PackedLinear(w['rnn1.weight_ih_l0'], bias=w['rnn1.bias_ih_l0'], device=dev)
         # rnn1's input product taken straight from the step input: W_ih (W_I x + b_I) + b_ih = (W_ih W_I) x + (W_ih b_I + b_ih),
         # composed in float64.  K drops from rnn_dims to 1 + feat + aux, and the product no longer waits for I's output
-        # (which is still computed, as the residual `x + h1` needs it).
+        # (which is still computed, as the residual `x + h1` needs it).  Both come out of one launch, see in_proj.
         w_ih, w_i = np.asarray(w['rnn1.weight_ih_l0'], np.float64), wI.astype(np.float64)
         b_comp = w_ih @ np.asarray(w['I.bias'], np.float64) + np.asarray(w['rnn1.bias_ih_l0'], np.float64)
-        self.ih1_x = PackedLinear((w_ih @ w_i).astype(np.float32), bias=b_comp.astype(np.float32), device=dev)
-        self.hh1 = PackedLinear(w['rnn1.weight_hh_l0'], bias=w['rnn1.bias_hh_l0'], device=dev)
+        # both products of the step input in one launch: rows [0, R) give I's output, rows [R, 4R) rnn1's input gates
+        self.in_proj = PackedLinear(np.concatenate([wI.astype(np.float64), w_ih @ w_i]).astype(np.float32),
+                                    bias=np.concatenate([np.asarray(w['I.bias'], np.float64), b_comp]).astype(np.float32), device=dev)
         self.ih2 = PackedLinear(w['rnn2.weight_ih_l0'], bias=w['rnn2.bias_ih_l0'], device=dev)
-        self.hh2 = PackedLinear(w['rnn2.weight_hh_l0'], bias=w['rnn2.bias_hh_l0'], device=dev)
+        # the two recurrent products depend only on the previous step's states: one batched launch (weights and biases of
+        # rnn2 follow rnn1's in one packed buffer; 3R is a multiple of 64, so the second matrix starts on a block boundary)
+        self.hh12 = PackedLinear(np.concatenate([np.asarray(w['rnn1.weight_hh_l0']), np.asarray(w['rnn2.weight_hh_l0'])]),
+                                 bias=np.concatenate([np.asarray(w['rnn1.bias_hh_l0']), np.asarray(w['rnn2.bias_hh_l0'])]), device=dev)
+        self.hh12.N = 3 * self.rnn_dims          # one product's width; the batch stride leads to the other
         self.fc1 = PackedLinear(w['fc1.weight'], bias=w['fc1.bias'], device=dev, act='relu')
         self.fc2 = PackedLinear(w['fc2.weight'], bias=w['fc2.bias'], device=dev, act='relu')
         self.fc3 = PackedLinear(w['fc3.weight'], bias=w['fc3.bias'], device=dev)
@@ -295,10 +297,10 @@ class WaveRNN:
     def _alloc_state(self, n_seq, L):
         f32 = dict(dtype=torch.float32, device=self.device)
         R, d = self.rnn_dims, self.aux_dims
-        return {'xin': torch.zeros(n_seq, self.k_in, **f32), 'xI': torch.empty(n_seq, R, **f32),
-                'gi': torch.empty(n_seq, 3 * R, **f32), 'gh': torch.empty(n_seq, 3 * R, **f32),
-                'gi2': torch.empty(n_seq, 3 * R, **f32), 'gh2': torch.empty(n_seq, 3 * R, **f32), 'gh_ready': False,
-                'h1': torch.zeros(n_seq, R, **f32), 'h2': torch.zeros(n_seq, R, **f32),
+        return {'xin': torch.zeros(n_seq, self.k_in, **f32),
+                'xg': torch.empty(n_seq, 4 * R, **f32),                       # [I's output | rnn1's input gates]
+                'gi2': torch.empty(n_seq, 3 * R, **f32), 'gh12': torch.empty(2, n_seq, 3 * R, **f32),
+                'h12': torch.zeros(2, n_seq, R, **f32),
                 'x1cat': torch.zeros(n_seq, R + d, **f32), 'x2cat': torch.zeros(n_seq, R + d, **f32),
                 'f1cat': torch.zeros(n_seq, self.fc_dims + d, **f32), 'f2': torch.empty(n_seq, self.fc_dims, **f32),
                 'logits': torch.empty(n_seq, self.n_classes, **f32), 'x_prev': torch.zeros(n_seq, **f32),
@@ -330,48 +332,21 @@ class WaveRNN:
         a.step, a.done, a.n_seq = st['step'].data_ptr(), st['done'].data_ptr(), n_seq
         return a
 
-    def _one_step(self, st, prep_args, sample_args, logits_out=None, side=None, prefetch=True):
-        """fatchord_version.py:180-216 for every sequence at once.
-
-        side: three extra streams.  The recurrent products h1 W_hh1 and h2 W_hh2 depend only on the previous step's
-        states and I's output is needed only as a residual, so they run on branches beside the chain
-        input -> rnn1 -> rnn2 -> fc1 -> fc2 -> fc3 -> sample (captured into a graph these become parallel nodes).  With
-        prefetch the recurrent products of the NEXT step are issued as soon as this step's states exist
-        (st['gh_ready'] says whether the current ones were)."""
+    def _one_step(self, st, prep_args, sample_args, logits_out=None):
+        """fatchord_version.py:180-216 for every sequence at once, 11 launches: conditioning, [I | rnn1 input gates] from the
+        step input, both recurrent products (they depend only on the previous step's states) as one batched launch, gates,
+        rnn2's input product, gates, fc1, fc2, fc3, sampling."""
         lib, R, F, pr = _lib.load(), self.rnn_dims, self.fc_dims, self.precision
-        main = torch.cuda.current_stream()
-
-        def branch(i, fn):
-            if side is None:
-                fn()
-                return
-            side[i].wait_stream(main)
-            with torch.cuda.stream(side[i]):
-                fn()
-
-        def join(i):
-            if side is not None:
-                main.wait_stream(side[i])
-
-        hh1 = lambda: ops.gemm(st['h1'], self.hh1, st['gh'], precision=pr, split=False)
-        hh2 = lambda: ops.gemm(st['h2'], self.hh2, st['gh2'], precision=pr, split=False)
-        if not st['gh_ready']:
-            branch(0, hh1)
-            branch(1, hh2)
+        n = st['h12'].shape[1]
+        h1, h2 = st['h12'][0], st['h12'][1]
+        xI, gi1 = st['xg'][:, :R], st['xg'][:, R:]
         check(lib.estts_wavernn_prep(prep_args, ops._stream()), 'estts_wavernn_prep')
-        branch(2, lambda: ops.gemm(st['xin'], self.I, st['xI'], precision=pr, split=False))
-        ops.gemm(st['xin'], self.ih1_x, st['gi'], precision=pr)
-        join(0)
-        join(2)
-        self._gates(st['gi'], st['gh'], st['h1'], st['xI'], st['x1cat'][:, :R])
-        if prefetch:
-            branch(0, hh1)
+        ops.gemm(st['xin'], self.in_proj, st['xg'], precision=pr)
+        ops.gemm(h1, self.hh12, st['gh12'][0], precision=pr, split=False,
+                 batch=(2, n * R, 3 * R * self.hh12.ldw, n * 3 * R, 3 * R))
+        self._gates(gi1, st['gh12'][0], h1, xI, st['x1cat'][:, :R])
         ops.gemm(st['x1cat'], self.ih2, st['gi2'], precision=pr)
-        join(1)
-        self._gates(st['gi2'], st['gh2'], st['h2'], st['x1cat'][:, :R], st['x2cat'][:, :R])
-        if prefetch:
-            branch(1, hh2)
-        st['gh_ready'] = prefetch
+        self._gates(st['gi2'], st['gh12'][1], h2, st['x1cat'][:, :R], st['x2cat'][:, :R])
         ops.gemm(st['x2cat'], self.fc1, st['f1cat'][:, :F], precision=pr)
         ops.gemm(st['f1cat'], self.fc2, st['f2'], precision=pr)
         ops.gemm(st['f2'], self.fc3, st['logits'] if logits_out is None else logits_out, precision=pr)
@@ -387,23 +362,22 @@ class WaveRNN:
         n = self.steps_per_graph
         done = 0
         if use_graph and L >= 2 * n:
-            self._one_step(st, prep_args, sample_args, prefetch=False)          # warm-up outside capture (also step 0)
+            self._one_step(st, prep_args, sample_args)          # warm-up outside capture (also step 0)
             done = 1
-            cap = torch.cuda.Stream()
-            side = [torch.cuda.Stream() for _ in range(3)] if self.branch_streams else None
-            cap.wait_stream(torch.cuda.current_stream())
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=cap):
-                for j in range(n):                                             # the last step leaves no branch open
-                    self._one_step(st, prep_args, sample_args, side=side, prefetch=j < n - 1)
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(n):
+                    self._one_step(st, prep_args, sample_args)
             # capture does not execute: the step counter still says `done`
             while L - done >= n:
                 g.replay()
                 done += n
-            torch.cuda.current_stream().wait_stream(cap)
+            torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         for _ in range(L - done):
-            self._one_step(st, prep_args, sample_args, prefetch=False)
+            self._one_step(st, prep_args, sample_args)
 
     # ------------------------------------------------------------------ reference surface
     def generate_batch(self, mel_list, batched=True, target=11_000, overlap=550, mu_law=True, seed=0, uniforms=None,
@@ -488,7 +462,7 @@ class WaveRNN:
         prep_args = self._prep_args(cond, st, seq_utt, seq_start, B)
         for t in range(L):
             sample_args = self._sample_args(st, B, 0, None, None, forced, logits=logits[t])
-            self._one_step(st, prep_args, sample_args, logits_out=logits[t], prefetch=False)
+            self._one_step(st, prep_args, sample_args, logits_out=logits[t])
         self.step += 1
         return logits.permute(1, 0, 2)
 

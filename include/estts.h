@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 14
+#define ESTTS_ABI_VERSION 15
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -109,6 +109,11 @@ typedef struct estts_gemm_args {
     float drop_rate;     /* 0 = no dropout */
     uint32_t drop_seed, drop_site;
     int32_t drop_row0;   /* generator row of output row 0 (an incremental decoder computes row i alone) */
+    /* batch > 1: that many independent products of one shape in a single launch (e.g. the two recurrent products of a
+     * WaveRNN step); product z uses A + z * batch_stride_a, W_hi / W_lo + z * batch_stride_w (uint16 elements), C and R +
+     * z * batch_stride_c, and s1 / b1 / s2 / b2 + z * batch_stride_v (floats).  LDS-staged tiles only (tune 0 or 5..8). */
+    int32_t batch;
+    int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_v;
 } estts_gemm_args;
 
 int estts_gemm(const estts_gemm_args* args, void* stream);

@@ -290,3 +290,23 @@ def test_length_regulator_bit_exact():
         ref[b, :len(rows)] = x.view(B, N, D)[b].numpy()[rows]
     assert np.array_equal(out.cpu().numpy().reshape(B, T, D), ref)
     assert np.array_equal(fm.cpu().numpy(), (np.arange(T)[None] >= reps.sum(axis=1)[:, None]).astype(np.float32))
+
+
+def test_gemm_batched_products_in_one_launch():
+    """batch = 2: two products of one shape (different inputs, weights, biases, outputs) from a single launch, as the two
+    recurrent products of a WaveRNN step are issued."""
+    rng = np.random.default_rng(5)
+    M, N, K = 200, 192, 96
+    x = rng.normal(size=(2, M, K)).astype(np.float32)
+    w = rng.normal(size=(2 * N, K)).astype(np.float32) * 0.2
+    b = rng.normal(size=2 * N).astype(np.float32)
+    lin = PackedLinear(w, bias=b, device=DEV)
+    lin.N = N
+    xd = torch.from_numpy(x).to(DEV)
+    out = torch.full((2, M, N), float('nan'), device=DEV)
+    ops.gemm(xd[0], lin, out[0], split=False, batch=(2, M * K, N * lin.ldw, M * N, N))
+    for z in range(2):
+        ref = x[z].astype(np.float64) @ w[z * N:(z + 1) * N].astype(np.float64).T + b[z * N:(z + 1) * N]
+        assert np.abs(out[z].cpu().numpy() - ref).max() < 3e-5 * np.abs(ref).max()
+    with pytest.raises(Exception):
+        ops.gemm(xd[0], lin, out[0], split=False, tune=4, batch=(2, M * K, N * lin.ldw, M * N, N))
