@@ -166,6 +166,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise EsttsError(f'{LIB_PATH} not found: the HIP extension is not built (make -C {_PKG}/csrc). '
                          'There is no CPU fallback for the hot path.')
+    # The library's code objects register with the HIP runtime torch ships.  That runtime has to be initialised by torch
+    # first: registered into an uninitialised runtime, every later launch reports "no ROCm-capable device is detected".
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
