@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -146,6 +146,9 @@ SIGNATURES = {
     'estts_gemm_f32': (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     'estts_spec_magnitude': (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     'estts_mel_normalize': (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
+    'estts_alignment_lengths': (_i32, [_vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    'estts_alignment_stats': (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    'estts_alignment_peaks': (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     'estts_pack_weights': (_i32, [_vp, _i32, _i64, _vp]),
     'estts_run_program': (_i32, [C.POINTER(ProgOp), _i32, _i32, _vp]),
     'estts_mol_loss': (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),

@@ -287,6 +287,42 @@ class AutoregressiveTransformer:
 
     __call__ = call
 
+    def _compile(self, stop_scaling, optimizer=None):
+        """AutoregressiveTransformer.py:224-231: masked MAE on the post-net output, stop-token cross entropy whose stop class
+        (index 2) weighs `stop_scaling`, masked MAE on the linear output; all three weights 1."""
+        self.loss_weights = [1., 1., 1.]
+        self.stop_scaling = float(stop_scaling)
+        self.optimizer = optimizer
+
+    def _gta_forward(self, inp, tar, stop_prob, spk_embed=None):
+        """AutoregressiveTransformer.py:195-218 with training=False: teacher-forced pass on tar[:, :-1] (every r-th frame), the
+        three losses against tar[:, 1:] / stop_prob[:, 1:] over the first mel_len output frames."""
+        from . import train_ops
+        if not hasattr(self, 'loss_weights'):
+            raise RuntimeError('call _compile(stop_scaling) first')
+        dev = self.device
+        tar = torch.as_tensor(tar, dtype=torch.float32, device=dev)
+        stop = torch.as_tensor(stop_prob, device=dev).to(torch.int32)
+        tar_real, tar_mel, tar_stop, mel_len = self.input_reshape(tar, stop)
+        out = self.call(inp, tar_mel.contiguous(), spk_embed)
+        B, C = tar.shape[0], tar.shape[2]
+        M = B * mel_len
+        losses = torch.zeros(3, dtype=torch.float32, device=dev)
+        target2 = tar_real.reshape(M, C)
+        ops.masked_mae(target2, out['final_output'][:, :mel_len, :].reshape(M, C), losses[0:1])
+        train_ops.scaled_xent(out['stop_prob'][:, :mel_len, :].reshape(M, 3), tar_stop.reshape(M).contiguous(), losses[1:2],
+                              index=2, scaling=self.stop_scaling)
+        ops.masked_mae(target2, out['mel_linear'][:, :mel_len, :].reshape(M, C), losses[2:3])
+        w = self.loss_weights
+        out['tts_loss'] = losses[0] * w[0] + losses[1] * w[1] + losses[2] * w[2]
+        out['losses'] = {'output': losses[0], 'stop_prob': losses[1], 'mel_linear': losses[2]}
+        out['reduced_target'] = tar_mel
+        return out
+
+    def val_step(self, inp, tar, stop_prob, spk_embed=None):
+        """AutoregressiveTransformer.py:220-222 (what extract_durations.py:125,144 runs over the data set)."""
+        return self._gta_forward(inp, tar, stop_prob, spk_embed)
+
     # ------------------------------------------------------------------ incremental decoding
     @staticmethod
     def _as_dense(lin):

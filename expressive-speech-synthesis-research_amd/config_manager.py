@@ -118,7 +118,9 @@ class ConfigManager:
         return {'learning_rate': float(learning_rate), 'beta_1': 0.9, 'beta_2': 0.98, 'epsilon': 1e-9}
 
     def compile_model(self, model):
-        if hasattr(model, '_compile'):
+        if self.model_kind == 'autoregressive':          # config_manager.py:165-166
+            model._compile(stop_scaling=self.config.get('stop_loss_scaling', 1.), optimizer=self.new_adam(self.learning_rate))
+        elif hasattr(model, '_compile'):
             model._compile(optimizer=self.new_adam(self.learning_rate))
 
     @staticmethod

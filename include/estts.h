@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 15
+#define ESTTS_ABI_VERSION 16
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -557,6 +557,33 @@ int estts_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, flo
 int estts_spec_magnitude(const float* reim, int64_t ld, int32_t nb, float* mag, int64_t ldm, int32_t M, void* stream);
 int estts_mel_normalize(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t M, int32_t C, int32_t mode, float ref_level_db,
                         float min_level_db, float scale, float shift, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Duration extraction from the decoder's cross-attention maps.
+ * Replaces the map reductions of get_durations_from_alignment (TransformerTTS/utils/alignments.py:87-165: padding lengths
+ * :103-112, weight_mask and the per-head scores :116-122 with :31-36, best head / weighted reference map :124-128,
+ * binary_attention :78-84, the column sums of the non-binary branch :140), called by TransformerTTS/extract_durations.py:177,212
+ * on maps it first copies to the host (:129-153).  The sequential part (jump repair, rounding repair, gap filling) stays on the
+ * host and reads only these reductions.  All sums are float64 like the reference's.
+ *
+ * With T' = mel_len[b] - 2 and N' = phon_len[b] - 2 (start / end vectors and tokens removed) and W[b, h] the window
+ * attn[b, h, 1 : 1 + T', 1 : 1 + N'] of the (B, H, Lq, Lk) float32 maps:
+ * estts_alignment_lengths:  mel_len[b] = T - #{t : sum_c |mels[b, t, c]| == 0},  phon_len[b] = N - #{n : tokens[b, n] == 0}
+ * estts_alignment_stats:    score[b, h] = sum_{t, n} |n / N' - t / T'| W[b, h][t, n];  colsum[b, h, n] = sum_t W[b, h][t, n]
+ *                           (colsum has Lk entries per head, zero past N')
+ * estts_alignment_peaks:    ref = W[b, best_head[b]] with best_head[b] = first argmin_h score[b, h] (weighted == 0), or
+ *                           ref = sum_h W[b, h] / score[b, h] (weighted != 0); for t < T':  peak_idx[b, t] = first argmax_n ref[t, n],
+ *                           peak_val[b, t] = that maximum, peak_ties[b, t] = number of entries equal to it (the reference asserts 1);
+ *                           rows t >= T' get -1 / 0 / 0.  peak_* have Lq entries per utterance.
+ * Lengths with mel_len - 1 > Lq or phon_len > Lk are clamped to the map on the device; the host layer rejects them.
+ * ------------------------------------------------------------------------------------------ */
+int estts_alignment_lengths(const float* mels, int64_t ldm, int32_t T, int32_t C, const int32_t* tokens, int32_t N, int32_t B,
+                            int32_t* mel_len, int32_t* phon_len, void* stream);
+int estts_alignment_stats(const float* attn, int32_t B, int32_t H, int32_t Lq, int32_t Lk, const int32_t* mel_len,
+                          const int32_t* phon_len, double* score, double* colsum, void* stream);
+int estts_alignment_peaks(const float* attn, int32_t B, int32_t H, int32_t Lq, int32_t Lk, const int32_t* mel_len,
+                          const int32_t* phon_len, const double* score, int32_t weighted, int32_t* peak_idx, double* peak_val,
+                          int32_t* peak_ties, int32_t* best_head, void* stream);
 
 #ifdef __cplusplus
 }

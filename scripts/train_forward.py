@@ -45,11 +45,13 @@ def file_batches(data_dir, batch_size, rank, world):
     rng = np.random.default_rng(rank)
     while True:
         rng.shuffle(files)
-        for i in range(0, len(files) - batch_size + 1, batch_size):
+        for i in range(0, len(files), batch_size):                     # the last batch of a pass may be smaller
             items = [np.load(f) for f in files[i:i + batch_size]]
+            batch_size_i = len(items)
             N, T = max(len(it['phonemes']) for it in items), max(it['mel'].shape[0] for it in items)
             C = items[0]['mel'].shape[1]
-            mel, tok, dur = np.zeros((batch_size, T, C), np.float32), np.zeros((batch_size, N), np.int32), np.zeros((batch_size, N), np.int32)
+            mel, tok, dur = (np.zeros((batch_size_i, T, C), np.float32), np.zeros((batch_size_i, N), np.int32),
+                             np.zeros((batch_size_i, N), np.int32))
             for b, it in enumerate(items):
                 mel[b, :it['mel'].shape[0]] = it['mel']
                 tok[b, :len(it['phonemes'])] = it['phonemes']

@@ -237,3 +237,45 @@ def test_incremental_predict_with_prenet_dropout_is_teacher_forced_consistent():
     assert (tf['final_output'][0] - mel).abs().max().item() < 2e-4
     other = model._predict_incremental(tokens, None, None, 16, False, False, dropout_seed=6)
     assert (other['mel'] - mel).abs().max().item() > 1e-3
+
+
+def test_val_step_losses_and_duration_extraction():
+    """The flow of the reference's extract_durations.py:125-185: val_step on (tokens, mel, stop labels), then the last decoder
+    block's cross-attention into get_durations_from_alignment.  Losses against the float64 oracle (1e-4); durations, being
+    integer work on the same maps, identical to the matrix-form oracle."""
+    from estts.alignments import get_durations_from_alignment
+    from oracle import alignments_numpy as OA
+    cfg = small_cfg('speaker_style_text', dense=1)
+    w = weights.init_autoregressive_transformer(cfg, seed=11)
+    rng = np.random.default_rng(5)
+    B, N, T = 3, 12, 31
+    tokens = rng.integers(1, cfg['vocab_size'], size=(B, N)).astype(np.int32)
+    tar = rng.normal(size=(B, T, 80)).astype(np.float32)
+    stop = np.ones((B, T), np.int32)
+    for b, (n, t) in enumerate(((12, 31), (9, 24), (7, 17))):
+        tokens[b, n:] = 0
+        tar[b, t:] = 0
+        stop[b, t - 1] = 2
+        stop[b, t:] = 0
+    spk = rng.normal(size=(B, 1, 16)).astype(np.float32)
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=1, decoder_prenet_dropout=0.0)
+    model._compile(stop_scaling=8.0)
+    out = model.val_step(tokens, tar, stop, spk)
+    ref = O.autoregressive_call(w, cfg, tokens, tar[:, :-1], spk, r=1)
+    total, vals = O.weighted_sum_losses((tar[:, 1:], stop[:, 1:], tar[:, 1:]),
+                                        (ref['final_output'], ref['stop_prob'], ref['mel_linear']),
+                                        [O.masked_mean_absolute_error, O.new_scaled_crossentropy(2, 8.0), O.masked_mean_absolute_error],
+                                        [1., 1., 1.])
+    assert abs(float(out['tts_loss']) - total) < 1e-4 * max(1.0, abs(total))
+    for key, v in zip(('output', 'stop_prob', 'mel_linear'), vals):
+        assert abs(float(out['losses'][key]) - v) < 1e-4 * max(1.0, abs(v)), key
+    attn = out['decoder_attention']['Decoder_ConvBlock1_CrossAttention']
+    assert tuple(attn.shape) == (B, 2, T - 1, N)
+    kw = dict(binary=True, fix_jumps=True, fill_gaps=True, fill_mode='max')
+    got = get_durations_from_alignment(attn, torch.from_numpy(tar).to(DEV), torch.from_numpy(tokens).to(DEV), **kw)
+    want = OA.get_durations_from_alignment(attn.cpu().numpy(), tar, tokens, **kw)
+    for b, (n, t) in enumerate(((12, 31), (9, 24), (7, 17))):
+        assert got[0][b].sum() == t - 2 and len(got[0][b]) == n - 2
+        assert np.array_equal(got[0][b], want[0][b])
+        assert np.abs(got[3][b] - want[3][b]).max() < 1e-6
