@@ -136,8 +136,29 @@ class ConfigManager:
         return w, step
 
     def latest_checkpoint(self):
+        """Newest ckpt-<step>.npz of this package, else the TensorFlow checkpoint prefix the reference's CheckpointManager
+        recorded in <weights_dir>/checkpoint (config_manager.py:206-211)."""
         files = sorted(glob.glob(str(self.weights_dir / 'ckpt-*.npz')), key=lambda p: int(p.rsplit('-', 1)[1][:-4]))
-        return files[-1] if files else None
+        if files:
+            return files[-1]
+        state = self.weights_dir / 'checkpoint'
+        if state.exists():
+            for line in state.read_text().splitlines():
+                if line.startswith('model_checkpoint_path:'):
+                    prefix = line.split(':', 1)[1].strip().strip('"')
+                    return prefix if os.path.isabs(prefix) else str(self.weights_dir / prefix)
+        return None
+
+    def read_any_weights(self, path):
+        """(.npz of this package) or (TensorFlow object-based checkpoint prefix, converted on the fly) -> (weights, step)."""
+        if not path.endswith('.npz') and os.path.exists(path + '.index'):
+            from .tf_checkpoint import load_tf_checkpoint
+            w, step = load_tf_checkpoint(path, self.model_kind, self.model_config_dict())
+            if step is None:                                     # tf.train.Checkpoint(net=model) alone: the prefix carries it
+                tail = path.rsplit('-', 1)[-1]
+                step = int(tail) if tail.isdigit() else 0
+            return w, step
+        return self.read_weights(path)
 
     def load_model(self, checkpoint_path=None, verbose=True, training=False, **kw):
         path = checkpoint_path or self.latest_checkpoint()
@@ -145,7 +166,7 @@ class ConfigManager:
         if path is None:
             print(f'WARNING: could not find weights file. Trying to load from \n {self.weights_dir}.')
         else:
-            w, step = self.read_weights(path)
+            w, step = self.read_any_weights(path)
         model = self.get_model(weights=w, training=training, **kw)
         self.compile_model(model)
         if training:
