@@ -102,28 +102,60 @@ __global__ __launch_bounds__(256) void wavernn_sample_kernel(const estts_wavernn
             // lane owns classes [lane * per, lane * per + per)
             const int per = (p.n_classes + 63) / 64;
             const int c0 = lane * per;
-            float mx = -INFINITY;
-            for (int k = 0; k < per; ++k)
-                if (c0 + k < p.n_classes) mx = fmaxf(mx, lg[c0 + k]);
-            mx = wave_max(mx);
-            float mine = 0.0f;
-            for (int k = 0; k < per; ++k)
-                if (c0 + k < p.n_classes) mine += expf(lg[c0 + k] - mx);
-            const float total = wave_sum(mine);
-            float incl = mine;  // inclusive prefix over lanes
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const float t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += t;
-            }
-            const float u = (p.u ? p.u[(long)step * p.n_seq + b] : uniform01(p.seed, step, b, 0)) * total;
-            float run = incl - mine;
+            const float u01 = p.u ? p.u[(long)step * p.n_seq + b] : uniform01(p.seed, step, b, 0);
             int cnt = 0;
-            for (int k = 0; k < per; ++k)
-                if (c0 + k < p.n_classes) {
-                    run += expf(lg[c0 + k] - mx);
+            if (p.n_classes == 512 && (p.ld_logits & 3) == 0 && (reinterpret_cast<uintptr_t>(p.logits) & 15) == 0) {
+                // the 9-bit case: the lane's eight logits in two 16-byte loads, exponentials computed once
+                float v[8];
+                *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(lg + c0);
+                *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(lg + c0 + 4);
+                float mx = v[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) mx = fmaxf(mx, v[k]);
+                mx = wave_max(mx);
+                float mine = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] = expf(v[k] - mx);
+                    mine += v[k];
+                }
+                const float total = wave_sum(mine);
+                float incl = mine;  // inclusive prefix over lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const float t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const float u = u01 * total;
+                float run = incl - mine;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    run += v[k];
                     cnt += (run <= u) ? 1 : 0;
                 }
+            } else {
+                float mx = -INFINITY;
+                for (int k = 0; k < per; ++k)
+                    if (c0 + k < p.n_classes) mx = fmaxf(mx, lg[c0 + k]);
+                mx = wave_max(mx);
+                float mine = 0.0f;
+                for (int k = 0; k < per; ++k)
+                    if (c0 + k < p.n_classes) mine += expf(lg[c0 + k] - mx);
+                const float total = wave_sum(mine);
+                float incl = mine;  // inclusive prefix over lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const float t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const float u = u01 * total;
+                float run = incl - mine;
+                for (int k = 0; k < per; ++k)
+                    if (c0 + k < p.n_classes) {
+                        run += expf(lg[c0 + k] - mx);
+                        cnt += (run <= u) ? 1 : 0;
+                    }
+            }
             cnt = (int)wave_sum((float)cnt);
             cnt = min(cnt, p.n_classes - 1);
             value = 2.0f * (float)cnt / ((float)p.n_classes - 1.0f) - 1.0f;
