@@ -180,12 +180,19 @@ def gemm_workspace(device):
     return ws
 
 
+def new_gemm_workspace(device, nbytes=4 << 20):
+    """A private split-K scratch for gemm(workspace=...)."""
+    return (torch.empty(nbytes // 4, dtype=torch.float32, device=device), torch.zeros(_N_COUNTERS, dtype=torch.int32, device=device))
+
+
 def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
-         split=True, conv2d=None, dropout=None, batch=None):
+         split=True, conv2d=None, dropout=None, batch=None, workspace=None):
     """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary).
     dropout = (rate, seed, site, row0): keep/scale after the activation, generator row = row0 + output row.
     batch = (count, stride_a, stride_w, stride_c, stride_v): that many products of this shape in one launch; x / lin / out
-    describe product 0 and the strides (elements) lead to the others (see estts_gemm_args.batch)."""
+    describe product 0 and the strides (elements) lead to the others (see estts_gemm_args.batch).
+    workspace = (float32 scratch, zeroed int32 tickets): split-K scratch of its own for launches on a second stream that may
+    run beside launches using the shared one (new_gemm_workspace())."""
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
     a = GemmArgs()
@@ -214,7 +221,7 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     if batch is not None:
         a.batch, a.batch_stride_a, a.batch_stride_w, a.batch_stride_c, a.batch_stride_v = batch
     if split:
-        ws, cnt = gemm_workspace(x.device)
+        ws, cnt = gemm_workspace(x.device) if workspace is None else workspace
         a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
     if lin.taps == 1 and x.shape[1] < lin.K:
         raise ValueError(f'gemm: x has {x.shape[1]} columns, weight expects K={lin.K}')

@@ -7,8 +7,10 @@ in train() mode, torch.optim.Adam at :104): `train_step(x, y, mels)` = forward, 
 checkpoint moves freely between this class, estts.wavernn.WaveRNN (generation) and the reference.
 
 All arithmetic runs in libestts.so kernels.  The two recurrences are 2 x T dependent (small GEMM + gate kernel) pairs in
-each direction; buffers are allocated once per (batch, window) shape so that each loop is captured into one hipGraph and
-replayed every step.  Master weights are float32 in one flat buffer ([in, out] layout, the transpose of torch's), with
+each direction; buffers are allocated once per (batch, window) shape so that each direction is captured into one hipGraph and
+replayed every step.  Within a direction the two layers' chains overlap on two streams (rnn2 follows rnn1 a chunk of steps
+behind; backward, rnn1 follows rnn2): each chain is latency-bound at 32 rows per product, side by side they cost little more
+than one.  Master weights are float32 in one flat buffer ([in, out] layout, the transpose of torch's), with
 gradients and Adam moments in buffers of the same shape.  The three upsampling kernels enter through their composite
 per-phase filter (see wavernn.composite_upsample_filter): its gradient is reduced on the device, the chain rule back to the
 three small kernels is a few hundred multiply-adds on the host.
@@ -250,6 +252,10 @@ class WaveRNNTrainer:
               'df2': torch.empty(M, F, **f32), 'df1cat': torch.empty(M, F + d, **f32), 'dx2cat': torch.empty(M, R + d, **f32),
               'dx1cat': torch.empty(M, R + d, **f32), 'dgi': torch.empty(M, 3 * R, **f32), 'dgh': torch.empty(M, 3 * R, **f32),
               'dhd': torch.empty(B, R, **f32), 'dhr': torch.empty(B, R, **f32), 'dxI': torch.empty(M, R, **f32),
+              # rnn1's own copies: its backward recurrence runs beside rnn2's
+              'dgi1': torch.empty(M, 3 * R, **f32), 'dgh1': torch.empty(M, 3 * R, **f32),
+              'dhd1': torch.empty(B, R, **f32), 'dhr1': torch.empty(B, R, **f32), 'res2': torch.zeros(M, R + d, **f32),
+              'stream_b': torch.cuda.Stream(device=dev), 'gemm_ws_b': ops.new_gemm_workspace(dev),
               'dxin': torch.empty(M, self.k_in, **f32), 'd_aux': torch.empty(Mr, self.res_out_dims, **f32),
               'dfir': torch.zeros(hop, self.ntaps, **f32), 'loss': torch.zeros(1, **f32),
               'labels': torch.zeros(M, **i32), 'yf': torch.zeros(M, **f32), 'graphs': {}}
@@ -278,27 +284,74 @@ class WaveRNNTrainer:
             return None
         g.replay()
 
-    def _gru_fwd(self, ws, gi, gh, H, hh, x_res, out, out_cols):
+    def _gru_fwd(self, ws, gi, gh, H, hh, x_res, out, out_cols, t0=0, t1=None, gemm_ws=None):
+        """Steps t0 .. t1 - 1 of one GRU layer over every window (one recurrent product and one gate kernel per step)."""
         B, T, R = ws['B'], ws['T'], self.rnn_dims
         gi3, gh3, H3 = gi.view(B, T, 3 * R), gh.view(B, T, 3 * R), H.view(B, T, R)
         xr3, out3 = x_res.view(B, T, -1), out.view(B, T, -1)
-        for t in range(T):
+        for t in range(t0, T if t1 is None else t1):
             hp = ws['h0'] if t == 0 else H3[:, t - 1]
-            ops.gemm(hp, hh.lin.fwd, gh3[:, t], precision=self.precision)
+            ops.gemm(hp, hh.lin.fwd, gh3[:, t], precision=self.precision, workspace=gemm_ws)
             T_.gru_step_fwd(gi3[:, t], gh3[:, t], hp, H3[:, t], x_res=xr3[:, t, :out_cols], out=out3[:, t, :out_cols])
 
-    def _gru_bwd(self, ws, gi, gh, H, hh, dout):
-        """dout: [M, >= R] gradient w.r.t. the layer output (columns 0..R-1); fills ws['dgi'], ws['dgh']."""
+    def _gru_bwd(self, ws, gi, gh, H, hh, dout, dgi, dgh, dhd, dhr, t_hi=None, t_lo=0, gemm_ws=None):
+        """Steps t_hi - 1 .. t_lo (descending) of one layer's backward recurrence.  dout: [M, >= R] gradient w.r.t. the layer
+        output (columns 0..R-1); fills dgi, dgh; dhd / dhr carry the hidden-state gradient between steps."""
         B, T, R = ws['B'], ws['T'], self.rnn_dims
         gi3, gh3, H3 = gi.view(B, T, 3 * R), gh.view(B, T, 3 * R), H.view(B, T, R)
-        dgi3, dgh3 = ws['dgi'].view(B, T, 3 * R), ws['dgh'].view(B, T, 3 * R)
+        dgi3, dgh3 = dgi.view(B, T, 3 * R), dgh.view(B, T, 3 * R)
         do3 = dout.view(B, T, -1)
-        for t in range(T - 1, -1, -1):
+        for t in range((T if t_hi is None else t_hi) - 1, t_lo - 1, -1):
             hp = ws['h0'] if t == 0 else H3[:, t - 1]
-            T_.gru_step_bwd(gi3[:, t], gh3[:, t], hp, do3[:, t, :R], None if t == T - 1 else ws['dhr'], dgi3[:, t], dgh3[:, t],
-                            ws['dhd'])
+            T_.gru_step_bwd(gi3[:, t], gh3[:, t], hp, do3[:, t, :R], None if t == T - 1 else dhr, dgi3[:, t], dgh3[:, t], dhd)
             if t > 0:
-                ops.gemm(dgh3[:, t], hh.lin.bwd, ws['dhr'], precision=self.precision, residual=ws['dhd'])
+                ops.gemm(dgh3[:, t], hh.lin.bwd, dhr, precision=self.precision, residual=dhd, workspace=gemm_ws)
+
+    CHUNK = None     # steps between hand-overs from one recurrence to the other; None: a quarter of the window (measured at
+                     # 32 windows x 1000 steps: one chunk 57.6 ms per training step, 500: 47.8, 250: 42.8, 125: 44.1, 50: 46.3)
+
+    def _chunks(self, T):
+        c = self.CHUNK or max(-(-T // 4), 1)
+        return [(c0, min(c0 + c, T)) for c0 in range(0, T, c)]
+
+    def _gru12_fwd(self, ws):
+        """Both GRU layers of the window as two chains that overlap: rnn2 only needs rnn1's outputs up to its own step, so
+        after every CHUNK steps of rnn1 (this stream) a second stream computes rnn2's input gates for those steps (one product
+        batched over the windows) and runs rnn2 over them while rnn1 goes on.  The chains are latency-bound (32 rows per
+        product), so side by side they take little more than one of them."""
+        B, T, R, d = ws['B'], ws['T'], self.rnn_dims, self.aux_dims
+        cur, sb = torch.cuda.current_stream(), ws['stream_b']
+        x1 = ws['x1cat'].view(B, T, R + d)
+        g2 = ws['gi2'].view(B, T, 3 * R)
+        for c0, c1 in self._chunks(T):
+            self._gru_fwd(ws, ws['gi1'], ws['gh1'], ws['H1'], self.hh1, ws['xI'], ws['x1cat'], R, c0, c1)
+            sb.wait_stream(cur)
+            with torch.cuda.stream(sb):
+                ops.gemm(x1[0, c0:c1], self.ih2.lin.fwd, g2[0, c0:c1], precision=self.precision, split=False,
+                         batch=(B, T * (R + d), 0, T * 3 * R, 0))
+                self._gru_fwd(ws, ws['gi2'], ws['gh2'], ws['H2'], self.hh2, ws['x1cat'], ws['x2cat'], R, c0, c1,
+                              gemm_ws=ws['gemm_ws_b'])
+        cur.wait_stream(sb)
+
+    def _gru21_bwd(self, ws):
+        """The backward recurrences the same way, from the last step down: rnn2 on this stream; after every CHUNK steps the
+        second stream turns rnn2's input-gate gradients of those steps into the gradient of rnn1's output (product with
+        W_ih2 plus the residual path, ws['res2']) and runs rnn1's backward recurrence over them."""
+        B, T, R, d = ws['B'], ws['T'], self.rnn_dims, self.aux_dims
+        cur, sb = torch.cuda.current_stream(), ws['stream_b']
+        dg2 = ws['dgi'].view(B, T, 3 * R)
+        dx1 = ws['dx1cat'].view(B, T, R + d)
+        res = ws['res2'].view(B, T, R + d)
+        for c0, c1 in reversed(self._chunks(T)):
+            self._gru_bwd(ws, ws['gi2'], ws['gh2'], ws['H2'], self.hh2, ws['dx2cat'], ws['dgi'], ws['dgh'], ws['dhd'], ws['dhr'],
+                          c1, c0)
+            sb.wait_stream(cur)
+            with torch.cuda.stream(sb):
+                ops.gemm(dg2[0, c0:c1], self.ih2.lin.bwd, dx1[0, c0:c1], precision=self.precision, split=False,
+                         residual=res[0, c0:c1], batch=(B, T * 3 * R, 0, T * (R + d), 0))
+                self._gru_bwd(ws, ws['gi1'], ws['gh1'], ws['H1'], self.hh1, ws['dx1cat'], ws['dgi1'], ws['dgh1'], ws['dhd1'],
+                              ws['dhr1'], c1, c0, gemm_ws=ws['gemm_ws_b'])
+        cur.wait_stream(sb)
 
     # ------------------------------------------------------------------ pieces of the step
     def _bn_train(self, z, bn, M, C):
@@ -397,9 +450,7 @@ class WaveRNNTrainer:
         check(_lib.load().estts_wavernn_prep(a, ops._stream()), 'estts_wavernn_prep')
         ops.gemm(ws['xin'], self.I.lin.fwd, ws['xI'], precision=pr)
         ops.gemm(ws['xI'], self.ih1.lin.fwd, ws['gi1'], precision=pr)
-        self._run(ws, 'gru1_fwd', lambda: self._gru_fwd(ws, ws['gi1'], ws['gh1'], ws['H1'], self.hh1, ws['xI'], ws['x1cat'], R))
-        ops.gemm(ws['x1cat'], self.ih2.lin.fwd, ws['gi2'], precision=pr)
-        self._run(ws, 'gru2_fwd', lambda: self._gru_fwd(ws, ws['gi2'], ws['gh2'], ws['H2'], self.hh2, ws['x1cat'], ws['x2cat'], R))
+        self._run(ws, 'gru12_fwd', lambda: self._gru12_fwd(ws))
         ops.gemm(ws['x2cat'], self.fc1.lin.fwd, ws['f1cat'][:, :F], precision=pr)
         ops.gemm(ws['f1cat'], self.fc2.lin.fwd, ws['f2'], precision=pr)
         ops.gemm(ws['f2'], self.fc3.lin.fwd, ws['logits'], precision=pr)
@@ -446,13 +497,12 @@ class WaveRNNTrainer:
         T_.wgrad(ws['x2cat'], g1, self.fc1.dk, M=M, precision=pr)
         ops.gemm(g1, self.fc1.lin.bwd, ws['dx2cat'], precision=pr)
         # x2cat[:, :R] = H2 + x1: the GRU output gradient is dx2cat[:, :R]; the residual path joins dx1cat below
-        self._run(ws, 'gru2_bwd', lambda: self._gru_bwd(ws, ws['gi2'], ws['gh2'], ws['H2'], self.hh2, ws['dx2cat']))
-        self._gru_param_grads(ws, ws['x1cat'], ws['H2'], self.ih2, self.hh2)
-        ops.gemm(ws['dgi'], self.ih2.lin.bwd, ws['dx1cat'], precision=pr)
-        T_.axpby(ws['dx2cat'][:, :R], ws['dx1cat'][:, :R], alpha=1.0, beta=1.0, M=M, D=R)
-        self._run(ws, 'gru1_bwd', lambda: self._gru_bwd(ws, ws['gi1'], ws['gh1'], ws['H1'], self.hh1, ws['dx1cat']))
-        self._gru_param_grads(ws, ws['xI'], ws['H1'], self.ih1, self.hh1)
-        ops.gemm(ws['dgi'], self.ih1.lin.bwd, ws['dxI'], precision=pr, residual=ws['dx1cat'][:, :R])
+        # (dx1cat = dgi2 W_ih2^T + [dx2cat[:, :R] | 0]; the second term, a copy, is ws['res2'], whose aux columns stay zero)
+        ws['res2'][:, :R].copy_(ws['dx2cat'][:, :R])
+        self._run(ws, 'gru21_bwd', lambda: self._gru21_bwd(ws))
+        self._gru_param_grads(ws, ws['x1cat'], ws['H2'], self.ih2, self.hh2, ws['dgi'], ws['dgh'])
+        self._gru_param_grads(ws, ws['xI'], ws['H1'], self.ih1, self.hh1, ws['dgi1'], ws['dgh1'])
+        ops.gemm(ws['dgi1'], self.ih1.lin.bwd, ws['dxI'], precision=pr, residual=ws['dx1cat'][:, :R])
         self._lin_bwd(ws['xin'], self.I, ws['dxI'], M, dx=ws['dxin'])
         T_.wavernn_prep_bwd(ws['dxin'], ws['dx1cat'][:, R:], ws['dx2cat'][:, R:], ws['df1cat'][:, F:], ws['mel'], ws['mel_off'],
                             ws['d_aux'], ws['dfir'], self.fir_kmin, ws['B'], ws['Tf'], self.feat_dims, d, self.hop_length, self.pad)
@@ -464,11 +514,11 @@ class WaveRNNTrainer:
         self._apply_gradients()
         return ws['loss'][0]
 
-    def _gru_param_grads(self, ws, x_in, H, ih, hh):
+    def _gru_param_grads(self, ws, x_in, H, ih, hh, dgi, dgh):
         M, T = ws['M'], ws['T']
-        T_.wgrad(x_in, ws['dgi'], ih.dk, M=M, precision=self.precision, db=ih.db)
+        T_.wgrad(x_in, dgi, ih.dk, M=M, precision=self.precision, db=ih.db)
         # h_{t-1} is H shifted by one step inside each window: a one-tap "convolution" with one row of left padding
-        T_.wgrad(H, ws['dgh'], hh.dk, taps=1, lpad=1, M=M, seg_len=T, precision=self.precision, db=hh.db)
+        T_.wgrad(H, dgh, hh.dk, taps=1, lpad=1, M=M, seg_len=T, precision=self.precision, db=hh.db)
 
     def _apply_gradients(self):
         st = self.store
