@@ -82,7 +82,12 @@ _AUTOREGRESSIVE = {
 _WAVERNN = {
     'sample_rate': 16000,
     'num_mels': 80,
+    'n_fft': 2048,                 # WaveRNN/hparams.py:16-23 (DSP)
     'hop_length': 200,
+    'win_length': 800,
+    'fmin': 40,
+    'min_level_db': -100,
+    'ref_level_db': 20,
     'bits': 9,
     'mu_law': True,
     'voc_mode': 'MOL',
@@ -123,7 +128,7 @@ def wavernn_hparams(**overrides):
 def wavernn_hparams_22k(**overrides):
     """LJSpeech-shaped variant: hop 256 @ 22 050 Hz (TransformerTTS/config/melgan/data_config.yaml:16-19),
     RAW 9-bit mu-law output."""
-    c = wavernn_hparams(sample_rate=22050, hop_length=256, voc_upsample_factors=(4, 8, 8), voc_mode='RAW',
+    c = wavernn_hparams(sample_rate=22050, hop_length=256, n_fft=1024, win_length=1024, fmin=0, voc_upsample_factors=(4, 8, 8), voc_mode='RAW',
                         voc_seq_len=256 * 5)
     c.update(overrides)
     return c
