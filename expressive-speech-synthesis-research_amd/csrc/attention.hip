@@ -58,8 +58,8 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const __bf16* p0, const __bf16* p
 
 // MAXT > 0: the attention weights are wanted and every wave sweeps at most MAXT key tiles (Lk <= 128 MAXT): the scaled
 // scores stay in registers and the weights are written after the merge, without a second sweep over K.
-template <int DH, int NS, int MAXT>
-__global__ __launch_bounds__(256) void attention_kernel(const estts_attention_args p) {
+template <int DH, int NS, int MAXT, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attention_args p) {
     constexpr int KS = DH / 32;        // k-steps of the score product
     constexpr int NT = DH / 16;        // 16-feature tiles of the output
     constexpr int LD = DH + 8;         // staged row length in bf16 (row stride = 2 DH + 16 bytes)
@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     constexpr int RPI = 64 / LPR;      // tile rows per load instruction
     constexpr int NLD = 32 / RPI;      // load instructions per 32-key tile
     constexpr int IMG = 32 * LD;       // one staged image (hi or lo)
-    constexpr int STAGE_BYTES = 4 * NS * IMG * 2;
+    constexpr int STAGE_BYTES = NW * NS * IMG * 2;
     constexpr int MERGE_FLOATS = NT * 256 + 128;  // per wave: O^T fragments + m + l
-    constexpr int MERGE_BYTES = 4 * MERGE_FLOATS * 4;
+    constexpr int MERGE_BYTES = NW * MERGE_FLOATS * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > MERGE_BYTES ? STAGE_BYTES : MERGE_BYTES];
 
     const int lane = threadIdx.x & 63;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     }
     auto tile_step = [&](int kt, float (&s)[2][4]) {
         stage_tile(kx);
-        if (kt + 4 < nkt) load_tile(kbase, p.ldk, kt + 4, kx);
+        if (kt + NW < nkt) load_tile(kbase, p.ldk, kt + NW, kx);
         scores(kt, s);
         float tmax = -INFINITY;
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
         const Frag<NS> pf = make_frag<NS>(pv);
 
         stage_tile(vx);  // same image: this wave's K fragment reads were issued before these writes (in-order LDS)
-        if (kt + 4 < nkt) load_tile(vbase, p.ldv, kt + 4, vx);
+        if (kt + NW < nkt) load_tile(vbase, p.ldv, kt + NW, vx);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             Frag<NS> vf;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     if constexpr (MAXT > 0) {
 #pragma unroll
         for (int it = 0; it < MAXT; ++it) {
-            const int kt = wave + 4 * it;
+            const int kt = wave + NW * it;
             if (kt < nkt) {
                 float s[2][4];
                 tile_step(kt, s);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
             }
         }
     } else {
-        for (int kt = wave; kt < nkt; kt += 4) {
+        for (int kt = wave; kt < nkt; kt += NW) {
             float s[2][4];
             tile_step(kt, s);
         }
@@ -236,23 +236,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
     __syncthreads();
     float m_all = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) m_all = fmaxf(m_all, mg[w * MERGE_FLOATS + NT * 256 + lane]);
-    float sc[4], l_all = 0.0f;
+    for (int w = 0; w < NW; ++w) m_all = fmaxf(m_all, mg[w * MERGE_FLOATS + NT * 256 + lane]);
+    float sc[NW], l_all = 0.0f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         sc[w] = expf(mg[w * MERGE_FLOATS + NT * 256 + lane] - m_all);
         l_all += mg[w * MERGE_FLOATS + NT * 256 + 64 + lane] * sc[w];
     }
     const float inv_l = 1.0f / l_all;
     if (qi < p.Lq) {
         float* op = p.ctx + ((long)b * p.Lq + qi) * p.ldo + h * DH + 4 * g;
-        for (int nt = wave; nt < NT; nt += 4) {
+        for (int nt = wave; nt < NT; nt += NW) {
             float r4[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float acc = 0.0f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) acc += mg[w * MERGE_FLOATS + (nt * 4 + r) * 64 + lane] * sc[w];
+                for (int w = 0; w < NW; ++w) acc += mg[w * MERGE_FLOATS + (nt * 4 + r) * 64 + lane] * sc[w];
                 r4[r] = acc * inv_l;
             }
             *reinterpret_cast<float4*>(op + nt * 16) = make_float4(r4[0], r4[1], r4[2], r4[3]);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
             const bool vec = (p.Lk & 3) == 0;
 #pragma unroll
             for (int it = 0; it < MAXT; ++it) {
-                const int kt = wave + 4 * it;
+                const int kt = wave + NW * it;
                 if (kt < nkt) {
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub) {
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const estts_attention_ar
         float* ap = p.attn + (((long)b * p.H + h) * p.Lq + qrow) * p.Lk;
         const bool vec = (p.Lk & 3) == 0;
         if (wave < nkt) load_tile(kbase, p.ldk, wave, kx);
-        for (int kt = wave; kt < nkt; kt += 4) {
+        for (int kt = wave; kt < nkt; kt += NW) {
             stage_tile(kx);
-            if (kt + 4 < nkt) load_tile(kbase, p.ldk, kt + 4, kx);
+            if (kt + NW < nkt) load_tile(kbase, p.ldk, kt + NW, kx);
             float s[2][4];
             scores(kt, s);
             if (qi < p.Lq) {
@@ -531,13 +531,13 @@ int launch_wide(const estts_attention_args& a, hipStream_t st) {
     return 0;
 }
 
-template <int DH, int MAXT>
+template <int DH, int MAXT, int NW = 4>
 int launch_t(const estts_attention_args& a, hipStream_t st) {
     dim3 grid((a.Lq + 15) / 16, a.H, a.B);
     if (a.precision == 3)
-        hipLaunchKernelGGL((attention_kernel<DH, 2, MAXT>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attention_kernel<DH, 2, MAXT, NW>), grid, dim3(NW * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((attention_kernel<DH, 1, MAXT>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attention_kernel<DH, 1, MAXT, NW>), grid, dim3(NW * 64), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_attention");
     return 0;
 }
@@ -549,6 +549,15 @@ int launch(const estts_attention_args& a, hipStream_t st) {
     // (at depth 128 the 16-query kernel needs more than 256 registers, one workgroup per CU: the shared-tile kernel wins earlier)
     const long wide_min = DH >= 128 ? 192 : 512;
     if (a.variant == 2 || (a.variant == 0 && wide_wgs >= wide_min && a.Lk >= 64)) return launch_wide<DH>(a, st);
+    // few workgroups and many key tiles (one utterance, depth 64): eight waves split the keys, three tiles each at 600 keys
+    const long narrow_wgs = (long)((a.Lq + 15) / 16) * a.H * a.B;
+    if constexpr (DH == 64) {
+        if (a.variant == 0 && narrow_wgs <= 256 && a.Lk > 256) {
+            const int per8 = ((a.Lk + 31) / 32 + 7) / 8;
+            if (a.attn && per8 <= 3) return launch_t<DH, 3, 8>(a, st);
+            if (!a.attn) return launch_t<DH, 0, 8>(a, st);
+        }
+    }
     const int per_wave = ((a.Lk + 31) / 32 + 3) / 4;   // key tiles each wave sweeps
     if (a.attn && per_wave <= 2) return launch_t<DH, 2>(a, st);
     if (a.attn && per_wave <= 5) return launch_t<DH, 5>(a, st);

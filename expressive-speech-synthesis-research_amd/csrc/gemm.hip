@@ -790,7 +790,9 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         // kernels (ids 1-3) never win at these sizes and are kept for explicit selection only.
         const long mt = (long)((a.M + 63) / 64) * (a.batch > 1 ? a.batch : 1);
         const long n8 = mt * ((a.N + 127) / 128), n6 = mt * ((a.N + 63) / 64);
-        tile = (a.N >= 128 && n8 >= 384) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
+        // (with K <= 256 a workgroup's eight K-steps do not amortise the wider tile's prologue: 19200 x 768 x 256 runs 44 us
+        // as 64 x 64 tiles, 49 us as 64 x 128)
+        tile = (a.N >= 128 && n8 >= 384 && a.K > 256) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
     }
     ESTTS_CHECK_ARG(a.batch <= 1 || (tile >= 5 && tile <= 8), "estts_gemm: batch > 1 needs an LDS-staged tile (tune 0 or 5..8)");
     ESTTS_CHECK_ARG(a.batch <= 65535, "estts_gemm: batch exceeds the grid limit");
