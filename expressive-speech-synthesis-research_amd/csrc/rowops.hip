@@ -130,6 +130,80 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const estts_rownorm_args p
     }
 }
 
+// The same for D = 256 NCH with every operand of the row requested before the first reduction: in the general kernel above the
+// residual row and the two pairs of scale / shift vectors are loaded where they are used, behind the reductions, and each of
+// those round trips (~0.5-1 us) lies on the critical path of a launch that is a few microseconds long at one utterance.
+template <int NCH, bool LNA, bool RES, bool LNB>
+__global__ __launch_bounds__(256) void rownorm_fast_kernel(const estts_rownorm_args p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    float4 v[NCH], r[NCH], ga[NCH], ba[NCH], gb[NCH], bb[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        v[i] = *reinterpret_cast<const float4*>(p.y + (long)row * p.ldy + c);
+        if (RES) r[i] = *reinterpret_cast<const float4*>(p.x + (long)row * p.ldx + c);
+        if (LNA) {
+            ga[i] = *reinterpret_cast<const float4*>(p.ga + c);
+            ba[i] = *reinterpret_cast<const float4*>(p.ba + c);
+        }
+        if (LNB) {
+            gb[i] = *reinterpret_cast<const float4*>(p.gb + c);
+            bb[i] = *reinterpret_cast<const float4*>(p.bb + c);
+        }
+    }
+    auto layer_norm = [&](const float4 (&g)[NCH], const float4 (&b)[NCH]) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+        const float mean = wave_sum(s) / (float)p.D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const float a = v[i].x - mean, b2 = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b2 * b2 + c * c + d * d;
+        }
+        const float inv = rsqrtf(wave_sum(q) / (float)p.D + p.eps);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            v[i].x = (v[i].x - mean) * inv * g[i].x + b[i].x;
+            v[i].y = (v[i].y - mean) * inv * g[i].y + b[i].y;
+            v[i].z = (v[i].z - mean) * inv * g[i].z + b[i].z;
+            v[i].w = (v[i].w - mean) * inv * g[i].w + b[i].w;
+        }
+    };
+    if (LNA) layer_norm(ga, ba);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i].x = apply_act(v[i].x, p.act);
+        v[i].y = apply_act(v[i].y, p.act);
+        v[i].z = apply_act(v[i].z, p.act);
+        v[i].w = apply_act(v[i].w, p.act);
+        if (RES) {
+            v[i].x += r[i].x;
+            v[i].y += r[i].y;
+            v[i].z += r[i].z;
+            v[i].w += r[i].w;
+        }
+    }
+    if (LNB) layer_norm(gb, bb);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<float4*>(p.out + (long)row * p.ldo + (lane + 64 * i) * 4) = v[i];
+}
+
+template <int NCH>
+bool launch_rownorm_fast(const estts_rownorm_args& a, dim3 grid, hipStream_t st) {
+    const int key = (a.ga ? 4 : 0) | (a.x ? 2 : 0) | (a.gb ? 1 : 0);
+    switch (key) {
+        case 7: hipLaunchKernelGGL((rownorm_fast_kernel<NCH, true, true, true>), grid, dim3(256), 0, st, a); return true;
+        case 3: hipLaunchKernelGGL((rownorm_fast_kernel<NCH, false, true, true>), grid, dim3(256), 0, st, a); return true;
+        case 6: hipLaunchKernelGGL((rownorm_fast_kernel<NCH, true, true, false>), grid, dim3(256), 0, st, a); return true;
+        case 4: hipLaunchKernelGGL((rownorm_fast_kernel<NCH, true, false, false>), grid, dim3(256), 0, st, a); return true;
+        default: return false;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // inclusive prefix sum of max(rint(dur), 0) along N, one 256-thread workgroup per batch row
 __global__ __launch_bounds__(256) void durations_cumsum_kernel(const float* dur, int32_t* cum, int32_t* totals, int N) {
@@ -282,7 +356,14 @@ extern "C" int estts_rownorm(const estts_rownorm_args* args, void* stream) {
     ESTTS_CHECK_ARG(!a.gb || a.bb, "estts_rownorm: gb without bb");
     ESTTS_CHECK_ARG(!a.dot_w || a.dot_out, "estts_rownorm: dot_w without dot_out");
     ESTTS_CHECK_ARG(a.drop_rate >= 0.0f && a.drop_rate < 1.0f, "estts_rownorm: drop_rate must be in [0, 1)");
-    hipLaunchKernelGGL(rownorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((a.M + 3) / 4);
+    // short launches (one utterance): the variant with every operand requested up front; long ones are HBM-bound either way
+    bool done = false;
+    if (a.drop_rate == 0.0f && !a.dot_w && a.out && a.M <= 4096) {
+        if (a.D == 256) done = launch_rownorm_fast<1>(a, grid, (hipStream_t)stream);
+        else if (a.D == 512) done = launch_rownorm_fast<2>(a, grid, (hipStream_t)stream);
+    }
+    if (!done) hipLaunchKernelGGL(rownorm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_rownorm");
     return 0;
 }
