@@ -327,7 +327,9 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
 //   * weights wanted: a first sweep over K finds m and l, a second one over K and V writes exp(s - m) / l and
 //     accumulates the normalised output.
 // ======================================================================================================
-template <int DH, int NS>
+// MAXT > 0: the weights are wanted and the keys fit MAXT tiles (Lk <= 32 MAXT): one sweep, the scaled scores stay in registers
+// and the weights are written after it (as in the kernel above) instead of a second sweep that recomputes them.
+template <int DH, int NS, int MAXT = 0>
 __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attention_args p) {
     constexpr int KS = DH / 32;
     constexpr int NT = DH / 16;
@@ -446,9 +448,7 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
             par ^= 1;
         }
     };
-    auto online = [&](int kt, const __bf16* kimg, const __bf16* vimg, bool with_v) {
-        float s[8];
-        scores(kt, kimg, s);
+    auto update = [&](const float (&s)[8], const __bf16* vimg, bool with_v) {
         float tmax = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 8; ++e) tmax = fmaxf(tmax, s[e]);
@@ -472,9 +472,61 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
             times_v(pv, vimg, o);
         }
     };
+    auto online = [&](int kt, const __bf16* kimg, const __bf16* vimg, bool with_v) {
+        float s[8];
+        scores(kt, kimg, s);
+        update(s, vimg, with_v);
+    };
 
     float inv_l;
-    if (!p.attn) {
+    if constexpr (MAXT > 0) {
+        float sk[MAXT][8];
+        load_tile(kbase, p.ldk, 0, kx);
+        load_tile(vbase, p.ldv, 0, vx);
+#pragma unroll
+        for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < nkt) {                                   // uniform over the workgroup
+                __bf16* kimg = &smem[par][0][0][0];
+                __bf16* vimg = &smem[par][1][0][0];
+                stage_tile(kx, kimg);
+                stage_tile(vx, vimg);
+                __syncthreads();
+                if (kt + 1 < nkt) {
+                    load_tile(kbase, p.ldk, kt + 1, kx);
+                    load_tile(vbase, p.ldv, kt + 1, vx);
+                }
+                scores(kt, kimg, sk[kt]);
+                update(sk[kt], vimg, true);
+                par ^= 1;
+            }
+        }
+        inv_l = 1.0f / l_run;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = o[nt] * inv_l;
+        if (qi < p.Lq) {
+            float* ap = p.attn + (((long)b * p.H + h) * p.Lq + qrow) * p.Lk;
+            const bool vec = (p.Lk & 3) == 0;
+#pragma unroll
+            for (int kt = 0; kt < MAXT; ++kt) {
+                if (kt < nkt) {
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        const int key0 = kt * 32 + sub * 16 + 4 * g;
+                        float w4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w4[j] = expf(sk[kt][sub * 4 + j] - m_run) * inv_l;
+                        if (vec && key0 + 3 < p.Lk) {
+                            *reinterpret_cast<float4*>(ap + key0) = make_float4(w4[0], w4[1], w4[2], w4[3]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (key0 + j < p.Lk) ap[key0 + j] = w4[j];
+                        }
+                    }
+                }
+            }
+        }
+    } else if (!p.attn) {
         const int last_q = min(blockIdx.x * 64 + 63, p.Lq - 1);
         const int nlim = p.causal ? min(nkt, last_q / 32 + 1) : nkt;
         sweep(0, nlim, true, [&](int kt, const __bf16* kimg, const __bf16* vimg) { online(kt, kimg, vimg, true); });
@@ -523,7 +575,12 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
 template <int DH>
 int launch_wide(const estts_attention_args& a, hipStream_t st) {
     dim3 grid((a.Lq + 63) / 64, a.H, a.B);
-    if (a.precision == 3)
+    if (a.attn && a.Lk <= 128) {
+        if (a.precision == 3)
+            hipLaunchKernelGGL((attention_wide_kernel<DH, 2, 4>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((attention_wide_kernel<DH, 1, 4>), grid, dim3(256), 0, st, a);
+    } else if (a.precision == 3)
         hipLaunchKernelGGL((attention_wide_kernel<DH, 2>), grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((attention_wide_kernel<DH, 1>), grid, dim3(256), 0, st, a);
@@ -547,7 +604,8 @@ int launch(const estts_attention_args& a, hipStream_t st) {
     // variant: 0 = by launch size, 1 = 16-query workgroups, 2 = 64-query workgroups
     const long wide_wgs = (long)((a.Lq + 63) / 64) * a.H * a.B;
     // (at depth 128 the 16-query kernel needs more than 256 registers, one workgroup per CU: the shared-tile kernel wins earlier)
-    const long wide_min = DH >= 128 ? 192 : 512;
+    // (and so does its one-sweep form for weights over at most 128 keys: 100 x 100, B = 32: 12.4 us against 15.0)
+    const long wide_min = (DH >= 128 || (a.attn && a.Lk <= 128)) ? 192 : 512;
     if (a.variant == 2 || (a.variant == 0 && wide_wgs >= wide_min && a.Lk >= 64)) return launch_wide<DH>(a, st);
     // few workgroups and many key tiles (one utterance, depth 64): eight waves split the keys, three tiles each at 600 keys
     const long narrow_wgs = (long)((a.Lq + 15) / 16) * a.H * a.B;
