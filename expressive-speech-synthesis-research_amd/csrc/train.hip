@@ -337,17 +337,18 @@ struct RowStats {
     float mean, rstd;
 };
 
-__device__ __forceinline__ RowStats row_stats(const float4 (&v)[4], int nch, int lane, int dq, int D, float eps) {
+template <int NCH>
+__device__ __forceinline__ RowStats row_stats(const float4 (&v)[NCH], int lane, int dq, int D, float eps) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < nch && lane + 64 * i < dq) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 64 * i < dq) s += v[i].x + v[i].y + v[i].z + v[i].w;
     RowStats r;
     r.mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < nch && lane + 64 * i < dq) {
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 64 * i < dq) {
             const float a = v[i].x - r.mean, b = v[i].y - r.mean, c = v[i].z - r.mean, d = v[i].w - r.mean;
             q += a * a + b * b + c * c + d * d;
         }
@@ -366,52 +367,55 @@ __device__ __forceinline__ RowStats row_stats(const float4 (&v)[4], int nch, int
 __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
 
 // LayerNorm input gradient for one row: g = dout * gamma (in), xh = normalised input; returns rstd * (g - mean(g) - xh * mean(g xh))
-__device__ __forceinline__ void ln_bwd_row(float4 (&g)[4], const float4 (&xh)[4], int nch, int lane, int dq, int D, float rstd) {
+template <int NCH>
+__device__ __forceinline__ void ln_bwd_row(float4 (&g)[NCH], const float4 (&xh)[NCH], int lane, int dq, int D, float rstd) {
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < nch && lane + 64 * i < dq) {
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 64 * i < dq) {
             a += g[i].x + g[i].y + g[i].z + g[i].w;
             b += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
         }
     a = wave_sum(a) / (float)D;
     b = wave_sum(b) / (float)D;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < nch && lane + 64 * i < dq) F4_OP(g[i], rstd * (f4e(g[i], e) - a - f4e(xh[i], e) * b));
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 64 * i < dq) F4_OP(g[i], rstd * (f4e(g[i], e) - a - f4e(xh[i], e) * b));
 }
 
 constexpr int ROWNORM_SLOTS = 16;
 
+// NCH: float4 chunks per lane (D <= 256 NCH); the per-row arrays are sized by it, so D = 256 runs with a quarter of the
+// registers of D = 1024 and several times the waves in flight
+template <int NCH>
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bwd_args p) {
     __shared__ float red[4][1024];
     const estts_rownorm_args& f = p.f;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int dq = f.D >> 2;
-    const int nch = (dq + 63) >> 6;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 acc_ga[4], acc_ba[4], acc_gb[4], acc_bb[4], acc_dw[4];
+    float4 acc_ga[NCH], acc_ba[NCH], acc_gb[NCH], acc_bb[NCH], acc_dw[NCH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc_ga[i] = acc_ba[i] = acc_gb[i] = acc_bb[i] = acc_dw[i] = zero;
+    for (int i = 0; i < NCH; ++i) acc_ga[i] = acc_ba[i] = acc_gb[i] = acc_bb[i] = acc_dw[i] = zero;
     float acc_db = 0.f;
     const float keep = f.drop_rate > 0.f ? 1.0f / (1.0f - f.drop_rate) : 1.0f;
 
     for (int row = blockIdx.x * 4 + wave; row < f.M; row += gridDim.x * 4) {
-        float4 xh1[4], r[4], xh2[4], d[4];
+        float4 xh1[NCH], r[NCH], xh2[NCH], d[NCH];
         float rstd1 = 1.f, rstd2 = 1.f;
         // ---- recompute the forward pass
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             xh1[i] = r[i] = xh2[i] = d[i] = zero;
-            if (i < nch && lane + 64 * i < dq) r[i] = ld4(f.y + (long)row * f.ldy + (lane + 64 * i) * 4);
+            if (lane + 64 * i < dq) r[i] = ld4(f.y + (long)row * f.ldy + (lane + 64 * i) * 4);
         }
         if (f.ga) {
-            const RowStats s = row_stats(r, nch, lane, dq, f.D, f.eps);
+            const RowStats s = row_stats<NCH>(r, lane, dq, f.D, f.eps);
             rstd1 = s.rstd;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nch && lane + 64 * i < dq) {
+            for (int i = 0; i < NCH; ++i)
+                if (lane + 64 * i < dq) {
                     const int c = (lane + 64 * i) * 4;
                     const float4 ga = ld4(f.ga + c), ba = ld4(f.ba + c);
                     F4_OP(xh1[i], (f4e(r[i], e) - s.mean) * s.rstd);
@@ -419,11 +423,11 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
                 }
         }
         // r = act(a); km = dropout factor; s = r * km + x
-        float4 km[4];
+        float4 km[NCH];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NCH; ++i) {
             km[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (i < nch && lane + 64 * i < dq) {
+            if (lane + 64 * i < dq) {
                 const int c = (lane + 64 * i) * 4;
                 F4_OP(r[i], apply_act(f4e(r[i], e), f.act));
                 if (f.drop_rate > 0.f) F4_OP(km[i], dropout_keep(f.drop_seed, f.drop_site, row, c + e, f.drop_rate) ? keep : 0.0f);
@@ -434,15 +438,15 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
                 }
             }
         }
-        float4 out[4];
+        float4 out[NCH];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[i] = xh2[i];
+        for (int i = 0; i < NCH; ++i) out[i] = xh2[i];
         if (f.gb) {
-            const RowStats s = row_stats(xh2, nch, lane, dq, f.D, f.eps);
+            const RowStats s = row_stats<NCH>(xh2, lane, dq, f.D, f.eps);
             rstd2 = s.rstd;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nch && lane + 64 * i < dq) {
+            for (int i = 0; i < NCH; ++i)
+                if (lane + 64 * i < dq) {
                     const int c = (lane + 64 * i) * 4;
                     const float4 gb = ld4(f.gb + c), bb = ld4(f.bb + c);
                     F4_OP(xh2[i], (f4e(xh2[i], e) - s.mean) * s.rstd);
@@ -451,13 +455,13 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
         }
         // ---- gradient w.r.t. out
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (p.dout && i < nch && lane + 64 * i < dq) d[i] = ld4(p.dout + (long)row * p.lddout + (lane + 64 * i) * 4);
+        for (int i = 0; i < NCH; ++i)
+            if (p.dout && lane + 64 * i < dq) d[i] = ld4(p.dout + (long)row * p.lddout + (lane + 64 * i) * 4);
         if (p.ddot) {
             float dot = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nch && lane + 64 * i < dq) {
+            for (int i = 0; i < NCH; ++i)
+                if (lane + 64 * i < dq) {
                     const float4 w = ld4(f.dot_w + (lane + 64 * i) * 4);
                     dot += out[i].x * w.x + out[i].y * w.y + out[i].z * w.z + out[i].w * w.w;
                 }
@@ -465,8 +469,8 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
             float gm = dot > 0.f ? p.ddot[row] * f.dot_scale : 0.0f;
             if (f.dot_mask) gm *= 1.0f - f.dot_mask[row];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nch && lane + 64 * i < dq) {
+            for (int i = 0; i < NCH; ++i)
+                if (lane + 64 * i < dq) {
                     const float4 w = ld4(f.dot_w + (lane + 64 * i) * 4);
                     F4_OP(acc_dw[i], f4e(acc_dw[i], e) + gm * f4e(out[i], e));
                     F4_OP(d[i], f4e(d[i], e) + gm * f4e(w, e));
@@ -476,19 +480,19 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
         // ---- LNb
         if (f.gb) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nch && lane + 64 * i < dq) {
+            for (int i = 0; i < NCH; ++i)
+                if (lane + 64 * i < dq) {
                     const float4 gb = ld4(f.gb + (lane + 64 * i) * 4);
                     F4_OP(acc_gb[i], f4e(acc_gb[i], e) + f4e(d[i], e) * f4e(xh2[i], e));
                     F4_OP(acc_bb[i], f4e(acc_bb[i], e) + f4e(d[i], e));
                     F4_OP(d[i], f4e(d[i], e) * f4e(gb, e));
                 }
-            ln_bwd_row(d, xh2, nch, lane, dq, f.D, rstd2);
+            ln_bwd_row<NCH>(d, xh2, lane, dq, f.D, rstd2);
         }
         // ---- residual branch, dropout and activation
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < nch && lane + 64 * i < dq) {
+        for (int i = 0; i < NCH; ++i)
+            if (lane + 64 * i < dq) {
                 const int c = (lane + 64 * i) * 4;
                 if (p.dx) {
                     float4 o = d[i];
@@ -503,19 +507,19 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
         // ---- LNa
         if (f.ga) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nch && lane + 64 * i < dq) {
+            for (int i = 0; i < NCH; ++i)
+                if (lane + 64 * i < dq) {
                     const float4 ga = ld4(f.ga + (lane + 64 * i) * 4);
                     F4_OP(acc_ga[i], f4e(acc_ga[i], e) + f4e(d[i], e) * f4e(xh1[i], e));
                     F4_OP(acc_ba[i], f4e(acc_ba[i], e) + f4e(d[i], e));
                     F4_OP(d[i], f4e(d[i], e) * f4e(ga, e));
                 }
-            ln_bwd_row(d, xh1, nch, lane, dq, f.D, rstd1);
+            ln_bwd_row<NCH>(d, xh1, lane, dq, f.D, rstd1);
         }
         if (p.dy) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nch && lane + 64 * i < dq) st4(p.dy + (long)row * p.lddy + (lane + 64 * i) * 4, d[i]);
+            for (int i = 0; i < NCH; ++i)
+                if (lane + 64 * i < dq) st4(p.dy + (long)row * p.lddy + (lane + 64 * i) * 4, d[i]);
         }
     }
 
@@ -523,13 +527,13 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
     // ROWNORM_SLOTS copies in the workspace when there is one (hundreds of workgroups adding to one address serialise at
     // ~0.1 us each); rownorm_bwd_finish_kernel adds the copies up
     const int slot = blockIdx.x % ROWNORM_SLOTS;
-    auto flush = [&](const float4 (&acc)[4], float* dst, int which) {
+    auto flush = [&](const float4 (&acc)[NCH], float* dst, int which) {
         if (dst == nullptr) return;  // uniform across the workgroup
         if (p.ws) dst = p.ws + ((long)slot * 6 + which) * 1024;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < nch && lane + 64 * i < dq) *reinterpret_cast<float4*>(&red[wave][(lane + 64 * i) * 4]) = acc[i];
+        for (int i = 0; i < NCH; ++i)
+            if (lane + 64 * i < dq) *reinterpret_cast<float4*>(&red[wave][(lane + 64 * i) * 4]) = acc[i];
         __syncthreads();
         for (int c = threadIdx.x; c < f.D; c += 256) atomic_add_f32(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
     };
@@ -747,11 +751,16 @@ extern "C" int estts_rownorm_bwd(const estts_rownorm_bwd_args* args, void* strea
                         (!a.dx || (a.lddx & 3) == 0),
                     "estts_rownorm_bwd: ld not multiple of 4");
     ESTTS_CHECK_ARG(!a.dx || f.x, "estts_rownorm_bwd: dx without a residual input");
+    const int nch = (f.D / 4 + 63) / 64;
+    // workgroups the instantiation keeps resident (four per CU at D <= 256, two above): rows beyond that are looped over
+    const int cap = nch == 1 ? 1024 : 512;
     int grid = (f.M + 3) / 4;
-    if (grid > 512) grid = 512;
+    if (grid > cap) grid = cap;
     estts_rownorm_bwd_args k = a;
     if (k.ws && (k.ws_bytes < (int64_t)ROWNORM_SLOTS * 6 * 1024 * 4 || grid <= 32)) k.ws = nullptr;
-    hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    if (nch == 1) hipLaunchKernelGGL(rownorm_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    else if (nch == 2) hipLaunchKernelGGL(rownorm_bwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(rownorm_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
     if (k.ws) {
         ESTTS_CHECK_LAUNCH("estts_rownorm_bwd");
         hipLaunchKernelGGL(rownorm_bwd_finish_kernel, dim3((f.D + 255) / 256, 6), dim3(256), 0, (hipStream_t)stream, k);
