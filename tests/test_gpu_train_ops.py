@@ -149,6 +149,8 @@ def test_attention_backward_strided_qkv_buffer(T):
     (64, True, 'relu', False, False, 0.0, False),   # duration predictor inner conv
     (128, True, 'relu', True, True, 0.0, True),     # duration predictor last stage + Dense(1, relu)
     (80, False, 'tanh', True, False, 0.25, False),
+    (384, True, None, True, True, 0.0, True),       # two chunks per lane, the second half full
+    (1024, True, 'relu', True, True, 0.1, False),   # four chunks per lane: the widest instantiation
 ])
 def test_rownorm_forward_backward(T, D, use_a, act, use_res, use_b, rate, dot):
     from estts import ops
