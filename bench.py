@@ -383,8 +383,12 @@ def main():
 
     from estts import parallel
     rank, world, local_rank = parallel.env_ranks()
-    torch.cuda.set_device(local_rank)
-    parallel.init_distributed('nccl')
+    # (ESTTS_DIST_BACKEND=gloo with more ranks than GPUs rehearses the multi-rank path on a one-GPU box: the replica workloads
+    # and train_wavernn run that way; gloo's host-staged collectives on GPU tensors stall under the ForwardTransformer trainer's
+    # larger exchange, which therefore cannot be rehearsed like this.  The driver's runs have one GPU per rank and use RCCL.)
+    backend = os.environ.get('ESTTS_DIST_BACKEND', 'nccl')
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank)
+    parallel.init_distributed(backend)
     dist = None
     if world > 1:
         import torch.distributed as dist
