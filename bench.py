@@ -383,9 +383,9 @@ def main():
 
     from estts import parallel
     rank, world, local_rank = parallel.env_ranks()
-    # (ESTTS_DIST_BACKEND=gloo with more ranks than GPUs rehearses the multi-rank path on a one-GPU box: the replica workloads
-    # and train_wavernn run that way; gloo's host-staged collectives on GPU tensors stall under the ForwardTransformer trainer's
-    # larger exchange, which therefore cannot be rehearsed like this.  The driver's runs have one GPU per rank and use RCCL.)
+    # (ESTTS_DIST_BACKEND=gloo with more ranks than GPUs rehearses the multi-rank paths on a one-GPU box; with gloo the
+    # ForwardTransformer trainer exchanges its gradients after the backward pass instead of overlapped with it, see
+    # parallel.GradientOverlap.  The driver's runs have one GPU per rank and use RCCL.)
     backend = os.environ.get('ESTTS_DIST_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank)
     parallel.init_distributed(backend)

@@ -108,6 +108,10 @@ class GradientOverlap:
         self.flat, self.bucket, self.group, self.comm = flat, bucket_elems, group, comm_stream
         self.min_elems = bucket_elems // 4 if min_elems is None else min_elems
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # gloo stages device buffers through host threads of its own; collectives issued while kernels are still queued
+        # stalled two ranks sharing one GPU, so with gloo on device memory the whole exchange waits for finish()
+        self.defer = self.active and flat.is_cuda and dist.get_backend(group) != 'nccl'
+        self.final = False
         self.hi = flat.numel()
         self.works = []
         self.calls = []          # (lo, hi) of every collective issued, for tests
@@ -115,6 +119,8 @@ class GradientOverlap:
     def ready(self, lo):
         lo = max(0, min(int(lo), self.hi))
         if not self.active or lo >= self.hi or (lo > 0 and self.hi - lo < self.min_elems):
+            return
+        if self.defer and not self.final:
             return
         ranges = [(lo + a, lo + b) for a, b in bucket_ranges(self.hi - lo, self.bucket)]
         if self.flat.is_cuda and self.comm is not None:
@@ -130,6 +136,9 @@ class GradientOverlap:
         if not self.active:
             return
         self.min_elems = 0
+        if self.defer:
+            self.final, self.comm = True, None
+            torch.cuda.current_stream(self.flat.device).synchronize()
         self.ready(0)
         if self.flat.is_cuda and self.comm is not None:
             with torch.cuda.stream(self.comm):

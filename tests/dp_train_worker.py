@@ -1,0 +1,65 @@
+"""One rank of the data-parallel ForwardTransformer training check (started by tests/test_gpu_dp_train.py under
+torch.distributed.run, every rank on GPU 0 with the gloo backend).
+
+Each rank trains on a batch of its own.  Checked: the gradient buffer after the step equals the sum over ranks of the
+gradients the ranks compute alone on the same batches; the weights after the Adam update are identical on every rank,
+also after a second step; the exchange was cut into more than one collective."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+
+import estts  # noqa: E402,F401
+from estts import parallel, weights  # noqa: E402
+from estts.forward_training import ForwardTransformerTrainer  # noqa: E402
+from test_gpu_training import batch, small_cfg  # noqa: E402
+
+
+def gathered(t):
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return out
+
+
+def main():
+    rank, world, _ = parallel.env_ranks()
+    torch.cuda.set_device(0)
+    parallel.init_distributed('gloo')
+    solo = [dist.new_group([r]) for r in range(world)][rank]
+    cfg = small_cfg(0.0)
+    w = weights.init_forward_transformer(cfg, seed=7)
+    data = [batch(cfg, 3, 19, seed=10 + rank), batch(cfg, 2, 23, seed=20 + rank)]
+
+    alone = ForwardTransformerTrainer(w, cfg, process_group=solo)
+    assert alone.world == 1
+    alone.train_step(*data[0])
+    expected = sum(gathered(alone.store.grad.cpu()))
+
+    model = ForwardTransformerTrainer(w, cfg, bucket_mb=0.5)
+    assert model.world == world
+    assert model.store.flat.numel() > 2 * model.bucket_elems
+    model.train_step(*data[0])
+    got = model.store.grad.cpu()
+    # two runs of one step differ a little (float atomics order the column sums differently, and a ReLU gate next to
+    # its kink may then fall the other way), so the comparison is over the whole vector; a missing rank gives ~0.7
+    scale = float(expected.norm())
+    err = float((got - expected).norm())
+    assert err <= 5e-3 * scale, (err, scale)
+    different = float((got - alone.store.grad.cpu()).norm())
+    assert different > 0.1 * scale, different          # the ranks really had different gradients
+    model.train_step(*data[1])
+    flats = gathered(model.store.flat.cpu())
+    assert all(torch.equal(flats[0], f) for f in flats[1:])
+    assert not torch.equal(flats[0], torch.from_numpy(np.asarray(alone.store.flat.cpu())))
+    print(f'rank {rank}: data-parallel step OK (gradient error {err:.2e} of {scale:.2e})', flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
