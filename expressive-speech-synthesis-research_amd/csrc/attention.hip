@@ -345,9 +345,25 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
     const int wave = tid >> 6;
     const int i = lane & 15;
     const int g = lane >> 4;
-    const int h = blockIdx.y;
-    const int b = blockIdx.z;
-    const int qi = blockIdx.x * 64 + wave * 16 + i;
+    // Linear workgroup id -> (query tile, batch x head).  Workgroups go to the eight XCDs round robin, so with B H a
+    // multiple of 8 every XCD gets B H / 8 whole (batch, head) pairs (their K / V stay in that XCD's L2) and the same mix
+    // of query tiles; the last query tiles come first: under a causal mask they sweep the most keys, and the short ones
+    // then fill the gaps the long ones leave.  (Without a mask, going through an XCD's pairs one after the other instead
+    // measured 2 % slower: 600 x 600 with weights, B = 32.)
+    const int BH = p.B * p.H;
+    const int nqt = (p.Lq + 63) / 64;
+    int bh, qt;
+    if ((BH & 7) == 0) {
+        const int per = BH >> 3, slot = blockIdx.x >> 3;
+        bh = (blockIdx.x & 7) * per + slot % per;
+        qt = nqt - 1 - slot / per;
+    } else {
+        bh = blockIdx.x % BH;
+        qt = nqt - 1 - blockIdx.x / BH;
+    }
+    const int h = bh % p.H;
+    const int b = bh / p.H;
+    const int qi = qt * 64 + wave * 16 + i;
     const int qrow = min(qi, p.Lq - 1);
     const float* qp = p.q + ((long)b * p.Lq + qrow) * p.ldq + h * DH + 8 * g;
     const long kvb = p.kv_shared ? 0 : b;
@@ -527,7 +543,7 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
             }
         }
     } else if (!p.attn) {
-        const int last_q = min(blockIdx.x * 64 + 63, p.Lq - 1);
+        const int last_q = min(qt * 64 + 63, p.Lq - 1);
         const int nlim = p.causal ? min(nkt, last_q / 32 + 1) : nkt;
         sweep(0, nlim, true, [&](int kt, const __bf16* kimg, const __bf16* vimg) { online(kt, kimg, vimg, true); });
         if (nlim < nkt) {
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
 
 template <int DH>
 int launch_wide(const estts_attention_args& a, hipStream_t st) {
-    dim3 grid((a.Lq + 63) / 64, a.H, a.B);
+    dim3 grid((unsigned)((long)((a.Lq + 63) / 64) * a.H * a.B));
     if (a.attn && a.Lk <= 128) {
         if (a.precision == 3)
             hipLaunchKernelGGL((attention_wide_kernel<DH, 2, 4>), grid, dim3(256), 0, st, a);
@@ -631,6 +647,7 @@ extern "C" int estts_attention(const estts_attention_args* args, void* stream) {
     ESTTS_CHECK_ARG(a.q && a.k && a.v && a.ctx, "estts_attention: null q/k/v/ctx");
     ESTTS_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "estts_attention: bad shape");
     ESTTS_CHECK_ARG(a.B <= 65535 && a.H <= 65535, "estts_attention: B / H exceed grid limits");
+    ESTTS_CHECK_ARG((long)((a.Lq + 15) / 16) * a.H * a.B < (1L << 31), "estts_attention: too many workgroups");
     ESTTS_CHECK_ARG(a.precision == 1 || a.precision == 3, "estts_attention: precision must be 1 or 3");
     ESTTS_CHECK_ARG((a.ldq & 3) == 0 && (a.ldk & 3) == 0 && (a.ldv & 3) == 0 && (a.ldo & 3) == 0,
                     "estts_attention: ld not multiple of 4");

@@ -11,6 +11,7 @@
 //   out^T   += (swept K or Q tile)^T (ds_read_b64_tr_b16)  x  dS           -> dQ^T or dK^T
 //   dV^T    += (swept dctx tile)^T  x  P                                   (OWN_Q = false only)
 // Partial results of the four waves are summed through LDS.
+// Launches with at least 192 workgroups of 64 owned rows use the batched variant further down instead.
 #include "common.h"
 
 namespace {
@@ -96,11 +97,25 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const estts_attentio
     const int wave = threadIdx.x >> 6;
     const int i = lane & 15;
     const int g = lane >> 4;
-    const int h = blockIdx.y;
-    const int b = blockIdx.z;
     const int L_own = OWN_Q ? p.Lq : p.Lk;
     const int L_oth = OWN_Q ? p.Lk : p.Lq;
-    const int oi = blockIdx.x * 16 + i;
+    // Linear workgroup id -> (batch x head, tile of 16 owned rows).  Workgroups go to the eight XCDs round robin: with
+    // B H a multiple of 8 every XCD works through B H / 8 whole (batch, head) pairs one after the other, so the other
+    // side's rows and the neighbouring 64-byte column blocks of the weights are found in that XCD's L2.
+    const int BH = p.B * p.H;
+    const int ntile = (L_own + 15) / 16;
+    int bh, tile;
+    if ((BH & 7) == 0) {
+        const int slot = blockIdx.x >> 3;
+        bh = (blockIdx.x & 7) * (BH >> 3) + slot / ntile;
+        tile = slot % ntile;
+    } else {
+        bh = blockIdx.x / ntile;
+        tile = blockIdx.x % ntile;
+    }
+    const int h = bh % p.H;
+    const int b = bh / p.H;
+    const int oi = tile * 16 + i;
     const int orow = min(oi, L_own - 1);
     const bool own_ok = oi < L_own;
 
@@ -245,16 +260,208 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const estts_attentio
     }
 }
 
+// Batched variant: a workgroup owns 64 rows of one (batch, head), 16 per wave, and the four waves share every staged tile
+// of the swept side (both operands of a tile in one double-buffered LDS image pair, one barrier per tile), so a swept
+// tile is fetched from L2 and split once per 64 owned rows instead of once per 16: at batch 32 the kernel above is bound
+// by exactly that traffic.  Every wave keeps the whole sum of its own rows, so nothing is merged at the end.  The weights
+// and delta of the next tile are fetched together with its rows, one tile ahead of their use.
+template <int DH, int NS, bool OWN_Q>
+__global__ __launch_bounds__(256) void attention_bwd_wide_kernel(const estts_attention_bwd_args p) {
+    constexpr int KS = DH / 32;
+    constexpr int NT = DH / 16;
+    constexpr int LD = DH + 8;
+    constexpr int IMG = 32 * LD;
+    constexpr int LPR = DH / 4;        // threads per tile row (one float4 each)
+    constexpr int RPP = 256 / LPR;     // tile rows per pass of the workgroup
+    constexpr int NLD = 32 / RPP;      // passes per 32-row tile
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2][2][NS][IMG];   // [buffer][dP operand, out operand][hi, lo]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int i = lane & 15;
+    const int g = lane >> 4;
+    const int L_own = OWN_Q ? p.Lq : p.Lk;
+    const int L_oth = OWN_Q ? p.Lk : p.Lq;
+    const int BH = p.B * p.H;          // workgroup id -> (batch x head, tile): as in the kernel above
+    const int ntile = (L_own + 63) / 64;
+    int bh, tile;
+    if ((BH & 7) == 0) {
+        const int slot = blockIdx.x >> 3;
+        bh = (blockIdx.x & 7) * (BH >> 3) + slot / ntile;
+        tile = slot % ntile;
+    } else {
+        bh = blockIdx.x / ntile;
+        tile = blockIdx.x % ntile;
+    }
+    const int h = bh % p.H;
+    const int b = bh / p.H;
+    const int oi = tile * 64 + wave * 16 + i;
+    const int orow = min(oi, L_own - 1);
+    const bool own_ok = oi < L_own;
+
+    const float* rp = OWN_Q ? p.dctx + ((long)b * p.Lq + orow) * p.lddo + h * DH + 8 * g
+                            : p.v + ((long)b * p.Lk + orow) * p.ldv + h * DH + 8 * g;
+    const float* sbase = OWN_Q ? p.v + (long)b * p.Lk * p.ldv + h * DH : p.dctx + (long)b * p.Lq * p.lddo + h * DH;
+    const int s_ld = OWN_Q ? p.ldv : p.lddo;
+    const float* obase = OWN_Q ? p.k + (long)b * p.Lk * p.ldk + h * DH : p.q + (long)b * p.Lq * p.ldq + h * DH;
+    const int o_ld = OWN_Q ? p.ldk : p.ldq;
+    const float* P = p.attn + ((long)b * p.H + h) * p.Lq * p.Lk;
+    const float* delta = p.delta + ((long)b * p.H + h) * p.Lq;
+    const float scale = 1.0f / sqrtf((float)DH);
+    const float own_delta = OWN_Q ? delta[orow] : 0.0f;
+    const bool vec = OWN_Q && (p.Lk & 3) == 0;
+
+    Frag<NS> rf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float t[8];
+        *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(rp + ks * 32);
+        *reinterpret_cast<float4*>(t + 4) = *reinterpret_cast<const float4*>(rp + ks * 32 + 4);
+        rf[ks] = make_frag<NS>(t);
+    }
+
+    const int ld_row = tid / LPR;
+    const int ld_col = (tid % LPR) * 4;
+    auto load_tile = [&](const float* base, int ld, int kt, float4 (&x)[NLD]) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int r = min(kt * 32 + j * RPP + ld_row, L_oth - 1);
+            x[j] = *reinterpret_cast<const float4*>(base + (long)r * ld + ld_col);
+        }
+    };
+    auto stage_tile = [&](const float4 (&x)[NLD], __bf16* dst) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            bf16x4 hi, lo;
+            split_bf16x4(x[j], hi, lo);
+            const int o = (j * RPP + ld_row) * LD + ld_col;
+            *reinterpret_cast<bf16x4*>(dst + o) = hi;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(dst + IMG + o) = lo;
+        }
+    };
+    // weights of this lane's row against the 8 swept rows it meets in tile kt (0 outside the map), and their delta
+    auto load_p = [&](int kt, float (&pp)[8], float (&dl)[8]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int oth0 = kt * 32 + sub * 16 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pp[sub * 4 + j] = 0.0f;
+            if (own_ok) {
+                if (vec && oth0 + 3 < L_oth) {
+                    const float4 t = *reinterpret_cast<const float4*>(P + (long)orow * p.Lk + oth0);
+                    pp[sub * 4] = t.x, pp[sub * 4 + 1] = t.y, pp[sub * 4 + 2] = t.z, pp[sub * 4 + 3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (oth0 + j < L_oth) pp[sub * 4 + j] = OWN_Q ? P[(long)orow * p.Lk + oth0 + j] : P[(long)(oth0 + j) * p.Lk + orow];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dl[sub * 4 + j] = OWN_Q ? own_delta : delta[min(oth0 + j, L_oth - 1)];
+        }
+    };
+    // out^T (16-feature tiles x owned rows) += (staged tile)^T x operand
+    auto accumulate = [&](f32x4* o, const Frag<NS>& bf, const __bf16* img) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            Frag<NS> af;
+            const int o0 = (4 * g + (i >> 2)) * LD + nt * 16 + 4 * (i & 3);
+            af.v[0] = tr_read_pair(img + o0, img + o0 + 16 * LD);
+            if (NS == 2) af.v[NS - 1] = tr_read_pair(img + IMG + o0, img + IMG + o0 + 16 * LD);
+            o[nt] = mfma_split<NS>(af, bf, o[nt]);
+        }
+    };
+
+    f32x4 o1[NT], o2[OWN_Q ? 1 : NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < (OWN_Q ? 1 : NT); ++nt) o2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (L_oth + 31) / 32;
+    float4 sx[NLD], ox[NLD];
+    float pn[8], dn[8];
+    load_tile(sbase, s_ld, 0, sx);
+    load_tile(obase, o_ld, 0, ox);
+    load_p(0, pn, dn);
+    int par = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __bf16* simg = &smem[par][0][0][0];
+        __bf16* oimg = &smem[par][1][0][0];
+        stage_tile(sx, simg);
+        stage_tile(ox, oimg);
+        float pv[8], dl[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = pn[e], dl[e] = dn[e];
+        __syncthreads();   // also: every wave is done with the other buffer, which the next tile will overwrite
+        if (kt + 1 < nkt) {
+            load_tile(sbase, s_ld, kt + 1, sx);
+            load_tile(obase, o_ld, kt + 1, ox);
+            load_p(kt + 1, pn, dn);
+        }
+        float dsv[8];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<NS> sf;
+                const int o = (sub * 16 + i) * LD + ks * 32 + g * 8;
+                sf.v[0] = *reinterpret_cast<const bf16x8*>(simg + o);
+                if (NS == 2) sf.v[NS - 1] = *reinterpret_cast<const bf16x8*>(simg + IMG + o);
+                acc = mfma_split<NS>(sf, rf[ks], acc);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dsv[sub * 4 + j] = pv[sub * 4 + j] * (acc[j] - dl[sub * 4 + j]) * scale;
+        }
+        if constexpr (!OWN_Q) {
+            const Frag<NS> pf = make_frag<NS>(pv);
+            accumulate(o2, pf, simg);
+        }
+        const Frag<NS> dsf = make_frag<NS>(dsv);
+        accumulate(o1, dsf, oimg);
+        par ^= 1;
+    }
+
+    if (own_ok) {
+        auto write = [&](const f32x4* o, float* dst, int ld) {
+            float* op = dst + ((long)b * L_own + oi) * ld + h * DH + 4 * g;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<float4*>(op + nt * 16) = make_float4(o[nt][0], o[nt][1], o[nt][2], o[nt][3]);
+        };
+        if constexpr (OWN_Q) {
+            write(o1, p.dq, p.lddq);
+        } else {
+            write(o1, p.dk, p.lddk);
+            write(o2, p.dv, p.lddv);
+        }
+    }
+}
+
+template <int DH, bool OWN_Q>
+void launch_side(const estts_attention_bwd_args& a, hipStream_t st) {
+    const int L_own = OWN_Q ? a.Lq : a.Lk;
+    const long BH = (long)a.H * a.B;
+    const long wide = (long)((L_own + 63) / 64) * BH;
+    if (wide >= 192) {   // enough 64-row workgroups to fill the chip
+        if (a.precision == 3)
+            hipLaunchKernelGGL((attention_bwd_wide_kernel<DH, 2, OWN_Q>), dim3((unsigned)wide), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((attention_bwd_wide_kernel<DH, 1, OWN_Q>), dim3((unsigned)wide), dim3(256), 0, st, a);
+    } else {
+        const dim3 grid((unsigned)((long)((L_own + 15) / 16) * BH));
+        if (a.precision == 3)
+            hipLaunchKernelGGL((attention_bwd_kernel<DH, 2, OWN_Q>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((attention_bwd_kernel<DH, 1, OWN_Q>), grid, dim3(256), 0, st, a);
+    }
+}
+
 template <int DH>
 int launch(const estts_attention_bwd_args& a, hipStream_t st) {
-    dim3 gq((a.Lq + 15) / 16, a.H, a.B), gk((a.Lk + 15) / 16, a.H, a.B);
-    if (a.precision == 3) {
-        hipLaunchKernelGGL((attention_bwd_kernel<DH, 2, true>), gq, dim3(256), 0, st, a);
-        hipLaunchKernelGGL((attention_bwd_kernel<DH, 2, false>), gk, dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((attention_bwd_kernel<DH, 1, true>), gq, dim3(256), 0, st, a);
-        hipLaunchKernelGGL((attention_bwd_kernel<DH, 1, false>), gk, dim3(256), 0, st, a);
-    }
+    launch_side<DH, true>(a, st);
+    launch_side<DH, false>(a, st);
     ESTTS_CHECK_LAUNCH("estts_attention_bwd");
     return 0;
 }
@@ -267,6 +474,7 @@ extern "C" int estts_attention_bwd(const estts_attention_bwd_args* args, void* s
     ESTTS_CHECK_ARG(a.q && a.k && a.v && a.ctx && a.dctx && a.attn && a.delta && a.dq && a.dk && a.dv, "estts_attention_bwd: null pointer");
     ESTTS_CHECK_ARG(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0 && a.B <= 65535 && a.H <= 65535, "estts_attention_bwd: bad shape");
     ESTTS_CHECK_ARG(a.precision == 1 || a.precision == 3, "estts_attention_bwd: precision must be 1 or 3");
+    ESTTS_CHECK_ARG((long)((std::max(a.Lq, a.Lk) + 15) / 16) * a.H * a.B < (1L << 31), "estts_attention_bwd: too many workgroups");
     const int hd = a.H * a.depth;
     ESTTS_CHECK_ARG(((a.ldq | a.ldk | a.ldv | a.ldo | a.lddo | a.lddq | a.lddk | a.lddv) & 3) == 0, "estts_attention_bwd: ld not multiple of 4");
     ESTTS_CHECK_ARG(a.ldq >= hd && a.ldk >= hd && a.ldv >= hd && a.ldo >= hd && a.lddo >= hd && a.lddq >= hd && a.lddk >= hd && a.lddv >= hd,

@@ -172,7 +172,8 @@ def test_attention(B, H, Lq, Lk, dh, causal, masked, precision, tol):
 
 @pytest.mark.parametrize('B,H,Lq,Lk,dh,causal,masked,first_masked', [
     (2, 2, 150, 150, 64, False, True, False), (2, 2, 150, 150, 64, True, True, False), (1, 2, 130, 130, 64, True, False, True),
-    (2, 1, 70, 45, 32, False, True, False), (1, 2, 65, 201, 128, False, False, False), (2, 2, 200, 200, 32, True, False, True)])
+    (2, 1, 70, 45, 32, False, True, False), (1, 2, 65, 201, 128, False, False, False), (2, 2, 200, 200, 32, True, False, True),
+    (4, 2, 150, 150, 64, True, True, False), (8, 4, 130, 97, 64, False, True, False), (2, 4, 330, 330, 64, True, False, True)])
 @pytest.mark.parametrize('with_weights', [False, True])
 def test_attention_64_query_variant(B, H, Lq, Lk, dh, causal, masked, first_masked, with_weights):
     """The batched kernel (64 queries per workgroup, shared K / V tiles), forced with variant=2: ragged Lq / Lk, key

@@ -85,7 +85,12 @@ def test_wgrad_large_rows_many_splits(T):
     assert rel_err(dw, x.T @ dy) < 3e-5
 
 
-@pytest.mark.parametrize('B,H,Lq,Lk,depth', [(2, 2, 37, 37, 64), (1, 4, 50, 21, 32), (2, 1, 16, 70, 128)])
+@pytest.mark.parametrize('B,H,Lq,Lk,depth', [(2, 2, 37, 37, 64), (1, 4, 50, 21, 32), (2, 1, 16, 70, 128), (4, 2, 37, 53, 64),
+                                            (4, 4, 70, 40, 32),
+                                            # enough 64-row workgroups for the batched kernel: on both sides, on the query
+                                            # side only, on the key side only, and with Lk not a multiple of 4
+                                            (8, 4, 400, 400, 64), (3, 4, 1030, 70, 32), (3, 4, 50, 1030, 128),
+                                            (16, 4, 200, 203, 128)])
 def test_attention_backward(T, B, H, Lq, Lk, depth):
     from estts import ops
     rng = np.random.default_rng(Lq * 7 + Lk)
@@ -117,11 +122,11 @@ def test_attention_backward(T, B, H, Lq, Lk, depth):
     assert rel_err(dv, vt.grad) < 1e-4
 
 
-def test_attention_backward_strided_qkv_buffer(T):
+@pytest.mark.parametrize('B,H,L,depth', [(2, 2, 45, 32), (16, 4, 200, 32)])
+def test_attention_backward_strided_qkv_buffer(T, B, H, L, depth):
     """q, k, v and their gradients as column blocks of one [M, 3d] buffer (the fused QKV projection layout)."""
     from estts import ops
     rng = np.random.default_rng(3)
-    B, H, L, depth = 2, 2, 45, 32
     d = H * depth
     qkv = rng.normal(size=(B * L, 3 * d))
     dctx = rng.normal(size=(B * L, d))
