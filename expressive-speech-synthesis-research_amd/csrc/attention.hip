@@ -21,6 +21,11 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
+// exp() of softmax terms (arguments <= 0, -inf included): v_exp_f32 of x log2(e).  Rounding the product costs |x| 2^-24
+// relative (1e-6 at a weight of 1e-9); the range reduction and fix-ups of expf() were a third of the vector
+// instructions of a key tile.
+__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 template <int NS>
 struct Frag {
     bf16x8 v[NS];
@@ -173,13 +178,13 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        const float alpha = exp_neg(m_run - m_new);  // exp(-inf) = 0 on the first tile
         float pv[8], psum = 0.0f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float e = expf(s[sub][j] - m_new);
+                const float e = exp_neg(s[sub][j] - m_new);
                 pv[sub * 4 + j] = e;
                 psum += e;
             }
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
     float sc[NW], l_all = 0.0f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-        sc[w] = expf(mg[w * MERGE_FLOATS + NT * 256 + lane] - m_all);
+        sc[w] = exp_neg(mg[w * MERGE_FLOATS + NT * 256 + lane] - m_all);
         l_all += mg[w * MERGE_FLOATS + NT * 256 + 64 + lane] * sc[w];
     }
     const float inv_l = 1.0f / l_all;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
                         const int key0 = kt * 32 + sub * 16 + 4 * g;
                         float w4[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w4[j] = expf(sk[it][sub * 4 + j] - m_all) * inv_l;
+                        for (int j = 0; j < 4; ++j) w4[j] = exp_neg(sk[it][sub * 4 + j] - m_all) * inv_l;
                         if (vec && key0 + 3 < p.Lk) {
                             *reinterpret_cast<float4*>(ap + key0) = make_float4(w4[0], w4[1], w4[2], w4[3]);
                         } else {
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
                     const int key0 = kt * 32 + sub * 16 + 4 * g;
                     float w4[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w4[j] = expf(s[sub][j] - m_all) * inv_l;
+                    for (int j = 0; j < 4; ++j) w4[j] = exp_neg(s[sub][j] - m_all) * inv_l;
                     if (vec && key0 + 3 < p.Lk) {
                         *reinterpret_cast<float4*>(ap + key0) = make_float4(w4[0], w4[1], w4[2], w4[3]);
                     } else {
@@ -471,11 +476,11 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first tile
+        const float alpha = exp_neg(m_run - m_new);  // exp(-inf) = 0 on the first tile
         float pv[8], psum = 0.0f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            pv[e] = expf(s[e] - m_new);
+            pv[e] = exp_neg(s[e] - m_new);
             psum += pv[e];
         }
         psum += __shfl_xor(psum, 16, 64);
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
                         const int key0 = kt * 32 + sub * 16 + 4 * g;
                         float w4[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w4[j] = expf(sk[kt][sub * 4 + j] - m_run) * inv_l;
+                        for (int j = 0; j < 4; ++j) w4[j] = exp_neg(sk[kt][sub * 4 + j] - m_run) * inv_l;
                         if (vec && key0 + 3 < p.Lk) {
                             *reinterpret_cast<float4*>(ap + key0) = make_float4(w4[0], w4[1], w4[2], w4[3]);
                         } else {
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
             float s[8], pv[8];
             scores(kt, kimg, s);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pv[e] = expf(s[e] - m_run) * inv_l;
+            for (int e = 0; e < 8; ++e) pv[e] = exp_neg(s[e] - m_run) * inv_l;
             if (qi < p.Lq) {
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub) {
