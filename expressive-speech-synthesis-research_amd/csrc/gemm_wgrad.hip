@@ -6,7 +6,7 @@
 // [32][64] and the dY tile [32][64] are read with coalesced float4 loads (one step ahead), split into bf16 hi (+ lo)
 // and staged in LDS with 144-byte rows; every operand fragment then comes from the transposing ds_read_b64_tr_b16
 // (4 rows x 16 columns per 16-lane group, delivered column-per-lane).  Both operands use the same slot <-> row
-// permutation, so the product needs no reordering.  Row ranges are spread over gridDim.z and the partial tiles are
+// permutation, so the product needs no reordering.  Row ranges are spread over the grid and the partial tiles are
 // added to dW with hardware float atomics.
 #include "common.h"
 #include "a_operand.h"
@@ -28,7 +28,8 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const __bf16* p0, const __bf16* p
 
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, const float* dY, const int lddy, float* dW,
-                                                    const int lddw, const int rows_per_split, float* db) {
+                                                    const int lddw, const int rows_per_split, float* db, const int ktiles,
+                                                    const int ntiles, const int nsplits) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][32 * LD];
     __shared__ __attribute__((aligned(16))) __bf16 Ys[2][NS][32 * LD];
@@ -38,8 +39,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     const int wave = tid >> 6;
     const int wk = wave >> 1, wn = wave & 1;
     const int i16 = lane & 15, g = lane >> 4;
-    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int m_begin = blockIdx.z * rows_per_split;
+    // Workgroups go to the eight XCDs round robin.  Every XCD takes a contiguous eighth of the (row range, n tile, k tile)
+    // order, k fastest: the tiles of one row range read the same A and dY rows, which are then fetched into one L2 instead
+    // of all eight.
+    const int per_xcd = gridDim.x >> 3;
+    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= ktiles * ntiles * nsplits) return;   // padding of the grid to a multiple of 8 (uniform over the workgroup)
+    const int kx = vid % ktiles;
+    const int k0 = kx * 64, n0 = (vid / ktiles) % ntiles * 64;
+    const int m_begin = vid / (ktiles * ntiles) * rows_per_split;
     const int m_end = min(m_begin + rows_per_split, ga.M);
 
     const int chunk = tid & 15;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     }
 
     // bias gradient: the workgroups of the first K tile add up the dY rows they staged anyway
-    if (db != nullptr && blockIdx.x == 0) {   // uniform over the workgroup
+    if (db != nullptr && kx == 0) {   // uniform over the workgroup
         __syncthreads();                      // the staging buffers are dead
         float* red = reinterpret_cast<float*>(&As[0][0][0]);   // [16 row lanes][64 columns]
         *reinterpret_cast<float4*>(red + r0 * 64 + chunk * 4) = bsum;
@@ -219,11 +227,16 @@ extern "C" int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream) {
     const int steps = (a.M + 31) / 32;
     const int rows_per_split = ((steps + splits - 1) / splits) * 32;
     splits = (a.M + rows_per_split - 1) / rows_per_split;
-    dim3 grid((a.K + 63) / 64, (a.N + 63) / 64, splits);
+    const int ktiles = (a.K + 63) / 64, ntiles = (a.N + 63) / 64;
+    const long total = (long)ktiles * ntiles * splits;
+    ESTTS_CHECK_ARG(total < (1L << 30), "estts_gemm_wgrad: too many workgroups");
+    dim3 grid((unsigned)((total + 7) / 8 * 8));
     if (a.precision == 3)
-        hipLaunchKernelGGL((wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db);
+        hipLaunchKernelGGL((wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
+                           ktiles, ntiles, splits);
     else
-        hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db);
+        hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
+                           ktiles, ntiles, splits);
     ESTTS_CHECK_LAUNCH("estts_gemm_wgrad");
     return 0;
 }

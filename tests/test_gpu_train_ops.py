@@ -38,7 +38,8 @@ def conv_ref(x, kernel, bias, taps, lpad, seg):
     return (y + bias).reshape(B * seg, -1)
 
 
-@pytest.mark.parametrize('taps,lpad,cin,N,B,seg', [(1, 0, 72, 40, 1, 50), (3, 1, 24, 52, 3, 37), (5, 2, 80, 64, 2, 33), (5, 4, 16, 20, 2, 19)])
+@pytest.mark.parametrize('taps,lpad,cin,N,B,seg', [(1, 0, 72, 40, 1, 50), (3, 1, 24, 52, 3, 37), (5, 2, 80, 64, 2, 33), (5, 4, 16, 20, 2, 19),
+                                                   (3, 1, 48, 132, 3, 37), (5, 2, 64, 256, 4, 50)])      # K, N >= 128
 def test_linear_forward_dgrad_wgrad(T, taps, lpad, cin, N, B, seg):
     from estts import ops
     rng = np.random.default_rng(taps * 100 + N)
