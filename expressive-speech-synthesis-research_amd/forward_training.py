@@ -28,6 +28,8 @@ class ParamStore:
     """Named views into flat parameter / gradient / Adam-moment buffers (trainable) and a flat state buffer
     (BatchNorm moving statistics)."""
 
+    ZERO_POOL = 1 << 16      # floats
+
     def __init__(self, device):
         self.device = device
         self._train, self._state = [], []
@@ -56,7 +58,12 @@ class ParamStore:
             hs[o:o + a.size] = a.reshape(-1)
         dev = self.device
         self.flat = torch.from_numpy(host).to(dev)
-        self.grad = torch.zeros_like(self.flat)
+        # the gradient buffer and a pool of small accumulators that must start every step at zero share one allocation,
+        # so that one fill per step clears both
+        self.grad_and_pool = torch.zeros(n + self.ZERO_POOL, dtype=torch.float32, device=dev)
+        self.grad = self.grad_and_pool[:n]
+        self.pool = self.grad_and_pool[n:]
+        self.pool_used = 0
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.state = torch.from_numpy(hs).to(dev)
@@ -65,6 +72,19 @@ class ParamStore:
         self.s = {k: self._view(self.state, o, s) for k, (o, s) in self.state_table.items()}
         del self._train, self._state
         return self
+
+    def clear_gradients(self):
+        self.grad_and_pool.zero_()
+        self.pool_used = 0
+
+    def zeros(self, *shape):
+        """A zeroed float32 tensor that lives until the next clear_gradients() (from the pool when it has room)."""
+        n = int(np.prod(shape))
+        if self.pool_used + n > self.pool.numel():
+            return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+        o = self.pool_used
+        self.pool_used += _ceil4(n)
+        return self.pool[o:o + n].view(*shape)
 
     @staticmethod
     def _view(buf, off, shape):
@@ -367,7 +387,7 @@ class ForwardTransformerTrainer:
 
     def _bn_train(self, z, norm, M, C):
         """Batch statistics of z [M, C] -> (mean, rstd, scale, shift); updates the moving statistics (momentum 0.99)."""
-        sums = torch.zeros(2, C, dtype=torch.float32, device=self.device)
+        sums = self.store.zeros(2, C)
         T.colreduce(0, sums[0], sums[1], z=z, M=M, C=C)
         st = self._empty(4, C)
         T.bn_finalize(sums[0], sums[1], z, M, C, norm.gamma, norm.beta, norm.mm, norm.mv, st[0], st[1], st[2], st[3])
@@ -512,7 +532,7 @@ class ForwardTransformerTrainer:
         st, de, dd, mc = self.store, self.de, self.dd, self.mel_channels
         Me, Md = B * N, B * Tm
         tape, enc_attn, dec_attn = [], {}, {}
-        st.grad.zero_()
+        st.clear_gradients()
 
         # ---- encoder
         key_mask = self._empty(B, N)
