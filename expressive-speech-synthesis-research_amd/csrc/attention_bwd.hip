@@ -310,7 +310,6 @@ __global__ __launch_bounds__(256) void attention_bwd_wide_kernel(const estts_att
     const float* delta = p.delta + ((long)b * p.H + h) * p.Lq;
     const float scale = 1.0f / sqrtf((float)DH);
     const float own_delta = OWN_Q ? delta[orow] : 0.0f;
-    const bool vec = OWN_Q && (p.Lk & 3) == 0;
 
     Frag<NS> rf[KS];
 #pragma unroll
@@ -340,22 +339,43 @@ __global__ __launch_bounds__(256) void attention_bwd_wide_kernel(const estts_att
             if (NS == 2) *reinterpret_cast<bf16x4*>(dst + IMG + o) = lo;
         }
     };
-    // weights of this lane's row against the 8 swept rows it meets in tile kt (0 outside the map), and their delta
+    // weights of this lane's row against the 8 swept rows it meets in tile kt (0 outside the map), and their delta.
+    // Tiles that lie inside the map take loads without bounds checks from one base address (the checks and the 64-bit
+    // address arithmetic of eight separate elements were a third of the vector instructions of a tile).  A lane whose
+    // own row is past the end reads its clamped row there: its column of the products is never written.
+    const bool quad_ok = (L_oth & 3) == 0;   // (OWN_Q: rows of P; otherwise: delta) can be read four at a time
+    const float* pbase = OWN_Q ? P + (long)orow * p.Lk + 4 * g : P + (long)(4 * g) * p.Lk + orow;
     auto load_p = [&](int kt, float (&pp)[8], float (&dl)[8]) {
+        if (kt * 32 + 32 <= L_oth && quad_ok) {   // uniform over the workgroup
+            if constexpr (OWN_Q) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    const float4 t = *reinterpret_cast<const float4*>(pbase + kt * 32 + sub * 16);
+                    pp[sub * 4] = t.x, pp[sub * 4 + 1] = t.y, pp[sub * 4 + 2] = t.z, pp[sub * 4 + 3] = t.w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dl[sub * 4 + j] = own_delta;
+                }
+            } else {
+                const float* pc = pbase + (long)kt * 32 * p.Lk;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pp[sub * 4 + j] = pc[(sub * 16 + j) * p.Lk];
+                    const float4 t = *reinterpret_cast<const float4*>(delta + kt * 32 + sub * 16 + 4 * g);
+                    dl[sub * 4] = t.x, dl[sub * 4 + 1] = t.y, dl[sub * 4 + 2] = t.z, dl[sub * 4 + 3] = t.w;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const int oth0 = kt * 32 + sub * 16 + 4 * g;
 #pragma unroll
             for (int j = 0; j < 4; ++j) pp[sub * 4 + j] = 0.0f;
             if (own_ok) {
-                if (vec && oth0 + 3 < L_oth) {
-                    const float4 t = *reinterpret_cast<const float4*>(P + (long)orow * p.Lk + oth0);
-                    pp[sub * 4] = t.x, pp[sub * 4 + 1] = t.y, pp[sub * 4 + 2] = t.z, pp[sub * 4 + 3] = t.w;
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (oth0 + j < L_oth) pp[sub * 4 + j] = OWN_Q ? P[(long)orow * p.Lk + oth0 + j] : P[(long)(oth0 + j) * p.Lk + orow];
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (oth0 + j < L_oth) pp[sub * 4 + j] = OWN_Q ? P[(long)orow * p.Lk + oth0 + j] : P[(long)(oth0 + j) * p.Lk + orow];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) dl[sub * 4 + j] = OWN_Q ? own_delta : delta[min(oth0 + j, L_oth - 1)];
@@ -480,7 +500,7 @@ extern "C" int estts_attention_bwd(const estts_attention_bwd_args* args, void* s
     ESTTS_CHECK_ARG(a.ldq >= hd && a.ldk >= hd && a.ldv >= hd && a.ldo >= hd && a.lddo >= hd && a.lddq >= hd && a.lddk >= hd && a.lddv >= hd,
                     "estts_attention_bwd: ld smaller than H*depth");
     ESTTS_CHECK_ARG((((uintptr_t)a.q | (uintptr_t)a.k | (uintptr_t)a.v | (uintptr_t)a.ctx | (uintptr_t)a.dctx | (uintptr_t)a.attn |
-                      (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv) & 15) == 0,
+                      (uintptr_t)a.dq | (uintptr_t)a.dk | (uintptr_t)a.dv | (uintptr_t)a.delta) & 15) == 0,
                     "estts_attention_bwd: pointers not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long rows = (long)a.B * a.Lq;
