@@ -91,6 +91,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
     const float* kbase = p.k + kvb * p.Lk * p.ldk + h * DH;
     const float* vbase = p.v + kvb * p.Lk * p.ldv + h * DH;
     const float* mask = p.key_mask ? p.key_mask + (long)b * p.Lk : nullptr;
+    const bool mask_quads = (p.Lk & 3) == 0 && (reinterpret_cast<uintptr_t>(p.key_mask) & 15) == 0;   // mask rows as float4
     const float scale = 1.0f / sqrtf((float)DH);
     __bf16* stage = reinterpret_cast<__bf16*>(smem) + wave * (NS * IMG);
 
@@ -129,11 +130,25 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
     auto scores = [&](int kt, float (&s)[2][4]) {
         // key-mask values of this lane's eight keys, loaded up front and without conditions (a load under a per-element
         // condition becomes a branch with its own wait: eight serialised round trips per tile)
+        // A tile inside the key range and, under a causal mask, before the workgroup's first query needs neither the range
+        // check nor the comparison with the query, and its mask values come as two float4 (uniform over the workgroup).
+        const bool inside = kt * 32 + 32 <= p.Lk && mask_quads;
+        const bool plain = inside && !(p.causal && kt * 32 + 31 > (int)blockIdx.x * 16);
         float mk[2][4];
+        if (inside) {
+            float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+            if (mask) {
+                m0 = *reinterpret_cast<const float4*>(mask + kt * 32 + 4 * g);
+                m1 = *reinterpret_cast<const float4*>(mask + kt * 32 + 16 + 4 * g);
+            }
+            mk[0][0] = m0.x, mk[0][1] = m0.y, mk[0][2] = m0.z, mk[0][3] = m0.w;
+            mk[1][0] = m1.x, mk[1][1] = m1.y, mk[1][2] = m1.z, mk[1][3] = m1.w;
+        } else {
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mk[sub][j] = mask ? mask[min(kt * 32 + sub * 16 + 4 * g + j, p.Lk - 1)] : 0.0f;
+                for (int j = 0; j < 4; ++j) mk[sub][j] = mask ? mask[min(kt * 32 + sub * 16 + 4 * g + j, p.Lk - 1)] : 0.0f;
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -145,12 +160,17 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
                 if (NS == 2) kf.v[NS - 1] = *reinterpret_cast<const bf16x8*>(stage + IMG + o);
                 acc = mfma_split<NS>(kf, qf[ks], acc);
             }
+            if (plain) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = kt * 32 + sub * 16 + 4 * g + j;
-                const float m = (p.causal && key > qi) ? 1.0f : mk[sub][j];
-                const float v = acc[j] * scale + m * -1e9f;
-                s[sub][j] = key >= p.Lk ? -INFINITY : v;
+                for (int j = 0; j < 4; ++j) s[sub][j] = acc[j] * scale + mk[sub][j] * -1e9f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int key = kt * 32 + sub * 16 + 4 * g + j;
+                    const float m = (p.causal && key > qi) ? 1.0f : mk[sub][j];
+                    const float v = acc[j] * scale + m * -1e9f;
+                    s[sub][j] = key >= p.Lk ? -INFINITY : v;
+                }
             }
         }
     };
@@ -375,6 +395,7 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
     const float* kbase = p.k + kvb * p.Lk * p.ldk + h * DH;
     const float* vbase = p.v + kvb * p.Lk * p.ldv + h * DH;
     const float* mask = p.key_mask ? p.key_mask + (long)b * p.Lk : nullptr;
+    const bool mask_quads = (p.Lk & 3) == 0 && (reinterpret_cast<uintptr_t>(p.key_mask) & 15) == 0;   // mask rows as float4
     const float scale = 1.0f / sqrtf((float)DH);
 
     Frag<NS> qf[KS];
@@ -407,9 +428,23 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
     };
     // scores of a staged K tile for this lane's query: s[sub * 4 + j] <-> key kt*32 + sub*16 + 4g + j
     auto scores = [&](int kt, const __bf16* kimg, float (&s)[8]) {
+        // A tile that lies inside the key range and, under a causal mask, before this wave's first query needs neither the
+        // range check nor the comparison with the query (a quarter of the vector instructions of a tile), and its mask
+        // values come as two float4.  Both conditions are uniform over the wave.
+        const bool inside = kt * 32 + 32 <= p.Lk && mask_quads;
+        const bool plain = inside && !(p.causal && kt * 32 + 31 > qt * 64 + wave * 16);
         float mk[8];     // loaded up front and without conditions: see the kernel above
+        if (inside) {
+            float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+            if (mask) {
+                m0 = *reinterpret_cast<const float4*>(mask + kt * 32 + 4 * g);
+                m1 = *reinterpret_cast<const float4*>(mask + kt * 32 + 16 + 4 * g);
+            }
+            mk[0] = m0.x, mk[1] = m0.y, mk[2] = m0.z, mk[3] = m0.w, mk[4] = m1.x, mk[5] = m1.y, mk[6] = m1.z, mk[7] = m1.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) mk[e] = mask ? mask[min(kt * 32 + (e >> 2) * 16 + 4 * g + (e & 3), p.Lk - 1)] : 0.0f;
+            for (int e = 0; e < 8; ++e) mk[e] = mask ? mask[min(kt * 32 + (e >> 2) * 16 + 4 * g + (e & 3), p.Lk - 1)] : 0.0f;
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -421,12 +456,17 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
                 if (NS == 2) kf.v[NS - 1] = *reinterpret_cast<const bf16x8*>(kimg + IMG + o);
                 acc = mfma_split<NS>(kf, qf[ks], acc);
             }
+            if (plain) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = kt * 32 + sub * 16 + 4 * g + j;
-                const float m = (p.causal && key > qi) ? 1.0f : mk[sub * 4 + j];
-                const float v = acc[j] * scale + m * -1e9f;
-                s[sub * 4 + j] = key >= p.Lk ? -INFINITY : v;
+                for (int j = 0; j < 4; ++j) s[sub * 4 + j] = acc[j] * scale + mk[sub * 4 + j] * -1e9f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int key = kt * 32 + sub * 16 + 4 * g + j;
+                    const float m = (p.causal && key > qi) ? 1.0f : mk[sub * 4 + j];
+                    const float v = acc[j] * scale + m * -1e9f;
+                    s[sub * 4 + j] = key >= p.Lk ? -INFINITY : v;
+                }
             }
         }
     };
