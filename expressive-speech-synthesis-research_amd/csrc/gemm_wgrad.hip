@@ -52,43 +52,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
 
     const int chunk = tid & 15;
     const int r0 = tid >> 4;
-    const ATap tp = make_atap(ga, k0 + chunk * 4);
     const int ncol = n0 + chunk * 4;
     const bool ycol_ok = ncol < ga.N;
 
-    // loads are unconditional and zeroed where they are used (see load_a_raw)
+    // A(m, k) of a dense layer or 1-D convolution: k = (tap, channel) is fixed per thread for the whole row loop, and the
+    // source row of output row m is m + tap - lpad wherever that stays inside m's sequence, so the address is linear in m
+    // and only the validity needs the position of m inside its sequence (carried along, rows only ever advance by 32).
+    const int kk = k0 + chunk * 4;
+    const bool k_ok = kk < ga.K;
+    int tap = 0, ch = kk;
+    if (ga.taps > 1) {
+        tap = kk / ga.c_per_tap;
+        ch = kk - tap * ga.c_per_tap;
+    }
+    const int seg = ga.conv_w;
+    const int shift = tap - ga.conv_pl;
+    const int pos_lo = -shift, pos_hi = seg - shift;   // valid positions of m inside its sequence
+    const bool need_pos = ga.taps > 1;                  // uniform
+    const float* a_col = ga.A + (long)shift * ga.lda + (k_ok ? ch : 0);
+    const bool want_db = db != nullptr && kx == 0;     // uniform
+
+    // loads are unconditional (an invalid element reads A[0]) and zeroed where they are used: a load under a condition
+    // becomes a branch around it
     float4 a_reg[2], y_reg[2];
     bool a_ok[2], y_ok[2];
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of this thread's dY values (the bias gradient)
-    // Rows only ever advance by 32: for dense layers and 1-D convolutions (one output row per image) the position of a
-    // row inside its sequence is carried along instead of being divided out again at every step.
-    const bool one_d = ga.conv_howo == ga.conv_wo;
-    int seq[2], pos[2];
+    int pos[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = m_begin + r0 + 16 * i;
-        seq[i] = row / ga.conv_howo;
-        pos[i] = row - seq[i] * ga.conv_howo;
-    }
+    for (int i = 0; i < 2; ++i) pos[i] = need_pos ? (m_begin + r0 + 16 * i) % seg : 0;
     auto load = [&](int m0) {   // called for m0 = m_begin, m_begin + 32, ... in order
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = m0 + r0 + 16 * i;
-            ARow ar;
-            if (one_d) {
-                ar.ok = row < ga.M;
-                ar.pix0 = seq[i] * ga.conv_h * ga.conv_w;
-                ar.h0 = -ga.conv_pt;
-                ar.w0 = pos[i] * ga.conv_stride - ga.conv_pl;
+            bool ok = k_ok && row < ga.M;
+            if (need_pos) {
+                ok = ok && pos[i] >= pos_lo && pos[i] < pos_hi;
                 pos[i] += 32;
-                while (pos[i] >= ga.conv_howo) {
-                    pos[i] -= ga.conv_howo;
-                    ++seq[i];
-                }
-            } else {
-                ar = make_arow(ga, row);
+                if (seg >= 32) pos[i] -= pos[i] >= seg ? seg : 0;
+                else pos[i] %= seg;
             }
-            a_reg[i] = load_a_raw(ga, ar, tp, a_ok[i]);
+            a_ok[i] = ok;
+            a_reg[i] = *reinterpret_cast<const float4*>(ok ? a_col + (long)row * ga.lda : ga.A);
             y_ok[i] = row < ga.M && ycol_ok;
             y_reg[i] = *reinterpret_cast<const float4*>(dY + (y_ok[i] ? (long)row * lddy + ncol : 0L));
         }
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
             const int o = (r0 + 16 * i) * LD + chunk * 4;
             const float4 az = zero_unless(a_ok[i], a_reg[i]);
             const float4 yz = zero_unless(y_ok[i], y_reg[i]);
-            bsum.x += yz.x; bsum.y += yz.y; bsum.z += yz.z; bsum.w += yz.w;
+            if (want_db) { bsum.x += yz.x; bsum.y += yz.y; bsum.z += yz.z; bsum.w += yz.w; }
             bf16x4 ah, al, yh, yl;
             split_bf16x4(az, ah, al);
             split_bf16x4(yz, yh, yl);
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     }
 
     // bias gradient: the workgroups of the first K tile add up the dY rows they staged anyway
-    if (db != nullptr && kx == 0) {   // uniform over the workgroup
+    if (want_db) {   // uniform over the workgroup
         __syncthreads();                      // the staging buffers are dead
         float* red = reinterpret_cast<float*>(&As[0][0][0]);   // [16 row lanes][64 columns]
         *reinterpret_cast<float4*>(red + r0 * 64 + chunk * 4) = bsum;
