@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     const int seg = ga.conv_w;
     const int shift = tap - ga.conv_pl;
     const int pos_lo = -shift, pos_hi = seg - shift;   // valid positions of m inside its sequence
-    const bool need_pos = ga.taps > 1;                  // uniform
+    const bool need_pos = ga.taps > 1 || ga.conv_pl != 0;   // uniform (a one-tap layer may still be shifted: h_{t-1} of a GRU)
     const float* a_col = ga.A + (long)shift * ga.lda + (k_ok ? ch : 0);
     const bool want_db = db != nullptr && kx == 0;     // uniform
 

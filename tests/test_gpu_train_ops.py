@@ -77,6 +77,20 @@ def test_linear_forward_dgrad_wgrad(T, taps, lpad, cin, N, B, seg):
     assert rel_err(db2, bt.grad) < 1e-5
 
 
+@pytest.mark.parametrize('B,seg,K,N', [(3, 37, 24, 40), (5, 8, 72, 20), (2, 700, 64, 192)])
+def test_wgrad_one_tap_shifted(T, B, seg, K, N):
+    """One tap with one row of left padding (h_{t-1} against the gate gradients of step t in the GRU backward pass): row m
+    meets row m - 1 of its own segment, the first row of every segment meets nothing."""
+    rng = np.random.default_rng(seg)
+    x, dy = rng.normal(size=(B * seg, K)), rng.normal(size=(B * seg, N))
+    prev = np.concatenate([np.zeros((B, 1, K)), x.reshape(B, seg, K)[:, :-1]], axis=1).reshape(B * seg, K)
+    dw = torch.zeros(K, N, device='cuda')
+    db = torch.zeros(N, device='cuda')
+    T.wgrad(dev(x), dev(dy), dw, taps=1, lpad=1, seg_len=seg, db=db)
+    assert rel_err(dw, prev.T @ dy) < 3e-5
+    assert rel_err(db, dy.sum(0)) < 1e-5
+
+
 def test_wgrad_large_rows_many_splits(T):
     rng = np.random.default_rng(0)
     M, K, N = 4100, 192, 136
