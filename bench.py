@@ -452,7 +452,7 @@ def main():
         if B * T <= 2400:
             cpu_step()                                                    # warm-up
         runs, t_cpu = 0, 0.0
-        while runs < 3 and t_cpu < 20.0:
+        while t_cpu < 20.0 and (runs < 3 or t_cpu < 10.0):      # about 10 s of CPU work, at least 3 passes within 20 s
             t0 = time.perf_counter()
             ref_mel = cpu_step()
             t_cpu += time.perf_counter() - t0
