@@ -26,14 +26,13 @@ struct Frag {
 
 template <int NS>
 __device__ __forceinline__ Frag<NS> make_frag(const float* x) {
+    // conversions in pairs (v_cvt_pk_bf16_f32); element by element they were a quarter of a tile's vector instructions
+    bf16x4 h0, l0, h1, l1;
+    split_bf16x4(make_float4(x[0], x[1], x[2], x[3]), h0, l0);
+    split_bf16x4(make_float4(x[4], x[5], x[6], x[7]), h1, l1);
     Frag<NS> f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 h, l;
-        split_bf16(x[j], h, l);
-        f.v[0][j] = h;
-        if (NS == 2) f.v[NS - 1][j] = l;
-    }
+    f.v[0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    if (NS == 2) f.v[NS - 1] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
     return f;
 }
 
