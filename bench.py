@@ -447,7 +447,7 @@ def main():
     # parity gate on the benchmarked utterance (rank 0): float32 restatement on the CPU
     cpu = None
     mel_l1 = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU leg belongs to the one-GPU run only
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         if B * T <= 2400:
             cpu_step()                                                    # warm-up
