@@ -181,7 +181,7 @@ def train_bench(args, rank, world, dist):
     loss0 = float(out['loss'])
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tts_train_torch as OTT
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         bs = min(B, 2)
@@ -269,7 +269,7 @@ def train_wavernn_bench(args, rank, world, dist):
     del trace
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import wavernn_train_torch as OWT
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         bs = min(B, 4)
