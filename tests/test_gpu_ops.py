@@ -216,6 +216,33 @@ def test_attention_64_query_variant(B, H, Lq, Lk, dh, causal, masked, first_mask
     assert (ctx1 - ctx[:, :d]).abs().max().item() < 3e-5
 
 
+@pytest.mark.parametrize('B,H,Lq,Lk,causal,variant', [(2, 4, 96, 96, True, 2), (2, 4, 96, 96, False, 1), (8, 4, 128, 64, False, 0)])
+def test_attention_key_mask_not_16_byte_aligned(B, H, Lq, Lk, causal, variant):
+    """Lk is a multiple of 4, so whole key tiles read their mask four values at a time -- unless the mask does not start on
+    a 16-byte boundary (here: a view one float into a buffer), which must give the same numbers."""
+    dh = 64
+    d = H * dh
+    q, k, v = _rand(B * Lq, d, seed=21), _rand(B * Lk, d, seed=22), _rand(B * Lk, d, seed=23)
+    mask = torch.zeros(B, Lk)
+    for b in range(B):
+        mask[b, Lk - 2 - 5 * b:] = 1.0
+    aligned = mask.to(DEV)
+    shifted = torch.zeros(B * Lk + 1, device=DEV)[1:].view(B, Lk)
+    shifted.copy_(aligned)
+    assert shifted.data_ptr() % 16 == 4 and aligned.data_ptr() % 16 == 0
+    outs = []
+    for m in (aligned, shifted):
+        ctx = torch.empty(B * Lq, d, device=DEV)
+        attn = torch.empty(B, H, Lq, Lk, device=DEV)
+        ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), ctx, B, H, Lq, Lk, dh, key_mask=m, causal=causal, attn=attn, variant=variant)
+        outs.append((ctx, attn))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    split = lambda t, L: t.double().view(B, L, H, dh).permute(0, 2, 1, 3)
+    ref, pref = _attention_ref(split(q, Lq), split(k, Lk), split(v, Lk), mask, causal)
+    assert (outs[1][0].cpu().double() - ref.permute(0, 2, 1, 3).reshape(B * Lq, d)).abs().max().item() < 3e-5
+    assert (outs[1][1].cpu().double() - pref).abs().max().item() < 3e-5
+
+
 def test_attention_online_softmax_rescale_branch():
     # one key far above the rest, late in the sequence: forces the running-max rescale at a chosen tile
     B, H, L, dh = 1, 1, 96, 32
