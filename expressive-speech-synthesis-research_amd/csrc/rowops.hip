@@ -358,9 +358,10 @@ extern "C" int estts_rownorm(const estts_rownorm_args* args, void* stream) {
     ESTTS_CHECK_ARG(!a.dot_w || a.dot_out, "estts_rownorm: dot_w without dot_out");
     ESTTS_CHECK_ARG(a.drop_rate >= 0.0f && a.drop_rate < 1.0f, "estts_rownorm: drop_rate must be in [0, 1)");
     const dim3 grid((a.M + 3) / 4);
-    // short launches (one utterance): the variant with every operand requested up front; long ones are HBM-bound either way
+    // inference shapes: the variant with every operand requested up front (3.4 vs 4.7 us at 100 rows; 11.6 vs 14.5 us,
+    // 5.1 TB/s, at 19200 rows of 256)
     bool done = false;
-    if (a.drop_rate == 0.0f && !a.dot_w && a.out && a.M <= 4096) {
+    if (a.drop_rate == 0.0f && !a.dot_w && a.out) {
         if (a.D == 256) done = launch_rownorm_fast<1>(a, grid, (hipStream_t)stream);
         else if (a.D == 512) done = launch_rownorm_fast<2>(a, grid, (hipStream_t)stream);
     }
