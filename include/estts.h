@@ -338,7 +338,8 @@ int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream);
 
 /* Gradients of estts_attention given the saved weights P = attn [B, H, Lq, Lk] and dctx:
  *   dV = P^T dctx;  dP = dctx V^T;  dS = P o (dP - delta);  dQ = dS K / sqrt(depth);  dK = dS^T Q / sqrt(depth)
- * with delta[b, h, i] = sum_f dctx[b, i, h, f] * ctx[b, i, h, f]  (computed into `delta`, [B, H, Lq] floats).
+ * with delta[b, h, i] = sum_f dctx[b, i, h, f] * ctx[b, i, h, f]  (computed into `delta`, [B, H, Lq] floats, 16-byte
+ * aligned like the other buffers).
  * q/k/v/ctx/dctx and dq/dk/dv use the row layouts of estts_attention. */
 typedef struct estts_attention_bwd_args {
     const float* q; int32_t ldq;
