@@ -265,27 +265,34 @@ __global__ __launch_bounds__(256) void conv2d_c1_kernel(const float* x, const fl
                                                         float* out, int B, int H, int W, int Ho, int Wo, int Cout, int stride,
                                                         int pad_t, int pad_l) {
     const int cq = Cout >> 2;
-    const long total = (long)B * Ho * Wo * cq;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cq) * 4;
-        long pix = idx / cq;
-        const int wo = (int)(pix % Wo);
+    const int total = B * Ho * Wo * cq;     // checked by the launcher to fit 31 bits
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int c = (idx % cq) * 4;
+        int pix = idx / cq;
+        const int wo = pix % Wo;
         pix /= Wo;
-        const int ho = (int)(pix % Ho);
-        const int b = (int)(pix / Ho);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int ho = pix % Ho;
+        const int b = pix / Ho;
+        // all nine taps are requested before the first is used, from clamped positions, and zeroed where the tap lies
+        // outside the image: a load under a condition becomes a branch with a wait of its own
+        float v[9];
+        float4 wv[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int hi = ho * stride + kh - pad_t;
-            if (hi < 0 || hi >= H) continue;
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int wi = wo * stride + kw - pad_l;
-                if (wi < 0 || wi >= W) continue;
-                const float v = x[((long)b * H + hi) * W + wi];
-                const float4 wv = *reinterpret_cast<const float4*>(w + (kh * 3 + kw) * Cout + c);
-                acc.x += v * wv.x; acc.y += v * wv.y; acc.z += v * wv.z; acc.w += v * wv.w;
+                const bool ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+                const float t = x[((long)b * H + min(max(hi, 0), H - 1)) * W + min(max(wi, 0), W - 1)];
+                v[kh * 3 + kw] = ok ? t : 0.0f;
+                wv[kh * 3 + kw] = *reinterpret_cast<const float4*>(w + (kh * 3 + kw) * Cout + c);
             }
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            acc.x += v[k] * wv[k].x; acc.y += v[k] * wv[k].y; acc.z += v[k] * wv[k].z; acc.w += v[k] * wv[k].w;
         }
         const float4 s = *reinterpret_cast<const float4*>(scale + c);
         const float4 bb = *reinterpret_cast<const float4*>(bias + c);
@@ -396,6 +403,7 @@ extern "C" int estts_conv2d_c1(const float* x, const float* w, const float* scal
                     "estts_conv2d_c1: bad shape (Cout must be a multiple of 4)");
     ESTTS_CHECK_ARG((Ho - 1) * stride - pad_t < H && (Wo - 1) * stride - pad_l < W, "estts_conv2d_c1: output grid leaves the image");
     const long total = (long)B * Ho * Wo * (Cout >> 2);
+    ESTTS_CHECK_ARG(total < (1L << 31) - (1L << 21), "estts_conv2d_c1: too many outputs");
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(conv2d_c1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, scale, bias, out, B, H, W, Ho,
                        Wo, Cout, stride, pad_t, pad_l);
