@@ -172,9 +172,15 @@ __global__ __launch_bounds__(256) void expand_bwd_kernel(const float* dout, int 
     const int dq = D >> 2;
     for (int ch = lane; ch < dq; ch += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int t = t0; t < t1; ++t) {
-            const float4 g = ld4(dout + ((long)b * T + t) * lddo + ch * 4);
-            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        for (int t = t0; t < t1; t += 4) {   // four frames in flight (the last group re-reads the last frame with weight 0)
+            float4 g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) g[u] = ld4(dout + ((long)b * T + min(t + u, t1 - 1)) * lddo + ch * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w = t + u < t1 ? 1.0f : 0.0f;
+                acc.x += w * g[u].x; acc.y += w * g[u].y; acc.z += w * g[u].z; acc.w += w * g[u].w;
+            }
         }
         st4(dx + tok * lddx + ch * 4, acc);
     }
