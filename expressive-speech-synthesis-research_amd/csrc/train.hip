@@ -234,20 +234,34 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_ar
         if (p.mode == 2) { mu = ld4(p.mean + c); rs = ld4(p.rstd + c); }
         const bool recompute = p.mode != 0 && !p.a && p.scale && p.act != ESTTS_ACT_NONE;
         if (recompute) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
-        for (int row = blockIdx.y * 4 + rl; row < p.M; row += gridDim.y * 4) {
+        // two rows in flight per thread: the loads of the second are requested before the first is consumed (the optional
+        // in-place store of a row keeps the compiler from doing that itself)
+        struct RowIn {
+            float4 g, z, a;
+        };
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto fetch = [&](int row) {
+            RowIn v = {zero4, zero4, zero4};
             if (p.mode == 0) {
-                const float4 z = ld4(p.z + (long)row * p.ldz + c);
-                const float a = z.x - k0.x, b = z.y - k0.y, cc = z.z - k0.z, d = z.w - k0.w;
+                v.z = ld4(p.z + (long)row * p.ldz + c);
+            } else {
+                v.g = ld4(p.g + (long)row * p.ldg + c);
+                if (p.mode == 2 || recompute) v.z = ld4(p.z + (long)row * p.ldz + c);
+                if (p.a) v.a = ld4(p.a + (long)row * p.lda + c);
+            }
+            return v;
+        };
+        auto consume = [&](int row, const RowIn& v) {
+            if (p.mode == 0) {
+                const float a = v.z.x - k0.x, b = v.z.y - k0.y, cc = v.z.z - k0.z, d = v.z.w - k0.w;
                 s0.x += a; s0.y += b; s0.z += cc; s0.w += d;
                 s1.x += a * a; s1.y += b * b; s1.z += cc * cc; s1.w += d * d;
             } else {
-                float4 g = ld4(p.g + (long)row * p.ldg + c);
-                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.mode == 2 || recompute) z = ld4(p.z + (long)row * p.ldz + c);
+                float4 g = v.g;
+                const float4 z = v.z;
                 if (p.a) {
-                    const float4 a = ld4(p.a + (long)row * p.lda + c);
-                    g.x *= act_grad_from_output(a.x, p.act); g.y *= act_grad_from_output(a.y, p.act);
-                    g.z *= act_grad_from_output(a.z, p.act); g.w *= act_grad_from_output(a.w, p.act);
+                    g.x *= act_grad_from_output(v.a.x, p.act); g.y *= act_grad_from_output(v.a.y, p.act);
+                    g.z *= act_grad_from_output(v.a.z, p.act); g.w *= act_grad_from_output(v.a.w, p.act);
                 } else if (recompute) {
                     g.x *= act_grad_from_output(apply_act(z.x * sc.x + sh.x, p.act), p.act);
                     g.y *= act_grad_from_output(apply_act(z.y * sc.y + sh.y, p.act), p.act);
@@ -261,7 +275,15 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_ar
                     s1.z += g.z * (z.z - mu.z) * rs.z; s1.w += g.w * (z.w - mu.w) * rs.w;
                 }
             }
+        };
+        const int stride = gridDim.y * 4;
+        int row = blockIdx.y * 4 + rl;
+        for (; row + stride < p.M; row += 2 * stride) {
+            const RowIn v0 = fetch(row), v1 = fetch(row + stride);
+            consume(row, v0);
+            consume(row + stride, v1);
         }
+        if (row < p.M) consume(row, fetch(row));
     }
     red[0][rl][chunk] = s0;
     red[1][rl][chunk] = s1;
