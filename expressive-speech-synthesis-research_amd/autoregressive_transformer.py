@@ -228,7 +228,7 @@ class AutoregressiveTransformer:
         enc_mask = torch.empty(B, N, **f32)
         ops.row_zero_mask(enc, enc_mask.view(-1))
         return (enc3, enc_mask.view(B, 1, 1, N), text_attn, gst_attn, gst_tokens, gst_out,
-                text_out.reshape(B, N, de).clone())
+                text_out.reshape(B, N, de))          # a view of this call's own workspace (allocated per call)
 
     def _next_dropout_seed(self):
         self.dropout_seed = (self.dropout_seed * 1000003 + 7919) & 0xFFFFFFFF
@@ -273,7 +273,7 @@ class AutoregressiveTransformer:
         self.postnet.run(mel, torch.empty(B * T, hid, **f32), torch.empty(B * T, hid, **f32), final, T, self.precision)
         mel3 = mel.view(B, T, C)
         return {'mel_linear': mel3, 'final_output': final.view(B, T, C), 'stop_prob': stop.view(B, T, 3),
-                'decoder_attention': attn, 'decoder_output': dec_out.reshape(B, Tq, dd).clone(), 'linear': mel3}
+                'decoder_attention': attn, 'decoder_output': dec_out.reshape(B, Tq, dd), 'linear': mel3}      # (a view of this call's workspace)
 
     def call(self, inputs, targets, spk_embed=None, train_text_encoder=False, train_style_encoder=False, train_decoder=False,
              return_attention=True):
