@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -112,6 +112,7 @@ SIGNATURES = {
     'estts_abi_version': (_i32, []),
     'estts_last_error': (C.c_char_p, []),
     'estts_gemm': (_i32, [C.POINTER(GemmArgs), _vp]),
+    'estts_gemm_noalloc': (_i32, [C.POINTER(GemmArgs), _vp]),
     'estts_attention': (_i32, [C.POINTER(AttentionArgs), _vp]),
     'estts_rownorm': (_i32, [C.POINTER(RownormArgs), _vp]),
     'estts_embed_posenc': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),

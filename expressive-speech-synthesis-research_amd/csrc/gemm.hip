@@ -26,6 +26,8 @@
 // drains its stores, workgroup barrier, one lane issues an agent-scope release fence and then the relaxed
 // agent-scope ticket add; the last arriver issues an agent-scope acquire fence before any wave reads the
 // slabs.  The counter is reset by the last arriver, so it must be zero only before the first ever launch.
+#include <mutex>
+
 #include "common.h"
 #include "a_operand.h"
 
@@ -667,10 +669,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
 }
 
 // ------------------------------------------------------------------------------------------------------
+thread_local const char* g_entry = "estts_gemm";   // entry point named in the split-K size error
+
 bool splitk_fits(const estts_gemm_args& a, dim3 grid, long tile_elems) {
     const long need = (long)grid.z * grid.x * grid.y * tile_elems * sizeof(float);
     if (!a.ws || !a.counters || need > a.ws_bytes || (long)grid.x * grid.y > a.n_counters) {
-        estts_set_error("estts_gemm: split-K needs %ld workspace bytes and %ld counters", need, (long)grid.x * grid.y);
+        estts_set_error("%s: split-K of this launch needs %ld scratch bytes and %ld tickets, the caller's buffer holds %ld and %d",
+                        g_entry, need, (long)grid.x * grid.y, (long)a.ws_bytes, a.n_counters);
         return false;
     }
     return true;
@@ -826,4 +831,64 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         case 3: return launch<32, 32, 2, 2>(a, splitk, st);
         default: return launch_small(a, splitk, (a.tune >> 16) & 0xff, st);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// estts_gemm without a caller workspace: the split-K slabs and tickets live in a file-scope device array.
+// Layout: [NOALLOC_TICKETS int32 tickets | NOALLOC_SLAB_BYTES of float32 slabs].
+namespace {
+constexpr int NOALLOC_TICKETS = 4096;
+constexpr long NOALLOC_SLAB_BYTES = 4l << 20;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[NOALLOC_TICKETS * 4 + NOALLOC_SLAB_BYTES];
+
+namespace {
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};   // device address of `scratch` on each GPU (every GPU holds its own copy)
+
+// Device address of this GPU's copy of `scratch`, looked up once per device with that device current.
+int scratch_of_current_device(unsigned char** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+        estts_set_error("estts_gemm_noalloc: hipGetDevice failed or device index %d out of range: %s", dev, hipGetErrorString(e));
+        return -2;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        unsigned char* ptr = nullptr;
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            estts_set_error("estts_gemm_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+            return -2;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" int estts_gemm_noalloc(const estts_gemm_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_gemm_noalloc: null args");
+    unsigned char* ptr = nullptr;
+    const int rc = scratch_of_current_device(&ptr);
+    if (rc != 0) return rc;
+    estts_gemm_args a = *args;
+    a.counters = reinterpret_cast<int32_t*>(ptr);
+    a.n_counters = NOALLOC_TICKETS;
+    a.ws = reinterpret_cast<float*>(ptr + NOALLOC_TICKETS * 4);
+    a.ws_bytes = NOALLOC_SLAB_BYTES;
+    // the tickets must be zero when the kernel starts; a finished launch leaves them zero, an aborted one may not
+    const hipError_t e = hipMemsetAsync(ptr, 0, NOALLOC_TICKETS * 4, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        estts_set_error("estts_gemm_noalloc: clearing the tickets failed: %s", hipGetErrorString(e));
+        return -2;
+    }
+    g_entry = "estts_gemm_noalloc";
+    const int r = estts_gemm(&a, stream);
+    g_entry = "estts_gemm";
+    return r;
 }

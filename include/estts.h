@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 16
+#define ESTTS_ABI_VERSION 17
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -117,6 +117,15 @@ typedef struct estts_gemm_args {
 } estts_gemm_args;
 
 int estts_gemm(const estts_gemm_args* args, void* stream);
+
+/* estts_gemm for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  No counterpart in the reference.  args->ws / ws_bytes / counters / n_counters are ignored: the
+ * split-K slabs and tickets live in a static device array inside the library (4 MiB of slabs + 4096 tickets per GPU, held
+ * until the process ends).  A launch whose split needs more is rejected with an error naming both sizes (tune = 0 never
+ * splits beyond 32 tiles, i.e. 1 MiB).  The call allocates nothing (one hipMemsetAsync of the tickets, then the launch);
+ * the first call on a device looks the array's address up.  Every call on one GPU shares that GPU's array: calls that may
+ * overlap on one GPU (different streams) race and must use estts_gemm with workspaces of their own instead. */
+int estts_gemm_noalloc(const estts_gemm_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-head scaled-dot-product attention over already-projected q / k / v.
