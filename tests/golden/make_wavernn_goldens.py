@@ -44,7 +44,7 @@ os.chdir(_cwd)
 
 
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from wavernn_common import small_hp  # noqa: E402
+from wavernn_common import small_hp, small_hp_hop256  # noqa: E402
 
 
 def build(hp, seed):
@@ -99,15 +99,17 @@ class Recorder:
         self._hook.remove()
 
 
-def make(mode, seed, T, fname):
-    hp = small_hp(mode)
+def make(mode, seed, T, fname, hp=None, up_frames=None, logits_every=1):
+    """up_frames: check the materialised upsampling on the first up_frames frames only (hop 256 writes 336 floats per
+    sample; the generate trace below still covers every frame)."""
+    hp = hp or small_hp(mode)
     model, w = build(hp, seed)
     model.eval()
     rng = np.random.default_rng(seed + 1)
     mel = rng.uniform(0, 1, size=(1, hp['num_mels'], T)).astype(np.float32)
     out = {'seed': seed, 'mel': mel}
     with torch.no_grad():
-        mp = torch.from_numpy(np.pad(mel, ((0, 0), (0, 0), (hp['voc_pad'], hp['voc_pad']))))
+        mp = torch.from_numpy(np.pad(mel[:, :, :up_frames], ((0, 0), (0, 0), (hp['voc_pad'], hp['voc_pad']))))
         up, aux = model.upsample(mp)
         out['upsampled_mel'] = up.numpy()
         out['aux'] = aux.numpy()
@@ -125,7 +127,7 @@ def make(mode, seed, T, fname):
     finally:
         rec.remove()
     out['wav'] = wav
-    out['gen_logits'] = np.stack(rec.logits)                       # (steps, folds, n_classes)
+    out['gen_logits'] = np.stack(rec.logits)[::logits_every]      # (steps, folds, n_classes), every logits_every-th step
     if mode == 'RAW':
         out['u'] = np.stack(rec.categorical_u)                     # (steps, folds)
     else:
@@ -138,3 +140,4 @@ def make(mode, seed, T, fname):
 if __name__ == '__main__':
     make('RAW', 101, 23, 'wavernn_raw_small.npz')
     make('MOL', 202, 23, 'wavernn_mol_small.npz')
+    make('RAW', 303, 23, 'wavernn_raw_hop256.npz', hp=small_hp_hop256(), up_frames=3, logits_every=8)

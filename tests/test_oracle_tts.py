@@ -110,3 +110,21 @@ def test_autoregressive_gst_two_restatements_agree():
         for key in ('final_output', 'mel_linear', 'stop_prob', 'gst_output', 'gst_encoder_attention'):
             np.testing.assert_allclose(a[key], b[key], atol=1e-9, err_msg=key)
         assert a['final_output'].shape == (2, 11 * r, 20)
+
+
+def test_ar_gst_fixture_matches_the_second_restatement(golden_dir):
+    """tests/golden/ar_gst_small.npz was written by oracle/tts_numpy.py; the independent PyTorch restatement reproduces it."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(golden_dir))
+    from make_tts_goldens import ar_gst_inputs
+    g = np.load(os.path.join(golden_dir, 'ar_gst_small.npz'))
+    cfg, seed, tokens, targets, spk, r = ar_gst_inputs()
+    assert seed == int(g['weight_seed']) and r == int(g['r'])
+    np.testing.assert_array_equal(tokens, g['tokens'])
+    np.testing.assert_array_equal(targets, g['targets'])
+    w = weights.init_autoregressive_transformer(cfg, seed=seed)
+    b = OT.autoregressive_call(w, cfg, tokens, targets, spk, r=r, dtype=torch.float64)
+    for key in ('final_output', 'mel_linear', 'stop_prob', 'gst_output', 'gst_encoder_attention', 'text_enc_output'):
+        np.testing.assert_allclose(b[key], g[key], atol=2e-6, err_msg=key)
+    np.testing.assert_allclose(b['decoder_attention'][-1], g['last_cross_attention'], atol=2e-6)

@@ -37,6 +37,24 @@ def test_generate_raw_trajectory_matches_reference(golden_dir):
     np.testing.assert_allclose(wav, g['wav'], atol=1e-6)
 
 
+def test_hop256_fixture_matches_reference(golden_dir):
+    """The vocoder shape of the benchmark (hop 256 = upsample factors (4, 8, 8)) at small widths, written by the reference."""
+    from wavernn_common import small_hp_hop256
+    g = np.load(os.path.join(golden_dir, 'wavernn_raw_hop256.npz'))
+    hp = small_hp_hop256()
+    w = weights.init_wavernn(hp, seed=int(g['seed']))
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    frames = g['upsampled_mel'].shape[1] // hp['hop_length']
+    mp = np.pad(g['mel'][:, :, :frames].astype(np.float64), ((0, 0), (0, 0), (hp['voc_pad'], hp['voc_pad'])))
+    up, aux = W.upsample_network(mp, w64, hp['voc_upsample_factors'], hp['voc_res_blocks'], hp['voc_pad'])
+    np.testing.assert_allclose(up, g['upsampled_mel'], atol=2e-6)
+    np.testing.assert_allclose(aux, g['aux'], atol=2e-5)
+    np.testing.assert_allclose(W.forward(g['fwd_x'], g['fwd_mels'], w, hp), g['fwd_logits'], atol=3e-5)
+    wav, logits, raw = W.generate(g['mel'], w, hp, g['u'], return_trace=True)
+    np.testing.assert_allclose(logits[::8], g['gen_logits'], atol=5e-5)
+    np.testing.assert_allclose(wav, g['wav'], atol=1e-6)
+
+
 def test_generate_mol_trajectory_matches_reference(golden_dir):
     g, hp, w = _load(golden_dir, 'MOL')
     wav, logits, raw = W.generate(g['mel'], w, hp, {'mix': g['u_mix'], 'logistic': g['u_logistic']}, return_trace=True)
