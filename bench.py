@@ -80,13 +80,45 @@ def time_kernels(trace, reps=20, rounds=3):
     return rows
 
 
-def wavernn_pass(precision):
+def launch_floor_us(n_launches=7, reps=50):
+    """Device time per dependent launch of a kernel that does nothing to speak of (one 4-element estts_axpby), replayed from
+    a hipGraph of reps x n_launches launches: what a chain of n_launches kernels costs before any of them does work."""
+    from estts import _lib
+    lib = _lib.load()
+    x = torch.zeros(4, device='cuda')
+    y = torch.zeros(4, device='cuda')
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        def chain():
+            for _ in range(n_launches):
+                _lib.check(lib.estts_axpby(x.data_ptr(), 4, 1.0, y.data_ptr(), 4, 1.0, 1, 4, stream.cuda_stream), 'estts_axpby')
+        chain()
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for _ in range(reps):
+                chain()
+        g.replay()
+        best = float('inf')
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            g.replay()
+            e1.record(stream)
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / (reps * n_launches))
+    torch.cuda.synchronize()
+    return best
+
+
+def wavernn_pass(precision, cpu_leg=True, kernel_table=False):
     """BASELINE config 4, one pass: 64 utterances x 560 frames, hop 256 @ 22.05 kHz, RAW 9-bit mu-law, batched folds
     (target 11 000, overlap 550).  Reported beside the headline metric, not as `value`."""
-    from estts.wavernn import WaveRNN
+    from estts.wavernn import WaveRNN, fold_starts
     hp = configs.wavernn_hparams_22k()
     m = WaveRNN.from_hparams(hp, precision=precision)
-    m.load_state_dict(weights.init_wavernn(hp, seed=1234))
+    w = weights.init_wavernn(hp, seed=1234)
+    m.load_state_dict(w)
     rng = np.random.default_rng(1234)
     mels = [rng.uniform(0, 1, size=(hp['num_mels'], 560)).astype(np.float32) for _ in range(64)]
     m.generate_batch(mels[:1], True, 1000, 100, True, seed=0)          # warm-up (library load, allocator)
@@ -98,11 +130,89 @@ def wavernn_pass(precision):
     samples = sum(len(o) for o in outs)
     audio = samples / hp['sample_rate']
     steps = hp['voc_target'] + 2 * hp['voc_overlap']
-    return {'workload': 'WaveRNN RAW 9-bit mu-law, 64 utterances x 560 frames, hop 256 / 22050 Hz (BASELINE config 4)',
-            'rtf': dt / audio, 'wall_s': dt, 'audio_s': audio, 'samples_per_s': samples / dt, 'us_per_step': dt / steps * 1e6,
-            'sequences': int(sum(-(-(560 * 256 - 550) // 11550) for _ in range(64))), 'precision': precision,
-            'includes': 'conditioning network, 12100 sampling steps (50 per hipGraph replay), device-to-host copy, '
-                        'host cross-fade / mu-law expansion'}
+    n_seq = int(sum(len(fold_starts(560 * hp['hop_length'], hp['voc_target'], hp['voc_overlap'])) for _ in range(64)))
+    res = {'workload': 'WaveRNN RAW 9-bit mu-law, 64 utterances x 560 frames, hop 256 / 22050 Hz (BASELINE config 4)',
+           'rtf': dt / audio, 'wall_s': dt, 'audio_s': audio, 'samples_per_s': samples / dt, 'us_per_step': dt / steps * 1e6,
+           'sequences': n_seq, 'precision': precision,
+           'includes': 'conditioning network, 12100 sampling steps (50 per hipGraph replay), device-to-host copy, '
+                       'host cross-fade / mu-law expansion'}
+
+    # one step's launches, traced and timed in isolation: the dominant layer against the matrix-core peak, the step against
+    # the launch-chain floor and the weight stream
+    cond = m._prepare(mels)
+    seq_utt, seq_start = [], []
+    for ui in range(64):
+        st_ = fold_starts(560 * hp['hop_length'], hp['voc_target'], hp['voc_overlap'])
+        seq_utt += [ui] * len(st_)
+        seq_start += st_
+    i32 = dict(dtype=torch.int32, device='cuda')
+    su, ss = torch.tensor(seq_utt, **i32), torch.tensor(seq_start, **i32)
+    st = m._alloc_state(n_seq, 8)
+    prep_args = m._prep_args(cond, st, su, ss, n_seq)
+    if m._use_layers():
+        st['cond_args'] = m._cond_args(cond, st, su, ss, n_seq)
+    sample_args = m._sample_args(st, n_seq, 1, None, None, None)
+    m._one_step(st, prep_args, sample_args)
+    m._one_step(st, prep_args, sample_args)
+    ops.start_trace()
+    m._one_step(st, prep_args, sample_args)
+    trace = ops.stop_trace()
+    torch.cuda.synchronize()
+    launches_per_step = len(trace) + (1 if m._use_layers() else 2)        # + the sampler (and the conditioning launch)
+    roof, _ = roofline_from_trace(trace, kernel_table, 0)
+    step_flops = sum(info['flops'] for _, info, _ in trace)
+    iso_us = None
+    if roof is not None:
+        key = lambda kind, info: (kind,) + tuple(sorted((k, v) for k, v in info.items() if k not in ('flops', 'bytes')))
+        groups = {}
+        for kind, info, fn in trace:
+            groups.setdefault(key(kind, info), (kind, info, fn))
+        times = dict(zip(groups, (t for _, _, t in time_kernels(list(groups.values()), reps=20))))
+        iso_us = sum(times[key(kind, info)] for kind, info, _ in trace) * 1e6
+    floor = launch_floor_us(launches_per_step)
+    n_params = sum(int(np.prod(v.shape)) for k, v in w.items() if k.startswith(('I.', 'rnn', 'fc')))
+    us = res['us_per_step']
+    res['roofline'] = {
+        'dominant_layer': roof,
+        'step_algorithmic_tflops': step_flops / (us * 1e-6) / 1e12,
+        'step_mfma_frac': step_flops / (us * 1e-6) / MFMA_BF16_PEAK,
+        'step_mfma_issue_frac': (3.0 if precision == 'bf16x3' else 1.0) * step_flops / (us * 1e-6) / MFMA_BF16_PEAK,
+        'weight_stream_gb_s': (4.0 if precision == 'bf16x3' else 2.0) * n_params / (us * 1e-6) / 1e9,
+        'weight_stream_note': 'bytes of the step\'s weights (bf16 hi + lo) per step: every step re-reads them from L2 / the Infinity '
+                              'Cache; HBM peak 8000 GB/s',
+        'launches_per_step': launches_per_step,
+        'launch_chain_floor_us': floor * launches_per_step,
+        'launch_chain_floor_note': f'{launches_per_step} dependent launches of an empty kernel replayed from a hipGraph, '
+                                   f'{floor:.2f} us each',
+        'sum_of_isolated_layer_kernels_us': iso_us,
+    }
+    if cpu_leg:
+        # CPU leg: the float32 NumPy restatement's step loop on the folds of 4 of the utterances for a bounded number of steps
+        from oracle import wavernn_numpy as W
+        w32 = {k: np.asarray(v, np.float32) for k, v in w.items() if not k.endswith('num_batches_tracked') and k != 'step'}
+        sub = np.stack(mels[:4])
+        mp = np.pad(sub, ((0, 0), (0, 0), (hp['voc_pad'], hp['voc_pad'])))
+        up, aux = W.upsample_network(mp, w32, hp['voc_upsample_factors'], hp['voc_res_blocks'], hp['voc_pad'])
+        up = np.concatenate([W.fold_with_overlap(up[i:i + 1], hp['voc_target'], hp['voc_overlap']) for i in range(4)])
+        aux = np.concatenate([W.fold_with_overlap(aux[i:i + 1], hp['voc_target'], hp['voc_overlap']) for i in range(4)])
+        B = up.shape[0]
+        h1 = np.zeros((B, hp['voc_rnn_dims']), np.float32)
+        h2 = np.zeros_like(h1)
+        x = np.zeros((B, 1), np.float32)
+        u = np.random.default_rng(5).uniform(0, 1, size=(4000, B))
+        t0 = time.perf_counter()
+        n_steps = 0
+        while n_steps < 4000 and time.perf_counter() - t0 < 12.0:
+            lg, h1, h2 = W.step_logits(x, up[:, n_steps], aux[:, n_steps], h1, h2, w32)
+            c = W.sample_raw(lg, u[n_steps])
+            x = (2 * c.astype(np.float32) / 511. - 1.)[:, None]
+            n_steps += 1
+        t_cpu = time.perf_counter() - t0
+        res['cpu_baseline'] = {'value': B * n_steps / t_cpu, 'unit': 'samples/s', 'cores': min(os.cpu_count() or 1, 16), 'kind': 'port',
+                               'sample': f'{n_steps} steps of the {B} folds of 4 of the 64 utterances, float32 NumPy restatement '
+                                         f'(oracle/wavernn_numpy.py step_logits + sample_raw; BLAS threads as the host gives)',
+                               'rtf_at_this_rate': samples / (B * n_steps / t_cpu) / audio}
+    return res
 
 
 NO_ROOFLINE = False
@@ -521,7 +631,7 @@ def main():
             'cpu_baseline': cpu,
         }
         if world == 1 and not args.no_wavernn:
-            line['wavernn'] = wavernn_pass(args.precision)
+            line['wavernn'] = wavernn_pass(args.precision, cpu_leg=not args.no_cpu_baseline, kernel_table=args.kernel_table)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 17
+ABI_VERSION = 21
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -101,10 +101,26 @@ class WavernnPrepArgs(C.Structure):
                 ('a4', _vp), ('ld_a4', _i32), ('n_seq', _i32), ('feat', _i32), ('d', _i32), ('hop', _i32), ('pad', _i32)]
 
 
+class WavernnLayerArgs(C.Structure):
+    _fields_ = [('a0', _vp), ('ks0', _i32), ('kpitch0', _i32), ('a1', _vp), ('ks1', _i32), ('kpitch1', _i32), ('W', _vp),
+                ('bias', _vp), ('n_seq', _i32), ('n_units', _i32), ('mode', _i32), ('act', _i32), ('unit_blocks', _i32),
+                ('h_prev', _vp), ('ldh', _i32), ('x_res', _vp), ('ldr', _i32), ('h_out', _vp), ('ldho', _i32),
+                ('h_panel', _vp), ('h_kpitch', _i32), ('out_f32', _vp), ('ldo', _i32), ('out_panel', _vp), ('out_kpitch', _i32)]
+
+
+class WavernnCondArgs(C.Structure):
+    _fields_ = [('mel', _vp), ('aux', _vp), ('fir', _vp), ('ntaps', _i32), ('seq_info', _vp), ('step', _vp), ('done', _vp),
+                ('xin_panel', _vp), ('a2_panel', _vp), ('a3_panel', _vp), ('a4_panel', _vp),
+                ('aux_ks', _i32), ('aux_kpitch', _i32), ('n_seq', _i32), ('feat', _i32), ('d', _i32), ('hop', _i32)]
+
+
 class WavernnSampleArgs(C.Structure):
     _fields_ = [('logits', _vp), ('ld_logits', _i32), ('n_classes', _i32), ('mode', _i32), ('u', _vp), ('u_mix', _vp),
                 ('forced', _vp), ('seed', C.c_uint32), ('wave', _vp), ('ld_wave', _i32), ('x_prev', _vp), ('step', _vp),
-                ('done', _vp), ('n_seq', _i32)]
+                ('done', _vp), ('n_seq', _i32), ('with_cond', _i32), ('cond', WavernnCondArgs)]
+
+
+
 
 
 # symbol -> (restype, argtypes); every symbol declared in include/estts.h must be listed here
@@ -124,6 +140,8 @@ SIGNATURES = {
     'estts_wavernn_prep': (_i32, [C.POINTER(WavernnPrepArgs), _vp]),
     'estts_gru_gates': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_wavernn_sample': (_i32, [C.POINTER(WavernnSampleArgs), _vp]),
+    'estts_wavernn_layer': (_i32, [C.POINTER(WavernnLayerArgs), _vp]),
+    'estts_wavernn_cond': (_i32, [C.POINTER(WavernnCondArgs), _vp]),
     'estts_pack_weight': (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     'estts_gemm_wgrad': (_i32, [C.POINTER(WgradArgs), _vp]),
     'estts_attention_bwd': (_i32, [C.POINTER(AttentionBwdArgs), _vp]),

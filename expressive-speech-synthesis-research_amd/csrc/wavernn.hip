@@ -2,6 +2,7 @@
 // The dense layers of a step run through estts_gemm; these kernels are the HBM/latency-bound glue around
 // them: conditioning assembly (upsampling filter applied on the fly), GRU gate math, sampling.
 #include "common.h"
+#include "wavernn_cond.h"
 
 namespace {
 
@@ -95,6 +96,19 @@ __global__ __launch_bounds__(256) void wavernn_sample_kernel(const estts_wavernn
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int step = p.step[0];
+    // the next step's conditioning of this sequence (everything but x_prev), one group of eight panel columns per lane: it does
+    // not depend on the draw, so its loads overlap the softmax below.  The wave of the last sequence also zero-fills the
+    // rest of the last row block.
+    if (p.with_cond) {
+        const int groups = 15 + 3 * (p.cond.d >> 3);
+        const int n_rows = ((p.n_seq + 15) >> 4) << 4;
+        if (b < p.n_seq && lane >= 1 && lane <= groups) wavernn_cond_group(p.cond, b, lane, step + 1);
+        if (b == p.n_seq - 1)
+            for (int bb = p.n_seq; bb < n_rows; ++bb)
+                if (lane <= groups) {
+                    if (lane >= 1) wavernn_cond_group(p.cond, bb, lane, step + 1);
+                }
+    }
     if (b < p.n_seq) {
         const float* lg = p.logits + (long)b * p.ld_logits;
         float value;
@@ -184,7 +198,16 @@ __global__ __launch_bounds__(256) void wavernn_sample_kernel(const estts_wavernn
         }
         if (lane == 0) {
             p.wave[(long)b * p.ld_wave + step] = value;
-            p.x_prev[b] = p.forced ? p.forced[(long)step * p.n_seq + b] : value;
+            const float fed = p.forced ? p.forced[(long)step * p.n_seq + b] : value;
+            p.x_prev[b] = fed;
+            if (p.with_cond) {   // first column group of the next step's input panel: [x_prev 0 0 0 0 0 0 0] as bf16 hi | lo
+                __bf16 hi, lo;
+                split_bf16(fed, hi, lo);
+                const bf16x8 z = {hi, 0, 0, 0, 0, 0, 0, 0}, zl = {lo, 0, 0, 0, 0, 0, 0, 0};
+                unsigned char* dst = reinterpret_cast<unsigned char*>(p.cond.xin_panel) + (long)(b >> 4) * 4 * 2048 + (b & 15) * 16;
+                *reinterpret_cast<bf16x8*>(dst) = z;
+                *reinterpret_cast<bf16x8*>(dst + 1024) = zl;
+            }
         }
     }
     // the last workgroup to finish has seen every workgroup read step[0]; it advances the counter
@@ -241,6 +264,14 @@ extern "C" int estts_wavernn_sample(const estts_wavernn_sample_args* args, void*
                     "estts_wavernn_sample: mode must be 0 (RAW) or 1 (MOL with <= 64 components)");
     ESTTS_CHECK_ARG(a.mode == 1 || a.n_classes <= 65536, "estts_wavernn_sample: too many classes");
     ESTTS_CHECK_ARG(a.mode == 0 || !a.u_mix == !a.u, "estts_wavernn_sample: MOL needs both u and u_mix or neither");
+    if (a.with_cond) {
+        const estts_wavernn_cond_args& c = a.cond;
+        ESTTS_CHECK_ARG(c.mel && c.aux && c.fir && c.seq_info && ((uintptr_t)c.seq_info & 15) == 0 && c.xin_panel && c.a2_panel && c.a3_panel &&
+                        c.a4_panel, "estts_wavernn_sample: null or misaligned pointer in the conditioning block");
+        ESTTS_CHECK_ARG(c.n_seq == a.n_seq && c.feat > 0 && c.d > 0 && (c.d & 7) == 0 && c.d <= 32 && c.hop > 0 && c.ntaps > 0 &&
+                        8 + c.feat + c.d <= 128 && c.aux_kpitch > c.aux_ks && c.aux_ks >= 0,
+                        "estts_wavernn_sample: bad conditioning block (see estts_wavernn_cond)");
+    }
     hipLaunchKernelGGL(wavernn_sample_kernel, dim3((a.n_seq + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_wavernn_sample");
     return 0;

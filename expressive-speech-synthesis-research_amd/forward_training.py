@@ -676,6 +676,9 @@ class ForwardTransformerTrainer:
         if self._infer is None:
             self._infer = ForwardTransformer(self.weights(), self.config, device=self.device, precision=self.precision,
                                              fold_ffn=False)
+        # (DecoderPrenet's dropout is on in the reference's validation pass too; its seed follows the optimizer step)
+        self._infer.set_constants(decoder_prenet_dropout=self.decoder_prenet_dropout)
+        self._infer.dropout_seed, self._infer._calls = self.seed, self.iterations
         out = self._infer.call(tokens, target_durations=td, max_frames=Tm)
         losses = torch.zeros(2, dtype=torch.float32, device=self.device)
         ops.masked_mae(mel_t.view(B * Tm, -1), out['mel'].reshape(B * Tm, -1), losses[0:1])

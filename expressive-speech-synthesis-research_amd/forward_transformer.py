@@ -26,6 +26,9 @@ class ForwardTransformer:
         self.device = torch.device(device)
         self.precision = precision
         self.drop_n_heads = 0
+        self.decoder_prenet_dropout = 0.0
+        self.dropout_seed = 0
+        self._calls = 0
         self.mel_channels = config['mel_channels']
         w, dev = weights, self.device
         de, dd = config['encoder_model_dimension'], config['decoder_model_dimension']
@@ -92,9 +95,20 @@ class ForwardTransformer:
         de, dd = self.de, self.dd
         d = ws['dec']
         ops.expand(ws['enc']['xc'][:, :de], ws['cum'], ws['mels_in'], ws['frame_mask'], B, N, T, de)
-        ops.gemm(ws['mels_in'], self.prenet1, ws['p1'], precision=self.precision)
+        # DecoderPrenet's dropout runs with training=True at inference too (layers.py:394-402): counter-based masks in the
+        # GEMM epilogue, keyed by (seed, site 1000 / 1001, row, column), a new seed for every call
+        rate = self.decoder_prenet_dropout
+        drop1 = drop2 = None
+        if rate > 0.0:
+            if torch.cuda.is_current_stream_capturing():
+                raise NotImplementedError('decoder_prenet_dropout > 0 cannot be captured into a graph: every replay would '
+                                          'draw the same mask (the seed is a launch argument)')
+            seed = (self.dropout_seed * 1000003 + self._calls * 7919 + 12345) & 0xFFFFFFFF
+            self._calls += 1
+            drop1, drop2 = (rate, seed, 1000, 0), (rate, seed, 1001, 0)
+        ops.gemm(ws['mels_in'], self.prenet1, ws['p1'], precision=self.precision, dropout=drop1)
         ops.gemm(ws['p1'], self.prenet2, d['xc'][:, :dd], alpha=math.sqrt(np.float32(dd)), residual=self.pe_dec,
-                 r_mod=T, precision=self.precision)
+                 r_mod=T, precision=self.precision, dropout=drop2)
         attn = self.decoder.run(d, B, T, ws['frame_mask'], self.precision, return_attention)
         ops.gemm(d['xc'][:, :dd], self.out, ws['mel0'], precision=self.precision)
         mel = torch.empty(B * T, self.mel_channels, dtype=torch.float32, device=self.device)
@@ -155,7 +169,12 @@ class ForwardTransformer:
         return self.call(input_sequence, target_durations=None, training=False, durations_scalar=durations_scalar, **kw)
 
     def set_constants(self, decoder_prenet_dropout=None, learning_rate=None, drop_n_heads=None, **kwargs):
-        """models.py:458-465 (inference object: only head drop is recorded; it is inactive outside training)."""
+        """models.py:458-465.  The decoder-prenet dropout rate takes effect at inference too, as in the reference
+        (layers.py:394-402); head drop is recorded only (it is inactive outside training)."""
+        if decoder_prenet_dropout is not None:
+            if not 0.0 <= float(decoder_prenet_dropout) < 1.0:
+                raise ValueError('decoder_prenet_dropout must be in [0, 1)')
+            self.decoder_prenet_dropout = float(decoder_prenet_dropout)
         if drop_n_heads is not None:
             self.drop_n_heads = drop_n_heads
 

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from ._lib import WavernnPrepArgs, WavernnSampleArgs, check
+from ._lib import WavernnCondArgs, WavernnLayerArgs, WavernnPrepArgs, WavernnSampleArgs, check
 from .ops import PackedLinear
 
 
@@ -122,6 +122,82 @@ def decode_mu_law(y, mu, from_labels=True):
     return np.sign(y) / mu * ((1 + mu) ** np.abs(y) - 1)
 
 
+def _fragment_blocks(w, kp):
+    """float [N, K] -> (hi, lo) int16 tensors [N / 16, kp / 32, 512]: the 1 KiB B-operand images of
+    v_mfma_f32_16x16x32_bf16 (lane l holds W[16 nb + (l & 15)][32 ks + 8 (l >> 4) .. + 7]), K zero-padded to kp."""
+    w = np.asarray(w, np.float32)
+    n, k = w.shape
+    wp = torch.zeros(n, kp, dtype=torch.float32)
+    wp[:, :k] = torch.from_numpy(w)
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.to(torch.float32)).to(torch.bfloat16)
+    img = lambda t: t.view(n // 16, 16, kp // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(n // 16, kp // 32, 512).view(torch.int16)
+    return img(hi), img(lo)
+
+
+def _with_slack(stream):
+    """Flat weight stream followed by 32 KiB of zeros: the layer kernel requests whole chunks unconditionally, so its last
+    workgroup reads (and ignores) up to one chunk past the end."""
+    return torch.cat([stream.reshape(-1), torch.zeros(16384, dtype=stream.dtype)]).contiguous()
+
+
+def pack_gru_stream(x_types, h_types):
+    """Weight stream of a GRU estts_wavernn_layer: for every 16-unit block the fragment images in the order the kernel's K loop
+    consumes them, (x phase: K-step, type, hi | lo), then (h phase: K-step, type, hi | lo).  x_types: float arrays [H, kx]
+    (rnn1: xI, r, z, n; rnn2: r, z, n); h_types: the three [H, H] recurrent matrices (r, z, n)."""
+    kx = x_types[0].shape[1]
+    H = h_types[0].shape[0]
+    if H % 32:
+        raise ValueError('rnn_dims must be a multiple of 32')
+
+    def phase(mats, kp):
+        fr = [_fragment_blocks(m, kp) for m in mats]                          # per type (hi, lo) [nub, nks, 512]
+        t = torch.stack([torch.stack(hl) for hl in fr])                      # [type, 2, nub, nks, 512]
+        return t.permute(2, 3, 0, 1, 4).reshape(H // 16, -1)                # [nub, nks * type * 2 * 512]
+    out = torch.cat([phase(x_types, (kx + 31) // 32 * 32), phase(h_types, H)], dim=1)
+    return _with_slack(out)
+
+
+def pack_dense_stream(w, unit_blocks):
+    """Weight stream of a dense estts_wavernn_layer: rows padded with zeros to whole groups of unit_blocks * 16 units;
+    per group the fragment images in the order (K-step, unit block, hi | lo).  Returns (stream [groups, ...], padded rows)."""
+    w = np.asarray(w, np.float32)
+    n, k = w.shape
+    per = 16 * unit_blocks
+    npad = (n + per - 1) // per * per
+    wp = np.zeros((npad, k), np.float32)
+    wp[:n] = w
+    hi, lo = _fragment_blocks(wp, (k + 31) // 32 * 32)                        # [npad / 16, nks, 512]
+    t = torch.stack([hi, lo], dim=2)                                          # [nub, nks, 2, 512]
+    t = t.view(npad // per, unit_blocks, t.shape[1], 2, 512).permute(0, 2, 1, 3, 4)
+    return _with_slack(t.reshape(npad // per, -1)), npad
+
+
+def panel_alloc(n_seq, kpitch, device):
+    """A zeroed activation panel for n_seq sequences and 32 * kpitch columns (see estts_wavernn_layer)."""
+    return torch.zeros((n_seq + 15) // 16, kpitch, 2, 512, dtype=torch.int16, device=device)
+
+
+def panel_pack(x, kpitch=None):
+    """float [n, K] -> activation panel (bf16 hi + lo fragment blocks) on x's device."""
+    n, k = x.shape
+    kp = (kpitch or (k + 31) // 32) * 32
+    npad = (n + 15) // 16 * 16
+    xp = torch.zeros(npad, kp, dtype=torch.float32, device=x.device)
+    xp[:n, :k] = x
+    hi = xp.to(torch.bfloat16)
+    lo = (xp - hi.to(torch.float32)).to(torch.bfloat16)
+    img = lambda t: t.view(npad // 16, 16, kp // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(npad // 16, kp // 32, 512).view(torch.int16)
+    return torch.stack([img(hi), img(lo)], dim=2).contiguous()
+
+
+def panel_unpack(panel, n, k):
+    """Activation panel -> float32 [n, k] (hi + lo)."""
+    rb, kb = panel.shape[0], panel.shape[1]
+    f = panel.view(torch.bfloat16).to(torch.float32).sum(dim=2)              # [rb, kb, 512]
+    return f.view(rb, kb, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(rb * 16, kb * 32)[:n, :k]
+
+
 def _fold_bn(w, p, eps=1e-5):
     s = np.asarray(w[p + '.weight'], np.float64) / np.sqrt(np.asarray(w[p + '.running_var'], np.float64) + eps)
     b = np.asarray(w[p + '.bias'], np.float64) - np.asarray(w[p + '.running_mean'], np.float64) * s
@@ -152,7 +228,10 @@ class WaveRNN:
         self.precision = precision
         self.step = 0
         self._sd = None
-        self.steps_per_graph = 50
+        self.steps_per_graph = 50        # even: the GRU states ping-pong between two buffers
+        # one launch per layer over activation panels (estts_wavernn_layer); False = separate products and gate launches
+        self.fused = rnn_dims % 32 == 0 and fc_dims == rnn_dims and (res_out_dims // 4) % 8 == 0 and res_out_dims // 4 <= 32 \
+            and 8 + feat_dims + res_out_dims // 4 <= 128
         ops.gemm_workspace(self.device)
 
     @classmethod
@@ -206,6 +285,26 @@ class WaveRNN:
         self.in_proj = PackedLinear(np.concatenate([wI.astype(np.float64), w_ih @ w_i]).astype(np.float32),
                                     bias=np.concatenate([np.asarray(w['I.bias'], np.float64), b_comp]).astype(np.float32), device=dev)
         self.ih2 = PackedLinear(w['rnn2.weight_ih_l0'], bias=w['rnn2.bias_ih_l0'], device=dev)
+        # the one-launch GRU layers (estts_wavernn_layer): one weight stream and one bias table per GRU
+        R = self.rnn_dims
+        wc = (w_ih @ w_i).astype(np.float32)
+        w_hh1, w_hh2 = np.asarray(w['rnn1.weight_hh_l0'], np.float32), np.asarray(w['rnn2.weight_hh_l0'], np.float32)
+        w_ih2 = np.asarray(w['rnn2.weight_ih_l0'], np.float32)
+        thirds = lambda m: [m[i * R:(i + 1) * R] for i in range(3)]
+        # (column order of the step-input panel: x_prev alone in the first group of eight, then mel and the aux slice)
+        spread = lambda m: np.concatenate([m[:, :1], np.zeros((m.shape[0], 7), np.float32), m[:, 1:n_in]], axis=1)
+        self.gru1_w = pack_gru_stream([spread(wI)] + [spread(t) for t in thirds(wc)], thirds(w_hh1)).to(dev)
+        self.gru2_w = pack_gru_stream(thirds(w_ih2), thirds(w_hh2)).to(dev)
+        b_hh1, b_hh2 = np.asarray(w['rnn1.bias_hh_l0'], np.float64), np.asarray(w['rnn2.bias_hh_l0'], np.float64)
+        b_ih2 = np.asarray(w['rnn2.bias_ih_l0'], np.float64)
+        f32 = lambda rows: torch.from_numpy(np.stack(rows).astype(np.float32)).to(dev)
+        self.gru1_b = f32([np.asarray(w['I.bias'], np.float64), b_comp[:R] + b_hh1[:R], b_comp[R:2 * R] + b_hh1[R:2 * R],
+                           b_comp[2 * R:], b_hh1[2 * R:]])
+        self.gru2_b = f32([b_ih2[:R] + b_hh2[:R], b_ih2[R:2 * R] + b_hh2[R:2 * R], b_ih2[2 * R:], b_hh2[2 * R:]])
+        self.n_in = n_in
+        self.k_in_panel = 8 + self.feat_dims + self.aux_dims
+        self.fc_unit_blocks = 1
+        self._pack_fc(w)
         # the two recurrent products depend only on the previous step's states: one batched launch (weights and biases of
         # rnn2 follow rnn1's in one packed buffer; 3R is a multiple of 64, so the second matrix starts on a block boundary)
         self.hh12 = PackedLinear(np.concatenate([np.asarray(w['rnn1.weight_hh_l0']), np.asarray(w['rnn2.weight_hh_l0'])]),
@@ -218,6 +317,16 @@ class WaveRNN:
             raise ValueError(f'fc3 has {self.fc3.N} outputs, mode {self.mode} expects {self.n_classes}')
         self._sd = {k: np.array(v) for k, v in w.items()}
         return self
+
+    def _pack_fc(self, w):
+        """Weight streams and padded biases of fc1, fc2, fc3 for estts_wavernn_layer (re-run after changing fc_unit_blocks)."""
+        dev = self.device
+        self.fc_streams = []
+        for name in ('fc1', 'fc2', 'fc3'):
+            stream, npad = pack_dense_stream(w[name + '.weight'], self.fc_unit_blocks)
+            b = np.zeros(npad, np.float32)
+            b[:w[name + '.bias'].shape[0]] = w[name + '.bias']
+            self.fc_streams.append((stream.to(dev), torch.from_numpy(b).to(dev)))
 
     def state_dict(self):
         sd = {k: torch.from_numpy(np.array(v)) for k, v in self._sd.items()}
@@ -297,15 +406,67 @@ class WaveRNN:
     def _alloc_state(self, n_seq, L):
         f32 = dict(dtype=torch.float32, device=self.device)
         R, d = self.rnn_dims, self.aux_dims
-        return {'xin': torch.zeros(n_seq, self.k_in, **f32),
+        return {'xin': torch.zeros(n_seq, (self.k_in + 31) // 32 * 32, **f32),   # zero beyond the inputs (the fused layer reads whole K-steps)
+                'parity': 0,
+                'panels': self._alloc_panels(n_seq) if self._use_layers() else None,
                 'xg': torch.empty(n_seq, 4 * R, **f32),                       # [I's output | rnn1's input gates]
                 'gi2': torch.empty(n_seq, 3 * R, **f32), 'gh12': torch.empty(2, n_seq, 3 * R, **f32),
                 'h12': torch.zeros(2, n_seq, R, **f32),
-                'x1cat': torch.zeros(n_seq, R + d, **f32), 'x2cat': torch.zeros(n_seq, R + d, **f32),
+                # (row pitch rounded up to whole K-steps of 32 and zero there: the fused layer reads whole K-steps)
+                'x1cat': torch.zeros(n_seq, (R + d + 31) // 32 * 32, **f32)[:, :R + d],
+                'x2cat': torch.zeros(n_seq, R + d, **f32),
                 'f1cat': torch.zeros(n_seq, self.fc_dims + d, **f32), 'f2': torch.empty(n_seq, self.fc_dims, **f32),
                 'logits': torch.empty(n_seq, self.n_classes, **f32), 'x_prev': torch.zeros(n_seq, **f32),
                 'wave': torch.zeros(n_seq, L, **f32), 'step': torch.zeros(1, dtype=torch.int32, device=self.device),
                 'done': torch.zeros(1, dtype=torch.int32, device=self.device)}
+
+    def _use_layers(self):
+        """One launch per layer over activation panels (split-bf16 only); else separate products and gate launches."""
+        return self.fused and self.precision == 'bf16x3'
+
+    def _alloc_panels(self, n_seq):
+        R, F, d, dev = self.rnn_dims, self.fc_dims, self.aux_dims, self.device
+        kx = (R + d + 31) // 32
+        native = (n_seq + 127) // 128 * (R // 16) * 2048
+        two = lambda kp: [panel_alloc(n_seq, kp, dev) for _ in range(2)]
+        # (two sets of the panels the conditioning writes: a step's conditioning is computed beside the previous step's layers)
+        return {'xin': two(4), 'x1': two(kx), 'x2': two(kx), 'f1': two(kx), 'f2': panel_alloc(n_seq, F // 32, dev),
+                'cstep': torch.zeros(2, dtype=torch.int32, device=dev),
+                'h1': [panel_alloc(n_seq, R // 32, dev) for _ in range(2)],
+                'h2': [panel_alloc(n_seq, R // 32, dev) for _ in range(2)],
+                # float32 states and rnn1's output in the GRU layers' own order (see estts_wavernn_layer)
+                'h1_f32': [torch.zeros(native, dtype=torch.float32, device=dev) for _ in range(2)],
+                'h2_f32': [torch.zeros(native, dtype=torch.float32, device=dev) for _ in range(2)],
+                'x1_f32': torch.zeros(native, dtype=torch.float32, device=dev)}
+
+    def _xprev_to_panel(self, st):
+        """First column of the step-input panel from st['x_prev'] (later steps: the sampler writes it)."""
+        x = st['x_prev']
+        hi = x.to(torch.bfloat16)
+        lo = (x - hi.to(torch.float32)).to(torch.bfloat16)
+        b = torch.arange(x.shape[0], device=x.device)
+        pn = st['panels']['xin'][0]
+        pn[b // 16, 0, 0, (b % 16) * 8] = hi.view(torch.int16)
+        pn[b // 16, 0, 1, (b % 16) * 8] = lo.view(torch.int16)
+
+    def _cond_args(self, cond, st, seq_utt, seq_start, n_seq):
+        return [self._cond_args_set(cond, st, seq_utt, seq_start, n_seq, q) for q in (0, 1)]
+
+    def _cond_args_set(self, cond, st, seq_utt, seq_start, n_seq, q):
+        a, pn = WavernnCondArgs(), st['panels']
+        if 'seq_info' not in st:
+            # per sequence: (first mel row + pad - fir_kmin, first aux row, start sample, samples of its utterance)
+            u = seq_utt.long()
+            st['seq_info'] = torch.stack([cond['mel_off'][u] + (self.pad - self.fir_kmin), cond['aux_off'][u], seq_start,
+                                          cond['utt_samples'][u]], dim=1).to(torch.int32).contiguous()
+        a.mel, a.aux, a.fir, a.ntaps = cond['mel'].data_ptr(), cond['aux'].data_ptr(), self.fir.data_ptr(), self.fir.shape[1]
+        a.seq_info = st['seq_info'].data_ptr()
+        a.step, a.done = pn['cstep'][0:].data_ptr(), pn['cstep'][1:].data_ptr()
+        a.xin_panel, a.a2_panel, a.a3_panel, a.a4_panel = (pn[k][q].data_ptr() for k in ('xin', 'x1', 'x2', 'f1'))
+        a.aux_ks, a.aux_kpitch = self.rnn_dims // 32, pn['x1'][q].shape[1]
+        a.n_seq, a.feat, a.d, a.hop = n_seq, self.feat_dims, self.aux_dims, self.hop_length
+        a._keep = (cond, st, seq_utt, seq_start)
+        return a
 
     def _prep_args(self, cond, st, seq_utt, seq_start, n_seq):
         a = WavernnPrepArgs()
@@ -330,6 +491,15 @@ class WaveRNN:
         a.seed = seed & 0xFFFFFFFF
         a.wave, a.ld_wave, a.x_prev = st['wave'].data_ptr(), st['wave'].stride(0), st['x_prev'].data_ptr()
         a.step, a.done, a.n_seq = st['step'].data_ptr(), st['done'].data_ptr(), n_seq
+        if st.get('panels') is not None:
+            # the value fed back also goes to the next step's input panel (the other set); step t uses set t & 1
+            # step t (panel set t & 1) also prepares step t + 1's conditioning, in the other set
+            b = WavernnSampleArgs.from_buffer_copy(a)
+            for args, nxt in ((a, 1), (b, 0)):
+                args.with_cond = 1
+                args.cond = _lib.WavernnCondArgs.from_buffer_copy(st['cond_args'][nxt])
+            a._keep = b._keep = (lg, u, u_mix, forced, st)
+            return [a, b]
         return a
 
     def _one_step(self, st, prep_args, sample_args, logits_out=None):
@@ -338,9 +508,35 @@ class WaveRNN:
         rnn2's input product, gates, fc1, fc2, fc3, sampling."""
         lib, R, F, pr = _lib.load(), self.rnn_dims, self.fc_dims, self.precision
         n = st['h12'].shape[1]
+        if self._use_layers():
+            # Step t works on panel set q = t & 1.  6 launches: rnn1 (with the input layer), rnn2, fc1, fc2, fc3, sampling; the
+            # sampler also writes the next step's conditioning (and x_prev) into the other set, its loads overlapping the
+            # softmax.  (The conditioning as a launch of its own cost 10 us + a launch boundary per step; on a second
+            # stream beside the previous step's layers it was slower still, 106 vs 89 us per step: the fork and join edges
+            # of the captured graph cost more than the kernel they take off the path.)
+            pn = st['panels']
+            q = st['parity']
+            st['parity'] ^= 1
+            n_seq = st['h12'].shape[1]
+            if not st.get('cond_primed'):        # the first step's own conditioning
+                check(lib.estts_wavernn_cond(st['cond_args'][q], ops._stream()), 'estts_wavernn_cond')
+                st['cond_primed'] = True
+            self._layer(1, n_seq, R, pn['xin'][q], (self.k_in_panel + 31) // 32, self.gru1_w, self.gru1_b, a1=pn['h1'][q],
+                        h_prev=pn['h1_f32'][q], h_out=pn['h1_f32'][q ^ 1], h_panel=pn['h1'][q ^ 1], out_f32=pn['x1_f32'],
+                        out_panel=pn['x1'][q])
+            self._layer(2, n_seq, R, pn['x1'][q], pn['x1'][q].shape[1], self.gru2_w, self.gru2_b, a1=pn['h2'][q],
+                        h_prev=pn['h2_f32'][q], h_out=pn['h2_f32'][q ^ 1], h_panel=pn['h2'][q ^ 1], x_res=pn['x1_f32'],
+                        out_panel=pn['x2'][q])
+            (w1, b1), (w2, b2), (w3, b3) = self.fc_streams
+            self._layer(0, n_seq, F, pn['x2'][q], pn['x2'][q].shape[1], w1, b1, act='relu', out_panel=pn['f1'][q])
+            self._layer(0, n_seq, F, pn['f1'][q], pn['f1'][q].shape[1], w2, b2, act='relu', out_panel=pn['f2'])
+            self._layer(0, n_seq, self.n_classes, pn['f2'], pn['f2'].shape[1], w3, b3,
+                        out_f32=st['logits'] if logits_out is None else logits_out)
+            check(lib.estts_wavernn_sample(sample_args[q], ops._stream()), 'estts_wavernn_sample')
+            return
+        check(lib.estts_wavernn_prep(prep_args, ops._stream()), 'estts_wavernn_prep')
         h1, h2 = st['h12'][0], st['h12'][1]
         xI, gi1 = st['xg'][:, :R], st['xg'][:, R:]
-        check(lib.estts_wavernn_prep(prep_args, ops._stream()), 'estts_wavernn_prep')
         ops.gemm(st['xin'], self.in_proj, st['xg'], precision=pr)
         ops.gemm(h1, self.hh12, st['gh12'][0], precision=pr, split=False,
                  batch=(2, n * R, 3 * R * self.hh12.ldw, n * 3 * R, 3 * R))
@@ -352,6 +548,29 @@ class WaveRNN:
         ops.gemm(st['f2'], self.fc3, st['logits'] if logits_out is None else logits_out, precision=pr)
         check(lib.estts_wavernn_sample(sample_args, ops._stream()), 'estts_wavernn_sample')
 
+    def _layer(self, mode, n_seq, n_units, a0, ks0, w, b, a1=None, h_prev=None, h_out=None, h_panel=None, x_res=None,
+               out_f32=None, out_panel=None, act=None):
+        a = WavernnLayerArgs()
+        a.a0, a.ks0, a.kpitch0 = a0.data_ptr(), ks0, a0.shape[1]
+        if a1 is not None:
+            a.a1, a.ks1, a.kpitch1 = a1.data_ptr(), n_units // 32, a1.shape[1]
+            a.h_prev, a.h_out = h_prev.data_ptr(), h_out.data_ptr()
+            a.h_panel, a.h_kpitch = h_panel.data_ptr(), h_panel.shape[1]
+        if x_res is not None:
+            a.x_res = x_res.data_ptr()
+        a.W, a.bias = w.data_ptr(), b.data_ptr()
+        a.n_seq, a.n_units, a.mode, a.act, a.unit_blocks = n_seq, n_units, mode, _lib.ACT[act], self.fc_unit_blocks
+        if out_f32 is not None:
+            a.out_f32, a.ldo = out_f32.data_ptr(), (out_f32.stride(0) if out_f32.dim() == 2 else 0)
+        if out_panel is not None:
+            a.out_panel, a.out_kpitch = out_panel.data_ptr(), out_panel.shape[1]
+        check(_lib.load().estts_wavernn_layer(a, ops._stream()), 'estts_wavernn_layer')
+        k = 32 * ks0
+        macs = n_units * ({0: 1, 1: 4, 2: 3}[mode] * k + (3 * n_units if mode else 0))
+        ops._record('wavernn_layer', {'mode': mode, 'n_seq': n_seq, 'n_units': n_units, 'K': k, 'flops': 2.0 * n_seq * macs,
+                                      'bytes': 4.0 * macs + 4.0 * n_seq * (k + (n_units if mode else 0) + n_units)},
+                    _lib.load().estts_wavernn_layer, a, keep=(a0, w, b, a1, h_prev, h_out, h_panel, x_res, out_f32, out_panel))
+
     def _gates(self, gi, gh, h, x_res, out):
         M, H = h.shape
         check(_lib.load().estts_gru_gates(gi.data_ptr(), gi.stride(0), gh.data_ptr(), gh.stride(0), h.data_ptr(), h.stride(0),
@@ -360,6 +579,8 @@ class WaveRNN:
 
     def _run_steps(self, st, prep_args, sample_args, L, use_graph):
         n = self.steps_per_graph
+        if n % 2:
+            raise ValueError('steps_per_graph must be even (the GRU states alternate between two buffers)')
         done = 0
         if use_graph and L >= 2 * n:
             self._one_step(st, prep_args, sample_args)          # warm-up outside capture (also step 0)
@@ -414,6 +635,8 @@ class WaveRNN:
                 raise ValueError(f'uniforms must have shape {(L, n_seq)}, got {tuple(u.shape)}')
         forced_d = None if forced is None else torch.as_tensor(np.asarray(forced), **f32).contiguous()
         prep_args = self._prep_args(cond, st, seq_utt_d, seq_start_d, n_seq)
+        if self._use_layers():
+            st['cond_args'] = self._cond_args(cond, st, seq_utt_d, seq_start_d, n_seq)
         sample_args = self._sample_args(st, n_seq, seed, u, u_mix, forced_d)
         self._run_steps(st, prep_args, sample_args, L, use_graph)
         raw = st['wave'].cpu().numpy().astype(np.float64)
@@ -456,10 +679,14 @@ class WaveRNN:
         st = self._alloc_state(B, L)
         xd = x.to(self.device)
         st['x_prev'].copy_(xd[:, 0])
+        if self._use_layers():
+            self._xprev_to_panel(st)
         forced = torch.zeros(L, B, dtype=torch.float32, device=self.device)
         forced[:L - 1] = xd[:, 1:].t()
         logits = torch.empty(L, B, self.n_classes, dtype=torch.float32, device=self.device)
         prep_args = self._prep_args(cond, st, seq_utt, seq_start, B)
+        if self._use_layers():
+            st['cond_args'] = self._cond_args(cond, st, seq_utt, seq_start, B)
         for t in range(L):
             sample_args = self._sample_args(st, B, 0, None, None, forced, logits=logits[t])
             self._one_step(st, prep_args, sample_args, logits_out=logits[t])

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 17
+#define ESTTS_ABI_VERSION 21
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -274,6 +274,77 @@ int estts_wavernn_prep(const estts_wavernn_prep_args* args, void* stream);
 int estts_gru_gates(const float* gi, int32_t ldgi, const float* gh, int32_t ldgh, float* h, int32_t ldh,
                     const float* x_res, int32_t ldx, float* out, int32_t ldo, int32_t M, int32_t H, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * WaveRNN generation, one launch per layer.  Between the layers an activation matrix X[n_seq, K] is an "activation
+ * panel": bf16 hi + lo (x = hi + lo to ~16 mantissa bits) in 1 KiB blocks, one per (16 sequences, 32 columns); block
+ * (rb, kb) starts at ((rb * kpitch + kb) * 2 + s) KiB (s = 0 hi, 1 lo) and holds for lane l = 0..63 the eight values
+ * X[16 rb + (l & 15)][32 kb + 8 (l >> 4) .. + 7], the A operand of v_mfma_f32_16x16x32_bf16.  A panel has
+ * ceil(n_seq / 16) row blocks of kpitch column blocks; columns no layer writes must be zero (allocate zeroed).
+ *
+ * estts_wavernn_layer, products in split-bf16 (hi * hi + lo * hi + hi * lo, fp32 accumulate):
+ *   mode 0 (dense: fc1, fc2, fc3):  y = act(W a0 + bias), a0 = panel of ks0 K-steps;
+ *          written to out_f32 [n_seq, ldo] and / or to columns [0, n_units) of out_panel (either may be NULL).
+ *          W: for each group of unit_blocks * 16 units, the fragment images (K-step, unit block, hi | lo); rows are padded
+ *          with zeros to a whole group, bias likewise.
+ *   mode 1 (rnn1 with the input layer) / mode 2 (rnn2), torch's gate order (r, z, n), x = a0 row, h = a1 row (the previous
+ *          state, ks1 = n_units / 32 K-steps):
+ *            r = sigmoid(Wx_r x + Wh_r h + b_r);  z = sigmoid(Wx_z x + Wh_z h + b_z);  n = tanh(Wx_n x + b_in + r (Wh_n h + b_hn))
+ *            h' = (1 - z) n + z h_prev;   y = h' + res
+ *          mode 1: x = the step input, Wx_* = W_ih W_I composed by the host, res = W_I x + b_I (the input layer's output,
+ *          a fifth sum); accumulators xI r z gi_n gh_n, bias rows [5][n_units] in that order (b_r, b_z = input-side + recurrent).
+ *          mode 2: res = x_res [n_seq, ldr]; accumulators r z gi_n gh_n, bias [4][n_units].
+ *          h' goes to h_out (must differ from h_prev) and h_panel (must differ from a1); y to out_f32 (may be NULL) and
+ *          out_panel.  The float32 arrays of a GRU call -- h_prev, h_out, x_res, out_f32 -- are private to the layer pair and
+ *          "tile-native": ceil(n_seq / 128) * (n_units / 16) * 2048 floats, element ((workgroup * 8 + wave) * 64 + lane) * 4 + j
+ *          being the (sequence, unit) pair that lane owns (the ld* fields are ignored); rnn2's x_res is rnn1's out_f32.
+ *          Zero them before the first step.  W: for each 16-unit block (phase 0: K-step, accumulator it feeds, hi | lo), then
+ *          (phase 1: K-step, r z gh_n, hi | lo).
+ * Replaces: self.I, nn.GRUCell x 2 with their residual adds, fc1 / fc2 (+ ReLU) and fc3 of one generation step,
+ * WaveRNN/models/fatchord_version.py:188-208.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct estts_wavernn_layer_args {
+    const uint16_t* a0; int32_t ks0; int32_t kpitch0;
+    const uint16_t* a1; int32_t ks1; int32_t kpitch1;      /* GRU: previous state panel */
+    const uint16_t* W;
+    const float* bias;
+    int32_t n_seq, n_units, mode, act, unit_blocks;        /* unit_blocks (dense only): 1, 2 or 4 blocks of 16 units per workgroup */
+    const float* h_prev; int32_t ldh;
+    const float* x_res; int32_t ldr;
+    float* h_out; int32_t ldho;
+    uint16_t* h_panel; int32_t h_kpitch;
+    float* out_f32; int32_t ldo;
+    uint16_t* out_panel; int32_t out_kpitch;
+} estts_wavernn_layer_args;
+
+int estts_wavernn_layer(const estts_wavernn_layer_args* args, void* stream);
+
+/* The conditioning of one step as panels (the arithmetic of estts_wavernn_prep): for sequence b at step s = step[0], with
+ * seq_info[b] = (m0, a0, start, live): sample n = start + s of its utterance, frame = n / hop, phase = n % hop,
+ *   mel columns:  sum_j fir[phase, j] * mel[m0 + frame - j, :]      (m0 = first padded mel row of the utterance + pad - fir_kmin)
+ *   aux columns:  aux[a0 + frame, :]                                 (a0 = first MelResNet row of the utterance)
+ * all zero when n >= live (the zero padding fold_with_overlap appends).
+ * xin_panel (kpitch 4: 128 columns) = [x_prev 0 0 0 0 0 0 0 | mel filtered to sample rate | aux slice 1 | zeros], of which this
+ * call writes everything but the first group of eight columns (estts_wavernn_sample writes that one); the aux slices 2, 3, 4
+ * (d columns each, d a multiple of 8, at most 32) go to K-step aux_ks of a2_panel, a3_panel, a4_panel (kpitch aux_kpitch):
+ * the inputs of rnn2, fc1 and fc2, whose first aux_ks K-steps the preceding layers fill.  The call keeps a step counter of
+ * its own (`step`, advanced by one per call).  The caller checks once that the filter stays inside the padded mels
+ * (pad - fir_kmin - (ntaps - 1) >= 0 and pad + fir_kmin >= 0).
+ * Replaces: what estts_wavernn_prep replaces. */
+typedef struct estts_wavernn_cond_args {
+    const float* mel;
+    const float* aux;
+    const float* fir; int32_t ntaps;
+    const int32_t* seq_info;  /* [n_seq][4], 16-byte aligned */
+    int32_t* step;            /* this call's own step counter (not the sampler's): read, then advanced by one */
+    int32_t* done;            /* one zero-initialised int32 used to find the last workgroup, which advances step[0] */
+    uint16_t* xin_panel;
+    uint16_t* a2_panel; uint16_t* a3_panel; uint16_t* a4_panel;
+    int32_t aux_ks, aux_kpitch;
+    int32_t n_seq, feat, d, hop;
+} estts_wavernn_cond_args;
+
+int estts_wavernn_cond(const estts_wavernn_cond_args* args, void* stream);
+
 /* Draws the next sample of every sequence from its logits and advances step[0].
  * mode 0 (RAW): softmax, inverse CDF at u (class = number of cdf entries <= u), value 2 c / (n - 1) - 1.
  * mode 1 (MOL): mixture of logistics with nr_mix = n_classes / 3 components, Gumbel-max component pick from
@@ -292,9 +363,15 @@ typedef struct estts_wavernn_sample_args {
     float* x_prev;
     int32_t* step; int32_t* done;
     int32_t n_seq;
+    int32_t with_cond;       /* 1: also prepare the NEXT step's conditioning (step[0] + 1) into the panels of `cond`, exactly as
+                                estts_wavernn_cond would, plus the value fed back as bf16 hi | lo followed by seven zeros in the
+                                first column group of cond.xin_panel; cond.step / cond.done are not used */
+    estts_wavernn_cond_args cond;
 } estts_wavernn_sample_args;
 
 int estts_wavernn_sample(const estts_wavernn_sample_args* args, void* stream);
+
+
 
 /* ==========================================================================================
  * Training (ForwardTransformer._train_step, pretrained_models/for_text_encoder/models.py:389-404:

@@ -271,8 +271,9 @@ def postnet_ar(x, w, prefix, n_layers):
 # --------------------------------------------------------------------------
 # ForwardTransformer (pretrained_models/for_text_encoder/models.py:283-477)
 # --------------------------------------------------------------------------
-def forward_transformer_call(w, cfg, tokens, target_durations=None, durations_scalar=1.0, dtype=np.float64):
-    """models.py:434-456, training=False.
+def forward_transformer_call(w, cfg, tokens, target_durations=None, durations_scalar=1.0, dtype=np.float64, prenet_masks=None):
+    """models.py:434-456, training=False.  prenet_masks: the two scaled keep masks of DecoderPrenet's dropout, which the
+    reference applies at inference too (layers.py:394-402); None = rate 0.
 
     tokens (B,N) int; target_durations (B,N) or None.  Returns dict with 'mel',
     'duration', 'expanded_mask', 'encoder_attention', 'decoder_attention'.
@@ -292,7 +293,7 @@ def forward_transformer_call(w, cfg, tokens, target_durations=None, durations_sc
     else:
         mels = expand(x, durations)
     expanded_mask = create_mel_padding_mask(mels).astype(dtype)
-    mels = decoder_prenet(mels, w, 'decoder_prenet')
+    mels = decoder_prenet(mels, w, 'decoder_prenet', prenet_masks)
     mels, dec_attn = self_attention_blocks(
         mels, expanded_mask, w, 'decoder', cfg['decoder_model_dimension'], cfg['decoder_num_heads'],
         cfg['decoder_dense_blocks'], cfg['decoder_attention_conv_kernel'],

@@ -224,3 +224,34 @@ def test_two_adam_steps_follow_the_oracle_and_training_reduces_the_loss():
     assert losses[-1] < 0.8 * losses[0], losses
     val = model.val_step(tokens, mel, durs)
     assert np.isfinite(float(val['loss']))
+
+
+def test_val_step_and_inference_honour_decoder_prenet_dropout():
+    """DecoderPrenet's dropout is on at inference in the reference (layers.py:394-402, training=True hard-coded), at the rate
+    set_constants sets: val_step and ForwardTransformer.call against the float64 oracle on the device's own masks."""
+    from estts import train_ops as T
+    from estts.forward_training import ForwardTransformerTrainer
+    from oracle import tts_numpy as O
+    cfg = small_cfg(0.0)
+    w = weights.init_forward_transformer(cfg, seed=23)
+    B, N = 2, 13
+    tokens, mel, durs = batch(cfg, B, N, seed=11)
+    Tm = mel.shape[1]
+    model = ForwardTransformerTrainer(w, cfg, seed=4)
+    model.set_constants(decoder_prenet_dropout=0.5)
+    seed_now = (4 * 1000003 + 0 * 7919 + 12345) & 0xFFFFFFFF
+    pm = []
+    for site, width in ((1000, cfg['decoder_feed_forward_dimension']), (1001, cfg['decoder_model_dimension'])):
+        ones = torch.ones(B * Tm, width, device='cuda')
+        T.dropout(ones, ones, 0.5, seed_now, site)
+        pm.append(ones.cpu().numpy().astype(np.float64).reshape(B, Tm, width))
+    ref = O.forward_transformer_call(w, cfg, tokens, durs, prenet_masks=pm)
+    plain = O.forward_transformer_call(w, cfg, tokens, durs)
+    out = model.val_step(tokens, mel, durs)
+    assert np.abs(out['mel'].cpu().numpy() - ref['mel']).max() < 5e-4
+    assert np.abs(plain['mel'] - ref['mel']).max() > 1e-2                 # the masks matter
+    l_mel = OT.masked_mae(torch.tensor(mel, dtype=torch.float64), torch.tensor(ref['mel']))
+    assert abs(float(out['losses']['mel']) - float(l_mel)) < 1e-4
+    model.set_constants(decoder_prenet_dropout=0.0)
+    out0 = model.val_step(tokens, mel, durs)
+    assert np.abs(out0['mel'].cpu().numpy() - plain['mel']).max() < 5e-4

@@ -135,3 +135,105 @@ def test_checkpoint_round_trip(tmp_path):
     assert m2.get_step() == 4321
     sd = torch.load(path, weights_only=True)
     assert set(k for k in sd if k != 'step') == set(w)
+
+
+def _layer_args(_lib, n_seq, n_units, mode, a0, ks0, w, b, **kw):
+    a = _lib.WavernnLayerArgs()
+    a.a0, a.ks0, a.kpitch0 = a0.data_ptr(), ks0, a0.shape[1]
+    a.W, a.bias = w.data_ptr(), b.data_ptr()
+    a.n_seq, a.n_units, a.mode = n_seq, n_units, mode
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if torch.is_tensor(v) else v)
+    return a
+
+
+@pytest.mark.parametrize('n_seq,H,kx,mode', [(832, 512, 113, 1), (832, 512, 544, 2), (5, 64, 89, 1), (131, 64, 72, 2)])
+def test_gru_layer_vs_float64(n_seq, H, kx, mode):
+    """estts_wavernn_layer modes 1 / 2 (both products, gates, state update, residual in one launch, activation panels in and
+    out) against the float64 formula of torch.nn.GRUCell (fatchord_version.py:188-195) on the panels' own (hi + lo) values.
+    Tolerance 5e-5: split-bf16 products, float32 gate math; the panel outputs round to ~2^-17 relative."""
+    from estts import _lib, ops
+    from estts.wavernn import pack_gru_stream, panel_alloc, panel_pack, panel_unpack
+    rng = np.random.default_rng(n_seq + kx)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    xp = panel_pack(d(rng.normal(size=(n_seq, kx)).astype(np.float32)))
+    h = rng.uniform(-1, 1, size=(n_seq, H)).astype(np.float32)
+    hpan = panel_pack(d(h))
+    sc = 1.0 / np.sqrt(H)
+    wx = [(rng.normal(size=(H, kx)) * sc).astype(np.float32) for _ in range(4 if mode == 1 else 3)]
+    wh = [(rng.normal(size=(H, H)) * sc).astype(np.float32) for _ in range(3)]
+    b = rng.normal(size=(5 if mode == 1 else 4, H)).astype(np.float32) * 0.3
+    res = rng.normal(size=(n_seq, H)).astype(np.float32)
+    bd, wd = d(b), pack_gru_stream(wx, wh).cuda()
+    # the layer's float32 side arrays are tile-native: element ((workgroup * 8 + wave) * 64 + lane) * 4 + j is the pair
+    # (sequence 128 mt + 32 (wave & 3) + 16 (wave >> 2) + 4 (lane >> 4) + j, unit 16 ub + (lane & 15)), workgroup = mt * (H / 16) + ub
+    n_mt, n_ub = (n_seq + 127) // 128, H // 16
+    wg, wv, ln, jj = np.meshgrid(np.arange(n_mt * n_ub), np.arange(8), np.arange(64), np.arange(4), indexing='ij')
+    rows = 128 * (wg // n_ub) + 32 * (wv & 3) + 16 * (wv >> 2) + 4 * (ln >> 4) + jj
+    units = 16 * (wg % n_ub) + (ln & 15)
+    ok = rows < n_seq
+    to_native = lambda m: d(np.where(ok, m[np.minimum(rows, n_seq - 1), units], 0).astype(np.float32).reshape(-1))
+
+    def from_native(t):
+        out = np.zeros((n_seq, H), np.float32)
+        out[rows[ok], units[ok]] = t.cpu().numpy().reshape(rows.shape)[ok]
+        return out
+    hd, resd = to_native(h), to_native(res)
+    h_out = torch.full_like(hd, float('nan'))
+    out = torch.full_like(hd, float('nan'))
+    h_new_p, out_p = panel_alloc(n_seq, H // 32, 'cuda'), panel_alloc(n_seq, H // 32 + 1, 'cuda')
+    a = _layer_args(_lib, n_seq, H, mode, xp, xp.shape[1], wd, bd, a1=hpan, ks1=H // 32, kpitch1=hpan.shape[1], h_prev=hd,
+                    h_out=h_out, h_panel=h_new_p, h_kpitch=h_new_p.shape[1], out_f32=out, out_panel=out_p,
+                    out_kpitch=out_p.shape[1])
+    if mode == 2:
+        a.x_res = resd.data_ptr()
+    _lib.check(_lib.load().estts_wavernn_layer(a, ops._stream()), 'estts_wavernn_layer')
+    h_out, out = torch.from_numpy(from_native(h_out)), torch.from_numpy(from_native(out))
+    x64 = panel_unpack(xp, n_seq, kx).cpu().numpy().astype(np.float64)        # what the kernel multiplies: hi + lo
+    hx64 = panel_unpack(hpan, n_seq, H).cpu().numpy().astype(np.float64)
+    b64 = b.astype(np.float64)
+    o = 1 if mode == 1 else 0
+    sig = lambda v: 1 / (1 + np.exp(-v))
+    r = sig(x64 @ wx[o].T.astype(np.float64) + hx64 @ wh[0].T.astype(np.float64) + b64[o])
+    z = sig(x64 @ wx[o + 1].T.astype(np.float64) + hx64 @ wh[1].T.astype(np.float64) + b64[o + 1])
+    n = np.tanh(x64 @ wx[o + 2].T.astype(np.float64) + b64[o + 2] + r * (hx64 @ wh[2].T.astype(np.float64) + b64[o + 3]))
+    hn = (1 - z) * n + z * h.astype(np.float64)
+    y = (x64 @ wx[0].T.astype(np.float64) + b64[0] if mode == 1 else res.astype(np.float64)) + hn
+    assert np.abs(h_out.cpu().numpy() - hn).max() < 5e-5
+    assert np.abs(out.cpu().numpy() - y).max() < 5e-5
+    assert np.abs(panel_unpack(h_new_p, n_seq, H).cpu().numpy() - hn).max() < 6e-5
+    assert np.abs(panel_unpack(out_p, n_seq, H).cpu().numpy() - y).max() < 1e-4
+    assert float(panel_unpack(out_p, n_seq, 32 * out_p.shape[1])[:, H:].abs().max()) == 0.0     # columns past n_units untouched
+
+
+@pytest.mark.parametrize('n_seq,N,K,nb,act', [(832, 512, 544, 1, 'relu'), (832, 512, 512, 4, None), (70, 30, 64, 1, None),
+                                              (300, 512, 544, 2, 'relu'), (17, 32, 96, 2, 'relu')])
+def test_dense_layer_vs_float64(n_seq, N, K, nb, act):
+    from estts import _lib, ops
+    from estts.wavernn import pack_dense_stream, panel_alloc, panel_pack, panel_unpack
+    rng = np.random.default_rng(n_seq + N + K)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    xp = panel_pack(d(rng.normal(size=(n_seq, K)).astype(np.float32)))
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    stream, npad = pack_dense_stream(w, nb)
+    b = np.zeros(npad, np.float32)
+    b[:N] = rng.normal(size=N)
+    out = torch.full((n_seq, N), float('nan'), device='cuda')
+    out_p = panel_alloc(n_seq, (N + 31) // 32, 'cuda')
+    a = _layer_args(_lib, n_seq, N, 0, xp, xp.shape[1], stream.cuda(), d(b), act=_lib.ACT[act], unit_blocks=nb, out_f32=out, ldo=N,
+                    out_panel=out_p, out_kpitch=out_p.shape[1])
+    _lib.check(_lib.load().estts_wavernn_layer(a, ops._stream()), 'estts_wavernn_layer')
+    x64 = panel_unpack(xp, n_seq, K).cpu().numpy().astype(np.float64)
+    y = x64 @ w.T.astype(np.float64) + b[:N]
+    if act == 'relu':
+        y = np.maximum(y, 0)
+    assert np.abs(out.cpu().numpy() - y).max() < 5e-5
+    assert np.abs(panel_unpack(out_p, n_seq, N).cpu().numpy() - y).max() < 1e-4
+
+
+def test_panel_pack_round_trip():
+    from estts.wavernn import panel_pack, panel_unpack
+    x = torch.randn(37, 75, device='cuda')
+    p = panel_pack(x)
+    assert tuple(p.shape) == (3, 3, 2, 512)
+    assert ((panel_unpack(p, 37, 75) - x).abs() / x.abs().clamp(min=1.0)).max().item() < 2e-5      # hi + lo keeps ~16 mantissa bits

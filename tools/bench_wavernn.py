@@ -21,11 +21,14 @@ ap.add_argument('--precision', default='bf16x3')
 ap.add_argument('--target', type=int, default=11000)
 ap.add_argument('--overlap', type=int, default=550)
 ap.add_argument('--steps-per-graph', type=int, default=50)
+ap.add_argument('--unfused', action='store_true', help='separate products and gate launches for the GRU layers')
 args = ap.parse_args()
 hp = configs.wavernn_hparams_22k() if args.hop == 256 else configs.wavernn_hparams(voc_mode='RAW')
 m = WaveRNN.from_hparams(hp, precision=args.precision)
 m.load_state_dict(weights.init_wavernn(hp, seed=1234))
 m.steps_per_graph = args.steps_per_graph
+if args.unfused:
+    m.fused = False
 rng = np.random.default_rng(1234)
 mels = [rng.uniform(0, 1, size=(hp['num_mels'], args.frames)).astype(np.float32) for _ in range(args.utts)]
 torch.cuda.synchronize()
