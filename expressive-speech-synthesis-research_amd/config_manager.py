@@ -124,16 +124,19 @@ class ConfigManager:
             model._compile(optimizer=self.new_adam(self.learning_rate))
 
     @staticmethod
-    def save_weights(path, weights, step=0):
+    def save_weights(path, weights, step=0, optimizer_state=None):
+        """optimizer_state: the trainer's optimizer_state() (Adam moments, step count, seed), stored beside the variables under
+        keys of the form __name__ as the reference's tf.train.Checkpoint(step, optimizer, net) stores its optimizer."""
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        np.savez(path, __step__=np.int64(step), **{k: np.asarray(v) for k, v in weights.items()})
+        np.savez(path, __step__=np.int64(step), **{k: np.asarray(v) for k, v in weights.items()}, **(optimizer_state or {}))
 
     @staticmethod
-    def read_weights(path):
+    def read_weights(path, with_optimizer=False):
         with np.load(path, allow_pickle=False) as z:
-            w = {k: z[k] for k in z.files if k != '__step__'}
+            w = {k: z[k] for k in z.files if not k.startswith('__')}
             step = int(z['__step__']) if '__step__' in z.files else 0
-        return w, step
+            opt = {k: z[k] for k in z.files if k.startswith('__') and k != '__step__'}
+        return (w, step, opt) if with_optimizer else (w, step)
 
     def latest_checkpoint(self):
         """Newest ckpt-<step>.npz of this package, else the TensorFlow checkpoint prefix the reference's CheckpointManager
@@ -171,6 +174,10 @@ class ConfigManager:
         self.compile_model(model)
         if training:
             model.iterations = step
+            if path and path.endswith('.npz'):
+                opt = self.read_weights(path, with_optimizer=True)[2]
+                if '__adam_m__' in opt:                 # resume Adam where it stopped (moments, step count, dropout seed)
+                    model.load_optimizer_state(opt)
         if verbose and path:
             print(f'restored weights from {path} at step {step}')
         const = {}

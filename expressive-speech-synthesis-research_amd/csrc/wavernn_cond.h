@@ -19,22 +19,43 @@ __device__ __forceinline__ void wavernn_cond_group(const estts_wavernn_cond_args
         const int frame = s / p.hop;
         const int phase = s - frame * p.hop;
         const int n_in = 8 + p.feat + p.d;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int col = q < 16 ? 8 * q + e : 128 + 8 * (q - 16) + e;
-            float x = 0.0f;
-            if (live) {
-                if (col < 8 + p.feat) {
-                    const float* m = p.mel + (long)(info.x + frame) * p.feat + (col - 8);
-                    const float* f = p.fir + phase * p.ntaps;
-                    for (int j = 0; j < p.ntaps; ++j) x += f[j] * m[-(long)j * p.feat];
-                } else if (col < n_in) {
-                    x = p.aux[(long)(info.y + frame) * (4 * p.d) + (col - 8 - p.feat)];
-                } else if (col >= 128) {
-                    x = p.aux[(long)(info.y + frame) * (4 * p.d) + p.d + (col - 128)];
+        const int col0 = q < 16 ? 8 * q : 128 + 8 * (q - 16);
+        if (live && (p.feat & 7) == 0) {
+            // whole groups of eight columns never straddle the mel / aux boundary: two 16-byte loads per filter tap or aux row
+            if (col0 >= 8 && col0 < 8 + p.feat) {
+                const float* m = p.mel + (long)(info.x + frame) * p.feat + (col0 - 8);
+                const float* f = p.fir + phase * p.ntaps;
+                for (int j = 0; j < p.ntaps; ++j) {
+                    const float fj = f[j];
+                    const float4 a = *reinterpret_cast<const float4*>(m - (long)j * p.feat);
+                    const float4 c = *reinterpret_cast<const float4*>(m - (long)j * p.feat + 4);
+                    v[0] += fj * a.x; v[1] += fj * a.y; v[2] += fj * a.z; v[3] += fj * a.w;
+                    v[4] += fj * c.x; v[5] += fj * c.y; v[6] += fj * c.z; v[7] += fj * c.w;
                 }
+            } else if ((col0 >= 8 + p.feat && col0 < n_in) || col0 >= 128) {
+                const float* src = p.aux + (long)(info.y + frame) * (4 * p.d) + (col0 >= 128 ? p.d + (col0 - 128) : col0 - 8 - p.feat);
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                const float4 c = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
             }
-            v[e] = x;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int col = col0 + e;
+                float x = 0.0f;
+                if (live) {
+                    if (col >= 8 && col < 8 + p.feat) {
+                        const float* m = p.mel + (long)(info.x + frame) * p.feat + (col - 8);
+                        const float* f = p.fir + phase * p.ntaps;
+                        for (int j = 0; j < p.ntaps; ++j) x += f[j] * m[-(long)j * p.feat];
+                    } else if (col >= 8 + p.feat && col < n_in) {
+                        x = p.aux[(long)(info.y + frame) * (4 * p.d) + (col - 8 - p.feat)];
+                    } else if (col >= 128) {
+                        x = p.aux[(long)(info.y + frame) * (4 * p.d) + p.d + (col - 128)];
+                    }
+                }
+                v[e] = x;
+            }
         }
     }
     bf16x4 h0, l0, h1, l1;

@@ -223,9 +223,10 @@ class ForwardTransformerTrainer:
         self.precision = precision
         self.seed = int(seed)
         self.pg = process_group
-        self.world = 1
+        self.world, self.rank = 1, 0
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
         self.mel_channels = cfg['mel_channels']
         self.dropout_rate = float(cfg.get('dropout_rate', 0.1))
@@ -476,6 +477,30 @@ class ForwardTransformerTrainer:
         """models.py:430-432 (optimizer iterations)."""
         return self.iterations
 
+    def optimizer_state(self):
+        """Adam's state for a checkpoint: the first and second moments (flat, in the parameter buffer's order), the step count
+        and the dropout seed (the reference checkpoints its optimizer: tf.train.Checkpoint(step, optimizer, net),
+        train_forward.py:105-111)."""
+        st = self.store
+        return {'__adam_m__': st.m.cpu().numpy(), '__adam_v__': st.v.cpu().numpy(),
+                '__iterations__': np.asarray(self.iterations, np.int64), '__seed__': np.asarray(self.seed, np.int64)}
+
+    def load_optimizer_state(self, state):
+        st = self.store
+        m, v = np.asarray(state['__adam_m__'], np.float32), np.asarray(state['__adam_v__'], np.float32)
+        if m.shape != tuple(st.m.shape) or v.shape != tuple(st.v.shape):
+            raise ValueError(f'optimizer state of {m.shape[0]} elements does not fit this model ({st.m.shape[0]})')
+        st.m.copy_(torch.from_numpy(m))
+        st.v.copy_(torch.from_numpy(v))
+        self.iterations = int(state['__iterations__'])
+        self.seed = int(state['__seed__'])
+
+    def broadcast_moving_statistics(self, src=0):
+        """BatchNorm moving statistics are per replica during data-parallel training (the reference is single-GPU; there is
+        no SyncBN): before a checkpoint every rank takes rank `src`'s, so that all replicas resume from what was saved."""
+        if self.world > 1:
+            torch.distributed.broadcast(self.store.state, src=src, group=self.pg)
+
     def weights(self):
         """Current variables as a dict name -> ndarray in the layouts of weights.py (for ForwardTransformer / checkpoints)."""
         cfg, raw, out = self.config, self.store.numpy(), {}
@@ -522,12 +547,25 @@ class ForwardTransformerTrainer:
         td = torch.from_numpy(tdn.astype(np.float32)).to(dev)
         return tokens, mel, td, B, N, Tm
 
-    def train_step(self, input_sequence, target_sequence, target_durations):
-        """models.py:389-404: forward (training=True), 3 * MAE(mel) + MAE(duration), gradients, Adam update."""
+    def train_step(self, input_sequence, target_sequence, target_durations, global_lengths=None):
+        """models.py:389-404: forward (training=True), 3 * MAE(mel) + MAE(duration), gradients, Adam update.
+
+        global_lengths = (T, N) (data-parallel runs): the padded mel and token lengths of the GLOBAL batch, i.e. the largest
+        over all ranks.  The reference's losses divide by the padded element count (Keras SUM_OVER_BATCH_SIZE over a padded
+        batch), so a rank that pads its shard to a shorter length weighs its utterances more; with global_lengths every rank
+        divides by the global batch's count instead and the N-rank step equals the one-GPU step on the concatenated batch
+        whatever the ranks pad to.  The returned losses are scaled the same way (their mean over ranks is the global loss)."""
         tokens, mel_t, td, B, N, Tm = self._prepare_batch(input_sequence, target_sequence, target_durations)
+        mel_w, dur_w = self.loss_weights
+        if global_lengths is not None:
+            Tg, Ng = global_lengths
+            if Tg < Tm or Ng < N:
+                raise ValueError(f'global_lengths {(Tg, Ng)} are shorter than this rank\'s batch {(Tm, N)}')
+            mel_w, dur_w = mel_w * Tm / Tg, dur_w * N / Ng
         self._infer = None
         self._site = 0
-        self._seed_now = (self.seed * 1000003 + self.iterations * 7919 + 12345) & 0xFFFFFFFF
+        # (the rank enters the seed: replicas draw different dropout masks and head drops for their shards)
+        self._seed_now = (self.seed * 1000003 + self.iterations * 7919 + 12345 + self.rank * 0x9E3779B1) & 0xFFFFFFFF
         self._host_rng = np.random.default_rng(self._seed_now)
         st, de, dd, mc = self.store, self.de, self.dd, self.mel_channels
         Me, Md = B * N, B * Tm
@@ -617,9 +655,9 @@ class ForwardTransformerTrainer:
 
         # ---- backward
         dmel = self._empty(Md, mc)
-        T.masked_mae_bwd(mel_t2, mel, dmel, self.loss_weights[0])
+        T.masked_mae_bwd(mel_t2, mel, dmel, mel_w)
         ddur = self._empty(Me)
-        T.masked_mae_bwd(td.view(Me, 1), dur.view(Me, 1), ddur.view(Me, 1), self.loss_weights[1])
+        T.masked_mae_bwd(td.view(Me, 1), dur.view(Me, 1), ddur.view(Me, 1), dur_w)
         # the gradient buffer is in forward order: every finished stage hands its tail to the all-reduce, which runs on
         # the communication stream beside the rest of the backward pass
         overlap = parallel.GradientOverlap(self.store.grad, self.bucket_elems, self.pg, self._comm)
@@ -653,6 +691,8 @@ class ForwardTransformerTrainer:
                 overlap.ready(self._first_offset(f'encoder.block{(idx - 1) // 2}.'))
         overlap.finish()
         self._apply_gradients()
+        if global_lengths is not None:
+            losses = losses * torch.tensor([Tm / global_lengths[0], N / global_lengths[1]], dtype=torch.float32, device=self.device)
         loss = losses[0] * self.loss_weights[0] + losses[1] * self.loss_weights[1]
         return {'mel': mel.view(B, Tm, mc), 'duration': dur.view(B, N, 1), 'expanded_mask': frame_mask.view(B, 1, 1, Tm),
                 'encoder_attention': enc_attn, 'decoder_attention': dec_attn, 'loss': loss,

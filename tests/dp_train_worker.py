@@ -33,17 +33,24 @@ def main():
     solo = [dist.new_group([r]) for r in range(world)][rank]
     cfg = small_cfg(0.0)
     w = weights.init_forward_transformer(cfg, seed=7)
-    data = [batch(cfg, 3, 19, seed=10 + rank), batch(cfg, 2, 23, seed=20 + rank)]
+    # ragged ranks: the ranks' batches pad to different token and frame counts; every rank divides its losses by the global
+    # batch's padded size (global_lengths), as scripts/train_forward.py does
+    data = [batch(cfg, 3, 19 + 4 * rank, seed=10 + rank), batch(cfg, 2, 23 - 3 * rank, seed=20 + rank)]
+    shapes = [torch.tensor([[d[1].shape[1], d[0].shape[1]] for d in data])]
+    all_shapes = gathered(shapes[0])
+    glob = [tuple(int(v) for v in torch.stack(all_shapes)[:, i].max(dim=0).values) for i in range(2)]   # (T, N) per step
+    assert len({int(t[0, 0]) for t in all_shapes}) == world        # the ranks really pad differently
 
     alone = ForwardTransformerTrainer(w, cfg, process_group=solo)
     assert alone.world == 1
-    alone.train_step(*data[0])
+    alone.rank = rank                                  # the same dropout stream as the data-parallel replica (rate 0 here)
+    alone.train_step(*data[0], global_lengths=glob[0])
     expected = sum(gathered(alone.store.grad.cpu()))
 
     model = ForwardTransformerTrainer(w, cfg, bucket_mb=0.5)
-    assert model.world == world
+    assert model.world == world and model.rank == rank
     assert model.store.flat.numel() > 2 * model.bucket_elems
-    model.train_step(*data[0])
+    model.train_step(*data[0], global_lengths=glob[0])
     got = model.store.grad.cpu()
     # two runs of one step differ a little (float atomics order the column sums differently, and a ReLU gate next to
     # its kink may then fall the other way), so the comparison is over the whole vector; a missing rank gives ~0.7
@@ -52,10 +59,16 @@ def main():
     assert err <= 5e-3 * scale, (err, scale)
     different = float((got - alone.store.grad.cpu()).norm())
     assert different > 0.1 * scale, different          # the ranks really had different gradients
-    model.train_step(*data[1])
+    model.train_step(*data[1], global_lengths=glob[1])
     flats = gathered(model.store.flat.cpu())
     assert all(torch.equal(flats[0], f) for f in flats[1:])
     assert not torch.equal(flats[0], torch.from_numpy(np.asarray(alone.store.flat.cpu())))
+    # per-replica BatchNorm statistics differ until a checkpoint broadcasts rank 0's
+    states = gathered(model.store.state.cpu())
+    assert not torch.equal(states[0], states[1])
+    model.broadcast_moving_statistics(src=0)
+    states = gathered(model.store.state.cpu())
+    assert all(torch.equal(states[0], t) for t in states[1:])
     print(f'rank {rank}: data-parallel step OK (gradient error {err:.2e} of {scale:.2e})', flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -255,3 +255,66 @@ def test_val_step_and_inference_honour_decoder_prenet_dropout():
     model.set_constants(decoder_prenet_dropout=0.0)
     out0 = model.val_step(tokens, mel, durs)
     assert np.abs(out0['mel'].cpu().numpy() - plain['mel']).max() < 5e-4
+
+
+def test_global_lengths_rescale_losses_and_gradients():
+    """train_step(global_lengths=(T, N)): the losses and their gradients are divided by the global batch's padded element
+    count instead of this batch's.  The forward pass does not change, so the loss values, the gradient of the last
+    BatchNorm's beta (a plain sum of d loss / d mel) and of the duration head's bias scale exactly by T_own / T and N_own / N."""
+    from estts.forward_training import ForwardTransformerTrainer
+    cfg = small_cfg(0.0)
+    w = weights.init_forward_transformer(cfg, seed=17)
+    tokens, mel, durs = batch(cfg, 3, 18, seed=5)
+    Tm, N = mel.shape[1], tokens.shape[1]
+    a, b = ForwardTransformerTrainer(w, cfg), ForwardTransformerTrainer(w, cfg)
+    oa = a.train_step(tokens, mel, durs)
+    ob = b.train_step(tokens, mel, durs, global_lengths=(Tm + 9, N + 5))
+    fm, fd = Tm / (Tm + 9), N / (N + 5)
+    assert abs(float(ob['losses']['mel']) - fm * float(oa['losses']['mel'])) < 1e-6
+    assert abs(float(ob['losses']['duration']) - fd * float(oa['losses']['duration'])) < 1e-6
+    ga, gb = grads_by_name(a), grads_by_name(b)
+    last_beta = f"decoder_postnet.norm{cfg['postnet_conv_layers']}.beta"
+    assert np.abs(ga[last_beta]).max() > 1e-4
+    assert np.abs(gb[last_beta] - fm * ga[last_beta]).max() < 1e-6 * max(1.0, np.abs(ga[last_beta]).max())
+    assert np.abs(gb['dur_pred.linear.bias'] - fd * ga['dur_pred.linear.bias']).max() < 1e-6
+    with pytest.raises(ValueError):
+        b.train_step(tokens, mel, durs, global_lengths=(Tm - 1, N))
+
+
+def test_checkpoint_resume_equals_uninterrupted_training(tmp_path):
+    """N steps + checkpoint (variables, BatchNorm statistics, Adam moments, step count, seed) + restore + N steps against 2 N
+    uninterrupted steps.  Not bit-identical (float atomics order the column sums differently from run to run), so the
+    weights are compared against how far one step moves them: Adam moves every weight by ~lr per step whatever its gradient's
+    size, so two runs of the same four steps already differ by a few percent of lr on average (entries whose tiny gradients
+    change sign between runs); resuming with zeroed moments is off by most of lr."""
+    from estts.config_manager import ConfigManager
+    from estts.forward_training import ForwardTransformerTrainer
+    cfg = small_cfg(0.1)
+    w = weights.init_forward_transformer(cfg, seed=19)
+    data = [batch(cfg, 2, 15, seed=30 + i) for i in range(4)]
+    lr = 1e-3
+
+    def run(model, items):
+        model.set_constants(learning_rate=lr, decoder_prenet_dropout=0.0, drop_n_heads=0)
+        for d in items:
+            model.train_step(*d)
+        return model
+
+    straight = run(ForwardTransformerTrainer(w, cfg, seed=6), data)
+    first = run(ForwardTransformerTrainer(w, cfg, seed=6), data[:2])
+    path = str(tmp_path / 'ckpt-2.npz')
+    ConfigManager.save_weights(path, first.weights(), first.step, first.optimizer_state())
+    w2, step, opt = ConfigManager.read_weights(path, with_optimizer=True)
+    assert step == 2 and set(w2) == set(w)
+    resumed = ForwardTransformerTrainer(w2, cfg, seed=999)
+    resumed.load_optimizer_state(opt)
+    assert resumed.step == 2 and resumed.seed == 6
+    run(resumed, data[2:])
+    cold = ForwardTransformerTrainer(w2, cfg, seed=6)           # what the old checkpoints gave: moments lost
+    cold.iterations = 2
+    run(cold, data[2:])
+    ref = straight.store.flat.cpu().numpy()
+    err = np.abs(resumed.store.flat.cpu().numpy() - ref)
+    err_cold = np.abs(cold.store.flat.cpu().numpy() - ref)
+    print(f'resume: mean |dw| {err.mean():.2e} (with the moments) vs {err_cold.mean():.2e} (without), lr {lr}')
+    assert err.mean() < 0.1 * lr and err_cold.mean() > 10 * err.mean()
