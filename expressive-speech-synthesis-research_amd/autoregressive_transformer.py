@@ -111,10 +111,22 @@ class ReferenceEncoderGST:
 
 
 class AutoregressiveTransformer:
-    def __init__(self, weights, config, device='cuda', precision='bf16x3', fold_ffn=True):
+    def __init__(self, weights=None, config=None, device='cuda', precision='bf16x3', fold_ffn=True, seed=1234, **keywords):
+        """weights: dict name -> ndarray (weights.py layouts), config: dict with the keys of config/*/autoregressive_config.yaml
+        (what ConfigManager.get_model passes); or the reference's own keyword form
+        (AutoregressiveTransformer(system_type=..., mel_channels=..., encoder_model_dimension=..., ..., max_r=...),
+        utils/config_manager.py:119-162), in which case the variables are initialised from `seed` as Keras would from its
+        initialisers."""
         if not torch.cuda.is_available():
             raise RuntimeError('AutoregressiveTransformer needs a GPU: the hot path has no CPU implementation')
         ops._lib.load()
+        if config is None:
+            from . import configs, weights as _weights
+            config = configs.config_from_keywords('autoregressive', **keywords)
+            if weights is None:
+                weights = _weights.init_autoregressive_transformer(config, seed=seed)
+        elif keywords:
+            raise TypeError(f'unexpected keywords beside a config dict: {sorted(keywords)}')
         cfg = self.config = dict(config)
         self.device = torch.device(device)
         self.precision = precision

@@ -95,6 +95,7 @@ class ConfigManager:
         if self.model_kind == 'autoregressive':
             cfg.setdefault('vocab_size', n_sym + 3)          # pad + start / end tokens (tokenizer.py:4-27)
             cfg['max_r'] = self.max_r
+            cfg.setdefault('speaker_embed_dim', 256)       # the reference's speaker embeddings are 256-d (synthesize_sentences_speaker.py:65)
         else:
             cfg.setdefault('vocab_size', n_sym + 1)
         return cfg

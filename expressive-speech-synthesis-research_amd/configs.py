@@ -132,3 +132,19 @@ def wavernn_hparams_22k(**overrides):
                         voc_seq_len=256 * 5)
     c.update(overrides)
     return c
+
+
+def config_from_keywords(kind, **kw):
+    """The reference constructs its models from keywords (utils/config_manager.py:119-162 for AutoregressiveTransformer,
+    pretrained_models/for_text_encoder/models.py:284-309 for ForwardTransformer): the same keywords -> this package's config
+    dict.  Keys the hot path does not use (phoneme_language, with_stress, debug) are accepted and kept."""
+    base = autoregressive_config() if kind == 'autoregressive' else forward_config()
+    rename = {'encoder_maximum_position_encoding': 'encoder_max_position_encoding',
+              'decoder_maximum_position_encoding': 'decoder_max_position_encoding'}
+    for k, v in kw.items():
+        if v is not None:
+            base[rename.get(k, k)] = v
+    if 'decoder_prenet_dimension' not in kw and kind == 'forward':
+        # ForwardTransformer's prenet is DecoderPrenet(model_dim=decoder_model_dimension, dense_hidden_units=decoder_feed_forward_dimension)
+        base['decoder_prenet_dimension'] = base['decoder_model_dimension']
+    return base

@@ -269,6 +269,10 @@ class ForwardTransformerTrainer:
             self._linears += blk[0].linears() + blk[1].linears()
         self._linears += self.dur.linears() + [self.prenet1.lin, self.prenet2.lin, self.out.lin] + self.postnet.linears()
         self._infer = None
+        # tests: set to a list and train_step appends, in forward order, the branch every ReLU took ([rows, channels] bool
+        # tensors) and then the signs (pred - target) of the two MAE losses, so that an oracle can differentiate the same
+        # piecewise-linear function the device did
+        self.gate_log = None
         self._comm = torch.cuda.Stream(device=dev) if self.world > 1 else None
 
     # ------------------------------------------------------------------ construction helpers
@@ -375,6 +379,10 @@ class ForwardTransformerTrainer:
         drop = (self.dropout_rate, self._seed_now, self._next_site())
         fa = ops.rownorm_args(h2, out, ln_a=Fb.ln.pair, act='relu', residual=x, ln_b=Fb.last_ln.pair, dropout=drop)
         ops.check(ops._lib.load().estts_rownorm(fa, ops._stream()), 'estts_rownorm')
+        if self.gate_log is not None:      # the same kernel up to the ReLU: the same arithmetic, hence the same branches
+            r = self._empty(M, Fb.d2.N)
+            ops.rownorm(h2, r, ln_a=Fb.ln.pair, act='relu')
+            self.gate_log.append(r > 0)
 
         def backward(dout):
             dh2, dx = self._empty(M, Fb.d2.N), self._empty(M, x.shape[1])
@@ -404,6 +412,12 @@ class ForwardTransformerTrainer:
             st = self._bn_train(z, norm, M, conv.N)
             nxt = self._empty(M, conv.N)
             T.affine_act(z, nxt, st[2], st[3], act, residual=x if i == n - 1 else None, M=M, C=conv.N)
+            if self.gate_log is not None and act == 'relu':
+                r = nxt
+                if i == n - 1:                      # the residual is already added: the activation alone, same kernel
+                    r = self._empty(M, conv.N)
+                    T.affine_act(z, r, st[2], st[3], act, M=M, C=conv.N)
+                self.gate_log.append(r > 0)
             saved.append((h, z, st))
             h = nxt
         s = h                                           # inputs + last activation
@@ -595,12 +609,18 @@ class ForwardTransformerTrainer:
         a0 = self._empty(Me, de)
         fa0 = ops.rownorm_args(z0, a0, ln_a=D.norms[0].pair, act='relu')
         ops.check(ops._lib.load().estts_rownorm(fa0, ops._stream()), 'estts_rownorm')
+        if self.gate_log is not None:
+            self.gate_log.append(a0 > 0)
         z1 = self._empty(Me, de)
         self._lin_fwd(a0, D.convs[1], z1, Me, N)
         dur = self._empty(Me)
         fa1 = ops.rownorm_args(z1, None, ln_a=D.norms[1].pair, act='relu', residual=enc_out, ln_b=D.norms[2].pair,
                                dot_w=self.dur_w, dot_b=self.dur_b, dot_scale=1.0, dot_mask=key_mask.view(-1), dot_out=dur)
         ops.check(ops._lib.load().estts_rownorm(fa1, ops._stream()), 'estts_rownorm')
+        if self.gate_log is not None:
+            r = self._empty(Me, de)
+            ops.rownorm(z1, r, ln_a=D.norms[1].pair, act='relu')
+            self.gate_log += [r > 0, (dur > 0).view(Me, 1)]
 
         # ---- length regulator, decoder prenet
         cum = torch.empty(B, N, dtype=torch.int32, device=self.device)
@@ -618,6 +638,8 @@ class ForwardTransformerTrainer:
         self._lin_fwd(mels_in, self.prenet1, p1, Md, dropout=(rp, self._seed_now, 1000, 0))
         p2 = self._empty(Md, dd)
         self._lin_fwd(p1, self.prenet2, p2, Md, dropout=(rp, self._seed_now, 1001, 0))
+        if self.gate_log is not None:
+            self.gate_log += [p1 > 0, p2 > 0]
         dcat0 = self._empty(Md, 2 * dd)
         y0 = dcat0[:, :dd]
         T.affine_act(p2, y0, self.dec_scale, self.dec_shift, None, residual=self.pe_dec, r_mod=Tm, M=Md, C=dd)
@@ -652,6 +674,8 @@ class ForwardTransformerTrainer:
         mel_t2 = mel_t.view(Md, mc)
         ops.masked_mae(mel_t2, mel, losses[0:1])
         ops.masked_mae(td.view(Me, 1), dur.view(Me, 1), losses[1:2])
+        if self.gate_log is not None:
+            self.gate_log += [torch.sign(mel - mel_t2), torch.sign(dur.view(Me, 1) - td.view(Me, 1))]
 
         # ---- backward
         dmel = self._empty(Md, mc)

@@ -16,12 +16,21 @@ from .text import Tokenizer, default_alphabet
 
 
 class ForwardTransformer:
-    def __init__(self, weights, config, device='cuda', precision='bf16x3', fold_ffn=True):
+    def __init__(self, weights=None, config=None, device='cuda', precision='bf16x3', fold_ffn=True, seed=1234, **keywords):
         """weights: dict name -> ndarray in Keras layouts (see weights.py); config: dict with the keys of
-        config/*/forward_config.yaml."""
+        config/*/forward_config.yaml; or the reference's own keyword form (ForwardTransformer(encoder_model_dimension=...,
+        decoder_model_dimension=..., dropout_rate=..., ...), models.py:284-309), in which case the variables are initialised
+        from `seed` as Keras would from its initialisers."""
         if not torch.cuda.is_available():
             raise RuntimeError('ForwardTransformer needs a GPU: the hot path has no CPU implementation')
         ops._lib.load()
+        if config is None:
+            from . import configs, weights as _weights
+            config = configs.config_from_keywords('forward', **keywords)
+            if weights is None:
+                weights = _weights.init_forward_transformer(config, seed=seed)
+        elif keywords:
+            raise TypeError(f'unexpected keywords beside a config dict: {sorted(keywords)}')
         self.config = dict(config)
         self.device = torch.device(device)
         self.precision = precision

@@ -1,22 +1,29 @@
 """Synthesize: the vocoder wrapper of the reference (WaveRNN/synthesizer_wavernn.py:8-33) over the MI355X WaveRNN."""
-from . import configs
+import os
+
+import numpy as np
+import torch
+
+from . import configs, weights
 from .wavernn import WaveRNN
 
 
 class Synthesize:
-    def __init__(self, model_path, hp=None, **kw):
-        """model_path: a reference `.pyt` state_dict (created with fresh weights if missing, as WaveRNN.restore does);
+    def __init__(self, model_path, hp=None, seed=1, **kw):
+        """model_path: a reference `.pyt` state_dict; None = seeded random weights (exercises the pipeline, produces noise);
         hp: the hparams dict (defaults to the shipped WaveRNN/hparams.py values)."""
         self.hp = hp if hp is not None else configs.wavernn_hparams()
         print('\nInitialising WaveRNN Model...\n')
         self.voc_model = WaveRNN.from_hparams(self.hp, **kw)
-        import os
-        if os.path.exists(model_path):
+        if model_path is None:
+            print(f'WARNING: no vocoder weights given: random weights (seed {seed})')
+            self.voc_model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.init_wavernn(self.hp, seed=seed).items()})
+        elif os.path.exists(model_path):
             self.voc_model.restore(model_path)
         else:
             raise FileNotFoundError(f'{model_path}: no vocoder weights (the reference would start a new training session here)')
 
     def generate(self, mel, batch_pred=True):
-        """mel: [1, feat, T] in the reference's [0, 1] normalisation -> float64 waveform."""
+        """mel: [1, feat, T] in the reference's [0, 1] normalisation (host or device) -> float64 waveform."""
         hp = self.hp
         return self.voc_model.generate(mel, batch_pred, hp['voc_target'], hp['voc_overlap'], hp['mu_law'])

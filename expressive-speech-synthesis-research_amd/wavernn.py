@@ -622,6 +622,9 @@ class WaveRNN:
         L = target + 2 * overlap if batched else max(cond['frames']) * hop
         i32 = dict(dtype=torch.int32, device=self.device)
         seq_utt_d, seq_start_d = torch.tensor(seq_utt, **i32), torch.tensor(seq_start, **i32)
+        if min(cond['frames']) < 21:
+            # the reference fails here too, with numpy's broadcast error (fatchord_version.py:235-237)
+            raise ValueError(f'generate needs at least 21 mel frames per utterance (the fade-out covers 20 hops), got {min(cond["frames"])}')
         st = self._alloc_state(n_seq, L)
         f32 = dict(dtype=torch.float32, device=self.device)
         u = u_mix = None

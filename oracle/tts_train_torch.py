@@ -25,10 +25,22 @@ from .tts_torch import _act, _conv1d, _pe
 
 
 class _Ctx:
-    def __init__(self, masks, head_keep, new_stats):
+    def __init__(self, masks, head_keep, new_stats, gates=None):
         self.masks = list(masks) if masks is not None else None
         self.head_keep = list(head_keep) if head_keep is not None else None
         self.new_stats = new_stats
+        self.gates = list(gates) if gates is not None else None
+
+    def relu(self, x):
+        """ReLU, or -- when the branches another implementation took are given -- the linear piece x * gate it evaluated, so
+        that both differentiate the same piecewise-linear function even where an input sits within rounding of zero."""
+        if self.gates is None:
+            return torch.relu(x)
+        g = torch.as_tensor(np.asarray(self.gates.pop(0)), dtype=x.dtype).reshape(x.shape)
+        return x * g
+
+    def act(self, x, name):
+        return self.relu(x) if name == 'relu' else _act(x, name)
 
     def dropout(self, x):
         if self.masks is None:
@@ -60,9 +72,9 @@ def _cnn_res_norm(x, w, p, n_layers, inner, last, padding, kind, c):
     norm = (lambda t, q: _ln(t, w, q)) if kind == 'layer' else (lambda t, q: _bn_train(t, w, q, c))
     y = x
     for i in range(n_layers - 1):
-        y = _act(norm(_conv1d(y, w[f'{p}.conv{i}.kernel'], w[f'{p}.conv{i}.bias'], padding), f'{p}.norm{i}'), inner)
+        y = c.act(norm(_conv1d(y, w[f'{p}.conv{i}.kernel'], w[f'{p}.conv{i}.bias'], padding), f'{p}.norm{i}'), inner)
     y = _conv1d(y, w[p + '.last_conv.kernel'], w[p + '.last_conv.bias'], padding)
-    y = _act(norm(y, f'{p}.norm{n_layers - 1}'), last)
+    y = c.act(norm(y, f'{p}.norm{n_layers - 1}'), last)
     return norm(x + y, f'{p}.norm{n_layers}')
 
 
@@ -95,7 +107,7 @@ def _sa_blocks(x, mask, w, p, d, heads, dense_blocks, max_pos, c):
         if i < dense_blocks:
             y = F.linear(x, w[b + '.ffn.d1.kernel'].t(), w[b + '.ffn.d1.bias'])
             y = F.linear(y, w[b + '.ffn.d2.kernel'].t(), w[b + '.ffn.d2.bias'])
-            y = c.dropout(torch.relu(_ln(y, w, b + '.ffn.ln')))
+            y = c.dropout(c.relu(_ln(y, w, b + '.ffn.ln')))
             x = _ln(y + x, w, b + '.ffn.last_ln')
         else:
             x = _cnn_res_norm(x, w, b + '.conv', 2, 'relu', 'relu', 'same', 'batch', c)
@@ -103,23 +115,33 @@ def _sa_blocks(x, mask, w, p, d, heads, dense_blocks, max_pos, c):
     return x, attn
 
 
-def masked_mae(targets, pred):
-    """utils/losses.py:41-47: MeanAbsoluteError with sample_weight = any(target != 0), SUM_OVER_BATCH_SIZE."""
+def masked_mae(targets, pred, sign=None):
+    """utils/losses.py:41-47: MeanAbsoluteError with sample_weight = any(target != 0), SUM_OVER_BATCH_SIZE.
+    sign: optional sign(pred - targets) as another implementation evaluated it (see _Ctx.relu)."""
     wgt = (targets != 0).any(dim=-1).to(pred.dtype)
-    per = (targets - pred).abs().mean(dim=-1) * wgt
+    diff = (targets - pred).abs() if sign is None else (pred - targets) * torch.as_tensor(np.asarray(sign), dtype=pred.dtype).reshape(pred.shape)
+    per = diff.mean(dim=-1) * wgt
     return per.sum() / per.numel()
 
 
-def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=None, dtype=torch.float64, prenet_masks=None):
+def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=None, dtype=torch.float64, prenet_masks=None,
+                       gates=None):
     """One forward + backward.  Returns dict(loss, mel_loss, dur_loss, mel, duration, grads {name: ndarray},
-    new_stats {moving statistic name: ndarray}); weights are NOT updated (see adam_update)."""
+    new_stats {moving statistic name: ndarray}); weights are NOT updated (see adam_update).
+    gates: optional list, in forward order, of the branch taken at every ReLU (arrays of 0 / 1, one per ReLU: encoder blocks,
+    duration predictor incl. its final Dense(1, relu), decoder prenet, decoder blocks) followed by the two MAE sign arrays
+    (mel, duration): the piecewise-linear pieces a device evaluated, which this oracle then differentiates instead of its own
+    (its own differ wherever an input is within the device's rounding error of a kink)."""
     dt = dtype
     wt = {}
     for k, v in w.items():
         t = torch.as_tensor(np.asarray(v)).to(dt)
         trainable = not (k.endswith('moving_mean') or k.endswith('moving_variance') or k.endswith('pos_encoding_scalar'))
         wt[k] = t.clone().requires_grad_(trainable)
-    c = _Ctx(masks, head_keep, {})
+    signs = None
+    if gates is not None:
+        gates, signs = list(gates[:-2]), gates[-2:]
+    c = _Ctx(masks, head_keep, {}, gates)
     tokens = torch.as_tensor(np.asarray(tokens)).long()
     B, N = tokens.shape
     pad = (tokens == 0).to(dt)
@@ -127,7 +149,7 @@ def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=Non
     x, enc_attn = _sa_blocks(x, pad[:, None, None, :], wt, 'encoder', cfg['encoder_model_dimension'], cfg['encoder_num_heads'],
                              cfg['encoder_dense_blocks'], cfg['encoder_max_position_encoding'], c)
     dp = _cnn_res_norm(x, wt, 'dur_pred.conv_blocks', 2, 'relu', 'relu', 'same', 'layer', c)
-    dur = torch.relu(F.linear(dp, wt['dur_pred.linear.kernel'].t(), wt['dur_pred.linear.bias']))
+    dur = c.relu(F.linear(dp, wt['dur_pred.linear.kernel'].t(), wt['dur_pred.linear.bias']))
     dur = (1.0 - pad)[:, :, None] * dur
     td = torch.as_tensor(np.asarray(durations)).to(dt).reshape(B, N, 1)
     reps = torch.round(td[..., 0]).long().clamp(min=0)
@@ -139,10 +161,10 @@ def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=Non
     mels = torch.stack(rows)
     emask = (mels.detach().abs().sum(-1) == 0).to(dt)[:, None, None, :]
     # DecoderPrenet (layers.py:394-402): dropout after each relu, always on; prenet_masks = two scaled keep masks or None
-    y = torch.relu(F.linear(mels, wt['decoder_prenet.d1.kernel'].t(), wt['decoder_prenet.d1.bias']))
+    y = c.relu(F.linear(mels, wt['decoder_prenet.d1.kernel'].t(), wt['decoder_prenet.d1.bias']))
     if prenet_masks is not None:
         y = y * torch.as_tensor(np.asarray(prenet_masks[0]), dtype=dt).reshape(y.shape)
-    y = torch.relu(F.linear(y, wt['decoder_prenet.d2.kernel'].t(), wt['decoder_prenet.d2.bias']))
+    y = c.relu(F.linear(y, wt['decoder_prenet.d2.kernel'].t(), wt['decoder_prenet.d2.bias']))
     if prenet_masks is not None:
         y = y * torch.as_tensor(np.asarray(prenet_masks[1]), dtype=dt).reshape(y.shape)
     y, dec_attn = _sa_blocks(y, emask, wt, 'decoder', cfg['decoder_model_dimension'], cfg['decoder_num_heads'],
@@ -150,8 +172,10 @@ def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=Non
     y = F.linear(y, wt['out.kernel'].t(), wt['out.bias'])
     y = _cnn_res_norm(y, wt, 'decoder_postnet', cfg['postnet_conv_layers'], 'tanh', 'linear', 'same', 'batch', c)
     mel_t = torch.as_tensor(np.asarray(mel)).to(dt)
-    l_mel = masked_mae(mel_t, y[:, :mel_t.shape[1]])
-    l_dur = masked_mae(td, dur)
+    l_mel = masked_mae(mel_t, y[:, :mel_t.shape[1]], None if signs is None else signs[0])
+    l_dur = masked_mae(td, dur, None if signs is None else signs[1])
+    if c.gates:
+        raise ValueError(f'{len(c.gates)} gate arrays left over: the gate list does not match this model')
     loss = 3.0 * l_mel + 1.0 * l_dur
     loss.backward()
     grads = {k: (t.grad.numpy() if t.grad is not None else np.zeros(t.shape)) for k, t in wt.items() if t.requires_grad}

@@ -74,9 +74,9 @@ def main():
     print(f'Extracting attention from layer {last}')
     samples = stored_samples(args.data) if args.data else synthetic_samples(args.synthetic or 8, cfg)
     os.makedirs(args.out, exist_ok=True)
-    spk_dim = cm.config.get('speaker_embed_dim')
+    spk_dim = cfg['speaker_embed_dim']
     all_durations, count = [], 0
-    for group in batches(samples, 5 * cm.config['batch_size']):               # extract_durations.py:99
+    for group in batches(samples, 5 * cm.config.get('batch_size', cm.config.get('tts_batch_size', 8))):   # extract_durations.py:99; the shipped yaml names it tts_batch_size
         B, N, T = len(group), max(len(p) for _, _, p in group), max(len(m) for _, m, _ in group)
         mel = np.zeros((B, T, cfg['mel_channels']), np.float32)
         phon = np.zeros((B, N), np.int32)

@@ -4,7 +4,11 @@ synthesize_sentences_speaker.py (model.predict, the (mel.T + 4) / 8 hand-off, Sy
 between the two models.
 
   python scripts/synthesize_sentences.py --config /path/to/config/wavernn --model forward --text "h@loU w3:ld" \
-      [--tts-weights ckpt-5.npz] [--vocoder-weights latest_weights.pyt] [--ref-mel ref.npy | --ref-wav ref.wav] --out out.npy
+      [--tts-weights ckpt-5.npz] [--vocoder-weights latest_weights.pyt] [--ref-mel ref.npy | --ref-wav ref.wav]
+      [--spk-embed speaker.npy] [--system-type style_text] --out out.npy
+
+The autoregressive model takes what its system_type asks for, as in the reference (synthesize_sentences_speaker.py:60-67): a
+reference mel or wav for the style encoder ('style' systems) and a 256-d speaker embedding ('speaker' systems).
 
 Text must already be phonemes (the phonemizer is an external program).  Without weight files both models run on seeded
 random weights, which exercises the pipeline but produces noise.
@@ -21,7 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import estts  # noqa: E402,F401
 from estts import configs, weights  # noqa: E402
 from estts.config_manager import ConfigManager  # noqa: E402
-from estts.wavernn import WaveRNN  # noqa: E402
+from estts.synthesizer_wavernn import Synthesize  # noqa: E402
 
 
 def main():
@@ -34,9 +38,16 @@ def main():
     ap.add_argument('--ref-mel', help='.npy reference mel (T, 80) for the style encoder (autoregressive model)')
     ap.add_argument('--ref-wav', help='16-bit PCM mono .wav reference at the data config\'s sampling rate: its mel is computed on the GPU '
                                       '(estts.audio.Audio, the reference\'s Audio.mel_spectrogram)')
+    ap.add_argument('--spk-embed', help='.npy speaker embedding (speaker_embed_dim values) for the speaker systems of the '
+                                        'autoregressive model (synthesize_sentences_speaker.py:65-67)')
+    ap.add_argument('--system-type', choices=['text', 'style_text', 'speaker_text', 'speaker_style_text'],
+                    help='override the yaml config\'s system_type (autoregressive model)')
+    ap.add_argument('--max-length', type=int, default=1000, help='most mel frames the autoregressive model may decode (predict\'s max_length)')
     ap.add_argument('--out', default='out.npy')
     args = ap.parse_args()
     cm = ConfigManager(args.config, args.model)
+    if args.system_type:
+        cm.config['system_type'] = args.system_type
     model = cm.load_model(args.tts_weights, verbose=True)
     t0 = time.perf_counter()
     if args.model == 'forward':
@@ -51,16 +62,23 @@ def main():
                     raise SystemExit(f'--ref-wav must be 16-bit mono at {cm.config["sampling_rate"]} Hz')
                 pcm = np.frombuffer(f.readframes(f.getnframes()), dtype='<i2').astype(np.float32) / 32768.0
             ref = Audio(cm.config).mel_spectrogram(pcm).t().contiguous()           # (T, 80), stays on the device
-        out = model.predict(args.text, ref, None, verbose=False)
+        system = cm.config['system_type']
+        if 'style' in system and ref is None:
+            raise SystemExit(f"system_type '{system}' needs --ref-mel or --ref-wav")
+        spk = None
+        if 'speaker' in system:
+            if not args.spk_embed:
+                raise SystemExit(f"system_type '{system}' needs --spk-embed")
+            spk = np.load(args.spk_embed).astype(np.float32).reshape(1, -1)
+            n_spk = cm.model_config_dict()['speaker_embed_dim']
+            if spk.shape[1] != n_spk:
+                raise SystemExit(f'--spk-embed has {spk.shape[1]} values, the model expects {n_spk}')
+        out = model.predict(args.text, ref if 'style' in system else None, spk, max_length=args.max_length, verbose=False)
     mel = out['mel']
     hp = configs.wavernn_hparams()
-    voc = WaveRNN.from_hparams(hp)
-    if args.vocoder_weights:
-        voc.load(args.vocoder_weights)
-    else:
-        voc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in weights.init_wavernn(hp, seed=1).items()})
+    vocoder = Synthesize(args.vocoder_weights, hp)             # synthesize_sentences_speaker.py:49
     mel_voc = ((mel.t() + 4.) / 8.)[None]                      # synthesize_sentences_speaker.py:69-70, stays on the device
-    wav = voc.generate(mel_voc, True, hp['voc_target'], hp['voc_overlap'], hp['mu_law'])
+    wav = vocoder.generate(mel_voc)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     np.save(args.out, wav)

@@ -54,3 +54,22 @@ def test_schedules_match_the_oracle_restatement():
     for step in (0, 1, 39_999, 40_000, 70_000, 100_000, 250_000):
         assert scheduling.piecewise_linear_schedule(step, sched) == np.float32(O.piecewise_linear_schedule(step, sched))
         assert scheduling.reduction_schedule(step, red) == O.reduction_schedule(step, red)
+
+
+def test_shipped_autoregressive_config_has_the_reference_schedules():
+    """config/wavernn/autoregressive_config.yaml carries the reference's schedule values
+    (TransformerTTS/config/wavernn/autoregressive_config.yaml:51-64: decoder-prenet dropout 0 until 25 000 then to 0.5 at
+    35 000; one head dropped from 15 000; reduction factor 10 until 80 000 then 1; system_type speaker_text), so that a
+    reference checkpoint restored at step s decodes with the reference's constants for s."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cm = ConfigManager(os.path.join(root, 'config', 'wavernn'), 'autoregressive')
+    c = cm.config
+    assert c['system_type'] == 'speaker_text' and c['use_mine'] is False and cm.max_r == 10
+    for step, r, drop, heads in ((0, 10, 0.0, 0), (20_000, 10, 0.0, 1), (30_000, 10, 0.25, 1), (79_999, 10, 0.5, 1),
+                                 (80_000, 1, 0.5, 1), (100_000, 1, 0.5, 1)):
+        assert scheduling.reduction_schedule(step, c['reduction_factor_schedule']) == r
+        assert abs(float(scheduling.piecewise_linear_schedule(step, c['decoder_prenet_dropout_schedule'])) - drop) < 1e-6
+        assert scheduling.reduction_schedule(step, c['head_drop_schedule']) == heads
+    f = ConfigManager(os.path.join(root, 'config', 'wavernn'), 'forward').config
+    assert f['batch_size'] == 16 and f['weights_save_frequency'] == 5000 and f['decoder_prenet_dropout_schedule'] == [[0, 0.0]]

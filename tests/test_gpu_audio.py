@@ -84,8 +84,20 @@ def test_reference_wav_to_style_conditioned_synthesis(tmp_path, monkeypatch):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     out = tmp_path / 'wav.npy'
+    np.save(tmp_path / 'spk.npy', np.random.default_rng(3).normal(size=256).astype(np.float32))
     monkeypatch.setattr(sys, 'argv', ['synthesize_sentences.py', '--config', os.path.join(root, 'config', 'wavernn'), '--model',
-                                      'autoregressive', '--text', 'D@ kwIk braUn fQks', '--ref-wav', str(path), '--out', str(out)])
+                                      'autoregressive', '--text', 'D@ kwIk braUn fQks', '--ref-wav', str(path), '--system-type', 'speaker_style_text',
+                                      '--spk-embed', str(tmp_path / 'spk.npy'), '--out', str(out)])
+    # seeded random weights may emit the stop token after a few frames, fewer than the vocoder's 20-frame fade-out needs:
+    # decode a fixed 40 frames instead
+    from estts.autoregressive_transformer import AutoregressiveTransformer
+    predict = AutoregressiveTransformer.predict
+
+    def predict_without_stop(self, *a, **kw):
+        self.stop_prob_index = 99
+        return predict(self, *a, **kw)
+    monkeypatch.setattr(AutoregressiveTransformer, 'predict', predict_without_stop)
+    sys.argv += ['--max-length', '40']
     mod.main()
     wav = np.load(out)
     assert wav.ndim == 1 and len(wav) > 1000 and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0 + 1e-6

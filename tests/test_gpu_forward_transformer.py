@@ -145,3 +145,39 @@ def test_end_to_end_synthesis_script(tmp_path, monkeypatch):
     mod.main()
     wav = np.load(out)
     assert wav.ndim == 1 and len(wav) > 1000 and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0 + 1e-6
+
+
+def test_reference_keyword_constructors():
+    """The reference builds its models from keywords (ConfigManager.get_model, utils/config_manager.py:119-162; ForwardTransformer,
+    models.py:284-309): the same call works here and equals the (weights, config) form on the same seed."""
+    from estts.autoregressive_transformer import AutoregressiveTransformer
+    cfg = small_cfg()
+    kw = dict(encoder_model_dimension=cfg['encoder_model_dimension'], decoder_model_dimension=cfg['decoder_model_dimension'],
+              dropout_rate=0.1, decoder_num_heads=cfg['decoder_num_heads'], encoder_num_heads=cfg['encoder_num_heads'],
+              encoder_maximum_position_encoding=cfg['encoder_max_position_encoding'],
+              decoder_maximum_position_encoding=cfg['decoder_max_position_encoding'],
+              postnet_conv_filters=cfg['postnet_conv_filters'], postnet_conv_layers=cfg['postnet_conv_layers'], postnet_kernel_size=5,
+              encoder_dense_blocks=cfg['encoder_dense_blocks'], decoder_dense_blocks=cfg['decoder_dense_blocks'], mel_channels=80,
+              phoneme_language='en', with_stress=False, encoder_attention_conv_filters=cfg['encoder_attention_conv_filters'],
+              decoder_attention_conv_filters=cfg['decoder_attention_conv_filters'], encoder_attention_conv_kernel=3,
+              decoder_attention_conv_kernel=3, encoder_feed_forward_dimension=cfg['encoder_feed_forward_dimension'],
+              decoder_feed_forward_dimension=cfg['decoder_feed_forward_dimension'], debug=False, vocab_size=cfg['vocab_size'])
+    a = ForwardTransformer(seed=5, **kw)
+    b = ForwardTransformer(weights.init_forward_transformer(a.config, seed=5), a.config)
+    tokens, durs = _inputs(cfg, 2, 11, seed=3)
+    assert torch.equal(a.call(tokens, target_durations=durs)['mel'], b.call(tokens, target_durations=durs)['mel'])
+    ar = AutoregressiveTransformer(system_type='text', mel_channels=80, encoder_model_dimension=64, decoder_model_dimension=64,
+                                   encoder_num_heads=[2, 2], decoder_num_heads=[2, 2], encoder_feed_forward_dimension=96,
+                                   decoder_feed_forward_dimension=96, encoder_maximum_position_encoding=64,
+                                   decoder_maximum_position_encoding=256, encoder_dense_blocks=1, decoder_dense_blocks=1,
+                                   decoder_prenet_dimension=48, encoder_prenet_dimension=64, encoder_attention_conv_kernel=3,
+                                   decoder_attention_conv_kernel=3, encoder_attention_conv_filters=80,
+                                   decoder_attention_conv_filters=80, postnet_conv_filters=32, postnet_conv_layers=3,
+                                   postnet_kernel_size=5, dropout_rate=0.1, ref_encoder_filters=[8, 8, 16], ref_encoder_kernel_size=3,
+                                   ref_encoder_strides=2, ref_encoder_gru_cell_units=32, gst_style_embed_dim=64, gst_multi_num_heads=2,
+                                   gst_heads=5, max_r=3, mel_start_value=4, mel_end_value=-4, phoneme_language='en',
+                                   with_stress=False, debug=False, vocab_size=30)
+    out = ar.call(np.array([[3, 4, 5, 0]], np.int32), np.zeros((1, 6, 80), np.float32) + 0.5, None)
+    assert tuple(out['final_output'].shape) == (1, 18, 80) and torch.isfinite(out['final_output']).all()
+    with pytest.raises(TypeError):
+        ForwardTransformer(None, cfg, bogus=1)

@@ -318,3 +318,62 @@ def test_checkpoint_resume_equals_uninterrupted_training(tmp_path):
     err_cold = np.abs(cold.store.flat.cpu().numpy() - ref)
     print(f'resume: mean |dw| {err.mean():.2e} (with the moments) vs {err_cold.mean():.2e} (without), lr {lr}')
     assert err.mean() < 0.1 * lr and err_cold.mean() > 10 * err.mean()
+
+
+def tight_compare(model, ref, tol=1e-3):
+    """Every gradient tensor within `tol` of its own largest entry (the oracle differentiated the device's own branches)."""
+    mine = grads_by_name(model)
+    errs = []
+    for k, r in ref['grads'].items():
+        a = mine[k].astype(np.float64)
+        r = np.asarray(r).reshape(a.shape)
+        scale = np.abs(r).max()
+        if scale < 1e-7:
+            assert np.abs(a).max() < 1e-5, k
+            continue
+        errs.append((float(np.abs(a - r).max() / scale), k))
+    errs.sort(reverse=True)
+    print(f'tight gradient check: worst {errs[:3]}, median {errs[len(errs) // 2][0]:.1e}')
+    assert errs[0][0] < tol, errs[:5]
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+def test_train_step_gradients_tight_on_the_device_branches(dropout):
+    """The oracle is given the branch the device took at every ReLU and the signs of its MAE terms (as it is given the
+    dropout masks), so both differentiate the same piecewise-linear function: every gradient tensor must then agree to 1e-3
+    of its largest entry (measured 1e-5..2e-4), which a wiring error upstream of any layer cannot pass."""
+    from estts import train_ops as T
+    from estts.forward_training import ForwardTransformerTrainer
+    cfg = small_cfg(dropout)
+    w = weights.init_forward_transformer(cfg, seed=27)
+    B, N = 3, 17
+    tokens, mel, durs = batch(cfg, B, N, seed=12)
+    Tm = mel.shape[1]
+    model = ForwardTransformerTrainer(w, cfg, seed=8)
+    masks = head_keep = None
+    if dropout > 0:
+        model.set_constants(drop_n_heads=1)
+        seed_now = (8 * 1000003 + 0 * 7919 + 12345) & 0xFFFFFFFF
+        # dropout sites in call order: positional encoding, then per block the attention output and (dense blocks) the FFN
+        shapes = [(B * N, 128)] * (1 + 2 * len(cfg['encoder_num_heads']) - (len(cfg['encoder_num_heads']) - cfg['encoder_dense_blocks'])) + \
+                 [(B * Tm, 64)] * (1 + 2 * len(cfg['decoder_num_heads']) - (len(cfg['decoder_num_heads']) - cfg['decoder_dense_blocks']))
+        masks = []
+        for site, sh in enumerate(shapes):
+            ones = torch.ones(*sh, device='cuda')
+            T.dropout(ones, ones, dropout, seed_now, site)
+            masks.append(ones.cpu().numpy().reshape(B, -1, sh[1]))
+        rng = np.random.default_rng(seed_now)
+        head_keep = []
+        for H in cfg['encoder_num_heads'] + cfg['decoder_num_heads']:
+            keep = np.ones((B, H))
+            for b in range(B):
+                keep[b, rng.permutation(H)[:1]] = 0.0
+            head_keep.append(keep * (H / (H - 1)))
+    model.gate_log = []
+    out = model.train_step(tokens, mel, durs)
+    gates = [g.float().cpu().numpy() for g in model.gate_log]
+    model.gate_log = None
+    ref = OT.forward_train_step(w, cfg, tokens, mel, durs, masks=masks, head_keep=head_keep, gates=gates)
+    assert abs(float(out['loss']) - ref['loss']) < 2e-5 * max(1.0, abs(ref['loss']))
+    assert np.abs(out['mel'].cpu().numpy() - ref['mel']).max() < 5e-4
+    tight_compare(model, ref)
