@@ -1,0 +1,473 @@
+"""Training of the AutoregressiveTransformer (GST TransformerTTS) on MI355X: the TTS half of the reference's
+`train_models_step` (TransformerTTS/model/traning_steps.py:16-56): teacher-forced forward in training mode, masked MAE on
+the post-net output + scaled stop-token cross entropy + masked MAE on the linear output, hand-written backward, Adam.
+
+Built from the layer passes of forward_training.ForwardTransformerTrainer (self-attention / FFN / conv-BN blocks with
+their backward closures, flat parameter store, Adam, re-packing) plus what the autoregressive model adds
+(model/AutoregressiveTransformer.py:124-181, model/layers.py:258-376): causal decoder self-attention, cross-attention over
+the concatenated encoder output [text | style | speaker], the reduction factor (FinalProj restricted to r frames per
+decoder step), the stop-token head and the causal post-net.
+
+The reference's three flags train_text_encoder / train_style_encoder / train_decoder select Keras' `training=` mode of the
+three sub-networks (dropout, head drop, BatchNorm batch statistics), not which variables receive gradients: the tape
+differentiates all trainable variables either way (traning_steps.py:54-55).  The shipped configuration sets all three
+True, and that is the mode implemented here; a False flag raises.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops, parallel, train_ops as T
+from .forward_training import (ForwardTransformerTrainer, ParamStore, _CnnResNorm, _Ffn, _Layer, _Norm, _Sarn)
+from .train_ops import TrainLinear
+from .weights import encoder_output_dim
+
+
+class _Carn:
+    """CrossAttentionResnorm (layers.py:258-274): wq over the decoder stream, wk | wv fused over the encoder output,
+    output projection over [q_in | ctx], LayerNorm(dropout(attn) + q_in)."""
+
+    def __init__(self, store, p, d, heads):
+        self.d, self.H = d, heads
+        self.wq = _Layer(store, p + '.mha.wq')
+        self.wkv = _Layer(store, p + '.mha.wkv')
+        self.wo = _Layer(store, p + '.mha.dense', need_bwd=False)
+        k = store.p[p + '.mha.dense.kernel']
+        self.wo_x = TrainLinear(k[:d], None, need_fwd=False)
+        self.wo_c = TrainLinear(k[d:], None, need_fwd=False)
+        self.ln = _Norm(store, p + '.layernorm', False)
+
+    def linears(self):
+        return [self.wq.lin, self.wkv.lin, self.wo.lin, self.wo_x, self.wo_c]
+
+
+def _register_autoregressive_params(store, w, cfg, shapes):
+    """Adds every AutoregressiveTransformer variable to the store in forward order (names of weights.py; wq / wk / wv of a
+    self-attention fused, wk / wv of a cross-attention fused, the stop head padded to 4 outputs).  `shapes` receives the
+    original shape of every variable whose stored layout differs."""
+    def add(name, a, trainable=True):
+        store.add(name, a, trainable)
+
+    def dense(p):
+        add(p + '.kernel', w[p + '.kernel'])
+        add(p + '.bias', w[p + '.bias'])
+
+    def conv(p):
+        k = np.asarray(w[p + '.kernel'])
+        shapes[p + '.kernel'] = k.shape
+        add(p + '.kernel', k.reshape(-1, k.shape[-1]))
+        add(p + '.bias', w[p + '.bias'])
+
+    def norm(p, batch):
+        add(p + '.gamma', w[p + '.gamma'])
+        add(p + '.beta', w[p + '.beta'])
+        if batch:
+            add(p + '.moving_mean', w[p + '.moving_mean'], False)
+            add(p + '.moving_variance', w[p + '.moving_variance'], False)
+
+    def sarn(p):
+        m = p + '.mha'
+        add(m + '.wqkv.kernel', np.concatenate([w[m + '.wq.kernel'], w[m + '.wk.kernel'], w[m + '.wv.kernel']], axis=1))
+        add(m + '.wqkv.bias', np.concatenate([w[m + '.wq.bias'], w[m + '.wk.bias'], w[m + '.wv.bias']]))
+        dense(m + '.dense')
+        norm(p + '.ln', False)
+        norm(p + '.last_ln', False)
+
+    def carn(p):
+        m = p + '.mha'
+        dense(m + '.wq')
+        add(m + '.wkv.kernel', np.concatenate([w[m + '.wk.kernel'], w[m + '.wv.kernel']], axis=1))
+        add(m + '.wkv.bias', np.concatenate([w[m + '.wk.bias'], w[m + '.wv.bias']]))
+        dense(m + '.dense')
+        norm(p + '.layernorm', False)
+
+    def cnn(p, n_layers):
+        for i in range(n_layers - 1):
+            conv(f'{p}.conv{i}')
+            norm(f'{p}.norm{i}', True)
+        conv(p + '.last_conv')
+        norm(f'{p}.norm{n_layers - 1}', True)
+        norm(f'{p}.norm{n_layers}', True)
+
+    def tail(b, dense_block):
+        if dense_block:
+            dense(b + '.ffn.d1')
+            dense(b + '.ffn.d2')
+            norm(b + '.ffn.ln', False)
+            norm(b + '.ffn.last_ln', False)
+        else:
+            cnn(b + '.conv', 2)
+
+    add('text_encoder_prenet.embeddings', w['text_encoder_prenet.embeddings'])
+    for i in range(len(cfg['encoder_num_heads'])):
+        b = f'text_encoder.block{i}'
+        sarn(b + '.sarn')
+        tail(b, i < cfg['encoder_dense_blocks'])
+    dense('decoder_prenet.d1')
+    dense('decoder_prenet.d2')
+    for i in range(len(cfg['decoder_num_heads'])):
+        b = f'decoder.block{i}'
+        sarn(b + '.sarn')
+        carn(b + '.carn')
+        tail(b, i < cfg['decoder_dense_blocks'])
+    dense('final_proj_mel')
+    ks = np.zeros((cfg['mel_channels'], 4), np.float32)
+    ks[:, :3] = np.asarray(w['decoder_postnet.stop_linear.kernel'])
+    bs = np.zeros(4, np.float32)
+    bs[:3] = np.asarray(w['decoder_postnet.stop_linear.bias'])
+    add('decoder_postnet.stop_linear.kernel', ks)     # a fourth, all-zero output: the data gradient needs N % 4 == 0
+    add('decoder_postnet.stop_linear.bias', bs)
+    cnn('decoder_postnet.conv_blocks', cfg['postnet_conv_layers'])
+
+
+class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
+    """The reference's AutoregressiveTransformer as `train_models_step` uses it: `input_reshape`, `train_step` (forward,
+    losses, gradients, optimizer), `set_constants`, `step`, `weights()`."""
+
+    def __init__(self, weights, config, device='cuda', precision='bf16x3', seed=0, process_group=None, bucket_mb=25):
+        self._init_common(config, device, precision, seed, process_group, bucket_mb)
+        cfg, dev = self.config, self.device
+        self.system_type = cfg['system_type']
+        if self.system_type in ('speaker_style_text', 'style_text'):
+            raise NotImplementedError("training the style systems runs through StyleTrainer (system types with a reference encoder)")
+        self.max_r = int(cfg['max_r'])
+        self.r = self.max_r
+        self.loss_weights = [1., 1., 1.]
+        self.stop_scaling = float(cfg.get('stop_loss_scaling', 1.0))
+        self._pos_scalars = {k: float(np.asarray(weights[k + '.pos_encoding_scalar'])) for k in ('text_encoder', 'decoder')}
+        self._orig_shapes = {}
+        st = self.store = ParamStore(dev)
+        _register_autoregressive_params(st, weights, cfg, self._orig_shapes)
+        st.build()
+        de, dd = cfg['encoder_model_dimension'], cfg['decoder_model_dimension']
+        self.de, self.dd = de, dd
+        self.enc_dim = encoder_output_dim(cfg)
+        self.emb, self.demb = st.p['text_encoder_prenet.embeddings'], st.g['text_encoder_prenet.embeddings']
+        if self.emb.shape[1] != de:
+            raise ValueError('encoder_prenet_dimension must equal encoder_model_dimension')
+        self.pe_enc = ops.positional_encoding_table(cfg['encoder_max_position_encoding'], de, dev) * self._pos_scalars['text_encoder']
+        self.pe_dec = ops.positional_encoding_table(cfg['decoder_max_position_encoding'], dd, dev) * self._pos_scalars['decoder']
+        self.enc_blocks = self._make_stack('text_encoder', de, cfg['encoder_num_heads'], cfg['encoder_dense_blocks'],
+                                           cfg['encoder_attention_conv_kernel'])
+        self.enc_names = self._attn_names('TextEncoder', cfg['encoder_num_heads'], cfg['encoder_dense_blocks'])
+        self.dec_blocks = []
+        k = cfg['decoder_attention_conv_kernel']
+        for i, h in enumerate(cfg['decoder_num_heads']):
+            b = f'decoder.block{i}'
+            tail = (_Ffn(st, b + '.ffn') if i < cfg['decoder_dense_blocks'] else
+                    _CnnResNorm(st, b + '.conv', 2, k, 'causal', 'relu', 'relu', True))
+            self.dec_blocks.append((_Sarn(st, b + '.sarn', dd, h), _Carn(st, b + '.carn', dd, h), tail))
+        nd = cfg['decoder_dense_blocks']
+        self.dec_names = [f'Decoder_DenseBlock{i + 1}_CrossAttention' if i < nd else f'Decoder_ConvBlock{i - nd + 1}_CrossAttention'
+                          for i in range(len(cfg['decoder_num_heads']))]
+        self.prenet1 = _Layer(st, 'decoder_prenet.d1', act='relu')
+        self.prenet2 = _Layer(st, 'decoder_prenet.d2', act='relu')
+        self.stop = _Layer(st, 'decoder_postnet.stop_linear')
+        self.postnet = _CnnResNorm(st, 'decoder_postnet.conv_blocks', cfg['postnet_conv_layers'], cfg['postnet_kernel_size'],
+                                   'causal', 'tanh', 'linear', True)
+        self.dec_scale = torch.full((dd,), math.sqrt(np.float32(dd)), device=dev)
+        self.dec_shift = torch.zeros(dd, device=dev)
+        self._final = {}
+        self._base_linears = []
+        for blk in self.enc_blocks:
+            self._base_linears += blk[0].linears() + blk[1].linears()
+        for S, C, tail in self.dec_blocks:
+            self._base_linears += S.linears() + C.linears() + tail.linears()
+        self._base_linears += [self.prenet1.lin, self.prenet2.lin, self.stop.lin] + self.postnet.linears()
+        self._linears = list(self._base_linears)
+
+    # ------------------------------------------------------------------ reference surface
+    def _compile(self, stop_scaling=None, optimizer=None):
+        """AutoregressiveTransformer.py:224-231."""
+        if stop_scaling is not None:
+            self.stop_scaling = float(stop_scaling)
+        super()._compile(optimizer)
+        self.loss_weights = [1., 1., 1.]
+
+    def set_constants(self, decoder_prenet_dropout=None, learning_rate=None, reduction_factor=None, drop_n_heads=None):
+        """AutoregressiveTransformer.py:298-307."""
+        super().set_constants(decoder_prenet_dropout, learning_rate, drop_n_heads)
+        if reduction_factor is not None:
+            r = int(reduction_factor)
+            if not 1 <= r <= self.max_r:
+                raise ValueError(f'reduction_factor must be in [1, {self.max_r}]')
+            self.r = r
+
+    def input_reshape(self, tar, stop_prob):
+        """AutoregressiveTransformer.py:318-327."""
+        tar_inp, tar_real = tar[:, :-1], tar[:, 1:]
+        return tar_real, tar_inp[:, 0::self.r, :], stop_prob[:, 1:], int(tar_inp.shape[1])
+
+    def _final_layer(self, r):
+        """FinalProj restricted to its first r * mel_channels outputs (AutoregressiveTransformer.py:173): a column view of
+        the full kernel, so the unused columns keep a zero gradient."""
+        L = self._final.get(r)
+        if L is None:
+            n = r * self.mel_channels
+            st = self.store
+
+            class _View:
+                pass
+            L = _View()
+            L.lin = TrainLinear(st.p['final_proj_mel.kernel'][:, :n], st.p['final_proj_mel.bias'][:n])
+            L.dk, L.db = st.g['final_proj_mel.kernel'][:, :n], st.g['final_proj_mel.bias'][:n]
+            L.taps, L.lpad, L.N, L.K = 1, 0, n, self.dd
+            self._final[r] = L
+            self._linears = self._base_linears + [v.lin for v in self._final.values()]
+            self._pack_plan = None
+        return L
+
+    def weights(self):
+        """Current variables as a dict name -> ndarray in the layouts of weights.py."""
+        raw, out = self.store.numpy(), {}
+        for k, v in raw.items():
+            if k.endswith('.mha.wqkv.kernel') or k.endswith('.mha.wkv.kernel'):
+                names = ('wq', 'wk', 'wv') if 'wqkv' in k else ('wk', 'wv')
+                d = v.shape[1] // len(names)
+                for j, n in enumerate(names):
+                    out[k.replace('wqkv' if 'wqkv' in k else 'wkv', n)] = v[:, j * d:(j + 1) * d].copy()
+            elif k.endswith('.mha.wqkv.bias') or k.endswith('.mha.wkv.bias'):
+                names = ('wq', 'wk', 'wv') if 'wqkv' in k else ('wk', 'wv')
+                d = v.shape[0] // len(names)
+                for j, n in enumerate(names):
+                    out[k.replace('wqkv' if 'wqkv' in k else 'wkv', n)] = v[j * d:(j + 1) * d].copy()
+            elif k == 'decoder_postnet.stop_linear.kernel':
+                out[k] = v[:, :3].copy()
+            elif k == 'decoder_postnet.stop_linear.bias':
+                out[k] = v[:3].copy()
+            elif k in self._orig_shapes:
+                out[k] = v.reshape(self._orig_shapes[k])
+            else:
+                out[k] = v
+        for k, s in self._pos_scalars.items():
+            out[k + '.pos_encoding_scalar'] = np.array(s, np.float32)
+        return out
+
+    # ------------------------------------------------------------------ layer passes
+    def _carn_fwd(self, Cx, cat, enc, d_enc, B, Lq, Lk, enc_mask, out, tape):
+        """cat [Mq, 2d]: left half holds q_in, the right half receives the attention context; enc [Mk, enc_dim]."""
+        Mq, Mk, d, H = B * Lq, B * Lk, Cx.d, Cx.H
+        q = self._empty(Mq, d)
+        self._lin_fwd(cat[:, :d], Cx.wq, q, Mq)
+        kv = self._empty(Mk, 2 * d)
+        self._lin_fwd(enc, Cx.wkv, kv, Mk)
+        attn = self._empty(B, H, Lq, Lk)
+        ctx = cat[:, d:]
+        ops.attention(q, kv[:, :d], kv[:, d:], ctx, B, H, Lq, Lk, d // H, key_mask=enc_mask, attn=attn, precision=self.precision)
+        hscale = hinv = None
+        if self.drop_n_heads > 0 and H > 1:
+            keep = np.ones((B, H), np.float32)
+            for b in range(B):
+                keep[b, self._host_rng.permutation(H)[:self.drop_n_heads]] = 0.0
+            sc = H / (H - self.drop_n_heads)
+            hscale = torch.from_numpy(keep * sc).to(self.device).view(-1)
+            hinv = torch.from_numpy(keep / sc).to(self.device).view(-1)
+            T.head_scale(ctx, hscale, B, Lq, H, d // H)
+        a = self._empty(Mq, d)
+        self._lin_fwd(cat, Cx.wo, a, Mq)
+        drop = (self.dropout_rate, self._seed_now, self._next_site())
+        fa = ops.rownorm_args(a, out, residual=cat[:, :d], ln_b=Cx.ln.pair, dropout=drop)
+        ops.check(ops._lib.load().estts_rownorm(fa, ops._stream()), 'estts_rownorm')
+
+        def backward(dout):
+            da, dx = self._empty(Mq, d), self._empty(Mq, d)
+            T.rownorm_bwd(fa, dout=dout, dy=da, dx=dx, dln_b=Cx.ln.dpair)
+            T.wgrad(cat, da, Cx.wo.dk, M=Mq, precision=self.precision)
+            T.colreduce(1, Cx.wo.db, g=da, M=Mq, C=d)
+            dctx = self._empty(Mq, d)
+            ops.gemm(da, Cx.wo_c.bwd, dctx, M=Mq, precision=self.precision)
+            ops.gemm(da, Cx.wo_x.bwd, dx, M=Mq, precision=self.precision, residual=dx)
+            delta = self._empty(B * H * Lq)
+            dq, dkv = self._empty(Mq, d), self._empty(Mk, 2 * d)
+            ctx_b = ctx
+            if hscale is not None:          # see _attention_bwd_headdrop
+                ctx_b = ctx.clone()
+                T.head_scale(ctx_b, hinv, B, Lq, H, d // H)
+                T.head_scale(dctx, hscale, B, Lq, H, d // H)
+            T.attention_bwd(q, kv[:, :d], kv[:, d:], ctx_b, dctx, attn, delta, dq, dkv[:, :d], dkv[:, d:], B, H, Lq, Lk, d // H,
+                            precision=self.precision)
+            self._lin_bwd(cat[:, :d], Cx.wq, dq, Mq, dx=dx, accumulate=True)
+            self._lin_bwd(enc, Cx.wkv, dkv, Mk, dx=d_enc, accumulate=True)
+            return dx
+
+        tape.append(backward)
+        return attn
+
+    # ------------------------------------------------------------------ the training step
+    def _encode(self, tokens, B, N, tape, enc_attn):
+        """Text encoder in training mode -> (text_out [Me, de] view, key_mask)."""
+        de, Me = self.de, B * N
+        key_mask = self._empty(B, N)
+        cat0 = self._empty(Me, 2 * de)
+        x0 = cat0[:, :de]
+        ops.embed_posenc(tokens, self.emb, self.pe_enc, None, x0, key_mask, math.sqrt(np.float32(de)))
+        site0 = self._next_site()
+        T.dropout(x0, x0, self.dropout_rate, self._seed_now, site0, M=Me, D=de)
+
+        def embed_backward(dx):
+            T.dropout(dx, dx, self.dropout_rate, self._seed_now, site0, M=Me, D=de)
+            T.embed_bwd(tokens, dx, self.demb, math.sqrt(np.float32(de)))
+            return None
+
+        tape.append(embed_backward)
+        return self._stack_fwd(self.enc_blocks, cat0, B, N, key_mask, de, tape, enc_attn, self.enc_names), key_mask
+
+    def train_step(self, tts_mel, tts_phonemes, tts_stop, tts_speaker=None, train_text_encoder=True, train_style_encoder=True,
+                   train_decoder=True, apply=True):
+        """The TTS half of train_models_step (traning_steps.py:22-56) without the style loss.
+        tts_mel [B, T + 1, C] (start / end vectors included), tts_phonemes [B, N] int, tts_stop [B, T + 1] int,
+        tts_speaker [B, 1, speaker_embed_dim] or None.  Returns the reference's model_out entries that exist after the TTS
+        half: final_output, mel_linear, stop_prob, decoder_attention, text_encoder_attention, text_enc_output, tts_loss,
+        loss, losses, reduced_target."""
+        if not (train_text_encoder and train_decoder):
+            raise NotImplementedError('sub-networks in inference mode inside a training step are not implemented')
+        dev, C, r = self.device, self.mel_channels, self.r
+        tokens = torch.as_tensor(tts_phonemes, device=dev).to(torch.int32).contiguous()
+        B, N = tokens.shape
+        tar = torch.as_tensor(tts_mel, dtype=torch.float32, device=dev)
+        stop_t = torch.as_tensor(tts_stop, device=dev).to(torch.int32)
+        tar_real, tar_mel, tar_stop, mel_len = self.input_reshape(tar, stop_t)
+        tar_mel = tar_mel.contiguous()
+        Tq = tar_mel.shape[1]
+        Tt = Tq * r
+        if N > self.pe_enc.shape[0] or Tt > self.pe_dec.shape[0] + r - 1:
+            raise ValueError('sequence exceeds the positional-encoding table')
+        self._infer = None
+        self._site = 0
+        self._seed_now = (self.seed * 1000003 + self.iterations * 7919 + 12345 + self.rank * 0x9E3779B1) & 0xFFFFFFFF
+        self._host_rng = np.random.default_rng(self._seed_now)
+        st, de, dd = self.store, self.de, self.dd
+        Me, Md, Mt = B * N, B * Tq, B * Tt
+        enc_tape, enc_attn, dec_attn = [], {}, {}
+        st.clear_gradients()
+
+        # ---- encoder output [text | speaker]
+        text_out, _ = self._encode(tokens, B, N, enc_tape, enc_attn)
+        enc = self._empty(Me, self.enc_dim)
+        enc[:, :de].copy_(text_out)
+        if self.system_type in ('speaker_style_text', 'speaker_text'):
+            spk = torch.as_tensor(tts_speaker, dtype=torch.float32, device=dev).reshape(B, 1, -1)
+            if spk.shape[2] != self.enc_dim - de:
+                raise ValueError(f'speaker embedding has {spk.shape[2]} values, the model expects {self.enc_dim - de}')
+            enc.view(B, N, self.enc_dim)[:, :, de:].copy_(spk.expand(B, N, spk.shape[2]))
+        enc_mask = self._empty(B, N)
+        ops.row_zero_mask(enc, enc_mask.view(-1))
+        d_enc = torch.zeros(Me, self.enc_dim, dtype=torch.float32, device=dev)
+
+        # ---- decoder prenet (dropout always on, layers.py:394-402), positional encoding of every r-th frame, dropout
+        dec_mask = self._empty(B, Tq)
+        tg2 = tar_mel.view(Md, C)
+        ops.row_zero_mask(tg2, dec_mask.view(-1))
+        rp = self.decoder_prenet_dropout
+        inv_keep = 1.0 / (1.0 - rp)
+        p1 = self._empty(Md, self.prenet1.N)
+        self._lin_fwd(tg2, self.prenet1, p1, Md, dropout=(rp, self._seed_now, 1000, 0))
+        p2 = self._empty(Md, dd)
+        self._lin_fwd(p1, self.prenet2, p2, Md, dropout=(rp, self._seed_now, 1001, 0))
+        if self.gate_log is not None:
+            self.gate_log += [p1 > 0, p2 > 0]
+        pe = self.pe_dec[0:Tt:r].contiguous()
+        cat = self._empty(Md, 2 * dd)
+        y0 = cat[:, :dd]
+        T.affine_act(p2, y0, self.dec_scale, self.dec_shift, None, residual=pe, r_mod=Tq, M=Md, C=dd)
+        site1 = self._next_site()
+        T.dropout(y0, y0, self.dropout_rate, self._seed_now, site1, M=Md, D=dd)
+
+        def prenet_backward(dy0):
+            T.dropout(dy0, dy0, self.dropout_rate, self._seed_now, site1, M=Md, D=dd)
+            T.axpby(dy0, dy0, alpha=math.sqrt(np.float32(dd)) * inv_keep, beta=0.0, M=Md, D=dd)
+            T.colreduce(1, self.prenet2.db, g=dy0, a=p2, act='relu', dy_out=dy0, M=Md, C=dd)
+            T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.precision)
+            dp1 = self._empty(Md, self.prenet1.N)
+            ops.gemm(dy0, self.prenet2.lin.bwd, dp1, M=Md, precision=self.precision, alpha=inv_keep)
+            T.colreduce(1, self.prenet1.db, g=dp1, a=p1, act='relu', dy_out=dp1, M=Md, C=self.prenet1.N)
+            T.wgrad(tg2, dp1, self.prenet1.dk, M=Md, precision=self.precision)
+
+        # ---- decoder blocks (layers.py:357-376)
+        dec_tape = []
+        n_blocks = len(self.dec_blocks)
+        for i, (S, Cx, tail) in enumerate(self.dec_blocks):
+            cat2 = self._empty(Md, 2 * dd)
+            self._sarn_fwd(S, cat, B, Tq, dec_mask, cat2[:, :dd], dec_tape, causal=True)
+            x2 = self._empty(Md, dd)
+            dec_attn[self.dec_names[i]] = self._carn_fwd(Cx, cat2, enc, d_enc, B, Tq, N, enc_mask, x2, dec_tape)
+            nxt = self._empty(Md, 2 * dd) if i + 1 < n_blocks else self._empty(Md, dd)
+            if isinstance(tail, _Ffn):
+                self._ffn_fwd(tail, x2, Md, nxt[:, :dd], dec_tape)
+            else:
+                self._cnn_bn_fwd(tail, x2, Md, Tq, nxt[:, :dd], dec_tape)
+            cat = nxt
+        dec_out = cat[:, :dd]
+
+        # ---- projections: r frames per decoder step, stop head, causal post-net
+        F = self._final_layer(r)
+        proj = self._empty(Md, r * C)
+        self._lin_fwd(dec_out, F, proj, Md)
+        mel = proj.view(Mt, C)
+        stop4 = self._empty(Mt, 4)
+        self._lin_fwd(mel, self.stop, stop4, Mt)
+        final = self._empty(Mt, C)
+        post_tape = []
+        self._cnn_bn_fwd(self.postnet, mel, Mt, Tt, final, post_tape)
+
+        # ---- losses over the first mel_len frames (traning_steps.py:33-40, utils/losses.py)
+        Ml = B * mel_len
+        target2 = tar_real.reshape(Ml, C)
+
+        def head(x3, width):
+            return x3.view(B, Tt, -1)[:, :mel_len, :width].reshape(Ml, width)
+
+        final_l, mel_l, stop_l = head(final, C), head(mel, C), head(stop4, 3)
+        labels = tar_stop.reshape(Ml).contiguous()
+        losses = torch.zeros(3, dtype=torch.float32, device=dev)
+        ops.masked_mae(target2, final_l, losses[0:1])
+        dstop_l = torch.zeros(Ml, 4, dtype=torch.float32, device=dev)
+        T.scaled_xent(stop_l, labels, losses[1:2], dlogits=dstop_l[:, :3], index=2, scaling=self.stop_scaling,
+                      scale=self.loss_weights[1] / Ml)
+        ops.masked_mae(target2, mel_l, losses[2:3])
+        if self.gate_log is not None:
+            self.gate_log += [torch.sign(final_l - target2), torch.sign(mel_l - target2)]
+        lw = self.loss_weights
+        # (scaled_xent was given scale = weight / M for its gradient; its loss value carries the weight too)
+        loss_vals = torch.stack([losses[0], losses[1] / lw[1], losses[2]])
+        tts_loss = loss_vals[0] * lw[0] + loss_vals[1] * lw[1] + loss_vals[2] * lw[2]
+
+        # ---- backward
+        def spread(g_l, width):
+            """[B * mel_len, width] -> [B * Tt, width] with zero rows past mel_len."""
+            if mel_len == Tt:
+                return g_l
+            g = torch.zeros(B, Tt, width, dtype=torch.float32, device=dev)
+            g[:, :mel_len].copy_(g_l.view(B, mel_len, width))
+            return g.view(Mt, width)
+
+        dfinal_l = self._empty(Ml, C)
+        T.masked_mae_bwd(target2, final_l, dfinal_l, lw[0])
+        dmel_l = self._empty(Ml, C)
+        T.masked_mae_bwd(target2, mel_l, dmel_l, lw[2])
+        dmel = post_tape[0](spread(dfinal_l, C))
+        T.axpby(spread(dmel_l, C), dmel, alpha=1.0, beta=1.0, M=Mt, D=C)
+        self._lin_bwd(mel, self.stop, spread(dstop_l, 4), Mt, dx=dmel, accumulate=True)
+        d_dec = self._empty(Md, dd)
+        self._lin_bwd(dec_out, F, dmel.view(Md, r * C), Md, dx=d_dec)
+        g = d_dec
+        for bw in reversed(dec_tape):
+            g = bw(g)
+        prenet_backward(g)
+        g = d_enc[:, :de].contiguous()
+        for bw in reversed(enc_tape):
+            g = bw(g)
+        overlap = parallel.GradientOverlap(self.store.grad, self.bucket_elems, self.pg, self._comm)
+        overlap.finish()
+        if apply:
+            self._apply_gradients()
+        return {'final_output': final.view(B, Tt, C), 'mel_linear': mel.view(B, Tt, C), 'stop_prob': stop4.view(B, Tt, 4)[:, :, :3],
+                'decoder_attention': dec_attn, 'text_encoder_attention': enc_attn, 'text_enc_output': text_out.reshape(B, N, de),
+                'gst_output': None, 'decoder_output': dec_out.reshape(B, Tq, dd), 'linear': mel.view(B, Tt, C),
+                'tts_loss': tts_loss, 'style_loss': 0, 'loss': tts_loss,
+                'losses': {'output': loss_vals[0], 'stop_prob': loss_vals[1], 'mel_linear': loss_vals[2]},
+                'reduced_target': tar_mel}
+
+    def val_step(self, *a, **kw):
+        raise NotImplementedError('validation runs through AutoregressiveTransformer.val_step on weights()')

@@ -73,6 +73,7 @@ class ReferenceEncoderGST:
     def run(self, x, precision, return_attention=True):
         """x: [B, T, mel] float32 device tensor -> (style embedding [B, sd], attention [B, heads, 1, tokens] or None)."""
         B, H, W = x.shape
+        precision = ops.precision_at(precision, 'gst')
         dev, f32 = self.device, dict(dtype=torch.float32, device=self.device)
         Ho, pt = same_pad(H, 3, self.stride)
         Wo, pl = same_pad(W, 3, self.stride)
@@ -129,7 +130,7 @@ class AutoregressiveTransformer:
             raise TypeError(f'unexpected keywords beside a config dict: {sorted(keywords)}')
         cfg = self.config = dict(config)
         self.device = torch.device(device)
-        self.precision = precision
+        self.precision = ops.as_precision(precision)
         self.system_type = cfg['system_type']
         self.mel_channels = cfg['mel_channels']
         self.max_r = cfg['max_r']
@@ -267,22 +268,22 @@ class AutoregressiveTransformer:
         dec_mask = torch.empty(B, Tq, **f32)
         ops.row_zero_mask(tg.view(B * Tq, C), dec_mask.view(-1))
         p1 = torch.empty(B * Tq, self.prenet1.N, **f32)
-        ops.gemm(tg.view(B * Tq, C), self.prenet1, p1, precision=self.precision, dropout=(rate, seed, 0, 0))
+        ops.gemm(tg.view(B * Tq, C), self.prenet1, p1, precision=self.precision, dropout=(rate, seed, 0, 0), site='prenet')
         pe = self.pe_dec[0:Tq * r:r].contiguous()
         ops.gemm(p1, self.prenet2, ws['xc'][:, :dd], alpha=math.sqrt(np.float32(dd)), residual=pe, r_mod=Tq,
-                 precision=self.precision, dropout=(rate, seed, 1, 0))
+                 precision=self.precision, dropout=(rate, seed, 1, 0), site='prenet')
         attn = self.decoder.run(ws, B, Tq, N, dec_mask, enc_mask, self.precision, return_attention)
         dec_out = ws['xc'][:, :dd]
         lin = self._final_proj(r)
         proj = torch.empty(B * Tq, r * C, **f32)
-        ops.gemm(dec_out, lin, proj, precision=self.precision)
+        ops.gemm(dec_out, lin, proj, precision=self.precision, site='out')
         mel = proj.view(B * Tq * r, C)                                    # (b, t, r, c) -> rows (b, t*r + j)
         T = Tq * r
         stop = torch.empty(B * T, 3, **f32)
-        ops.gemm(mel, self.stop_linear, stop, precision=self.precision)
+        ops.gemm(mel, self.stop_linear, stop, precision=self.precision, site='stop')
         hid = max(self.postnet.hidden(), 4)
         final = torch.empty(B * T, C, **f32)
-        self.postnet.run(mel, torch.empty(B * T, hid, **f32), torch.empty(B * T, hid, **f32), final, T, self.precision)
+        self.postnet.run(mel, torch.empty(B * T, hid, **f32), torch.empty(B * T, hid, **f32), final, T, self.precision, site='postnet')
         mel3 = mel.view(B, T, C)
         return {'mel_linear': mel3, 'final_output': final.view(B, T, C), 'stop_prob': stop.view(B, T, 3),
                 'decoder_attention': attn, 'decoder_output': dec_out.reshape(B, Tq, dd), 'linear': mel3}      # (a view of this call's workspace)
@@ -353,7 +354,8 @@ class AutoregressiveTransformer:
     def _predict_incremental(self, inp, targets, spk_embed, max_length, encode, verbose, program=True, dropout_seed=None):
         rate = self.decoder_prenet_dropout
         seed = self._next_dropout_seed() if dropout_seed is None else int(dropout_seed) & 0xFFFFFFFF
-        dev, f32, pr = self.device, dict(dtype=torch.float32, device=self.device), self.precision
+        dev, f32 = self.device, dict(dtype=torch.float32, device=self.device)
+        pr = ops.precision_at(self.precision, 'incremental')       # one-row products: latency-bound at either precision
         d, r, C = self.dd, self.r, self.mel_channels
         if targets is not None:
             targets = self.encode_ref(targets)

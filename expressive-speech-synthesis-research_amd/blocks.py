@@ -68,10 +68,10 @@ class SelfAttentionLayer:
 
     def run(self, xc, qkv, y, x1, B, L, key_mask, causal, attn, precision):
         d = self.d
-        ops.gemm(xc[:, :d], self.qkv, qkv, precision=precision)
+        ops.gemm(xc[:, :d], self.qkv, qkv, precision=precision, site='qkv')
         ops.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], xc[:, d:], B, self.heads, L, L, d // self.heads,
                       key_mask=key_mask, causal=causal, attn=attn, precision=precision)
-        ops.gemm(xc, self.out, y, precision=precision)
+        ops.gemm(xc, self.out, y, precision=precision, site='attn_out')
         ops.rownorm(y, x1, ln_a=self.ln, residual=xc[:, :d], ln_b=self.last_ln)
 
 
@@ -98,10 +98,10 @@ class FFNLayer:
 
     def run(self, x1, h, y, out, precision):
         if self.fold:
-            ops.gemm(x1, self.d12, y, precision=precision)
+            ops.gemm(x1, self.d12, y, precision=precision, site='ffn')
         else:
-            ops.gemm(x1, self.d1, h, precision=precision)
-            ops.gemm(h, self.d2, y, precision=precision)
+            ops.gemm(x1, self.d1, h, precision=precision, site='ffn')
+            ops.gemm(h, self.d2, y, precision=precision, site='ffn')
         ops.rownorm(y, out, ln_a=self.ln, act='relu', residual=x1, ln_b=self.last_ln)
 
 
@@ -119,15 +119,15 @@ class ConvBNLayer:
     def hidden(self):
         return max([l.N for l in self.layers[:-1]] + [0])
 
-    def run(self, x, h_a, h_b, out, seg_len, precision):
+    def run(self, x, h_a, h_b, out, seg_len, precision, site='conv'):
         """x: block input view; h_a/h_b: two scratch buffers wide enough for the hidden size; out: output view."""
         src = x
         bufs = (h_a, h_b)
         for i, lin in enumerate(self.layers[:-1]):
             dst = bufs[i & 1][:, :lin.N]
-            ops.gemm(src, lin, dst, seg_len=seg_len, precision=precision)
+            ops.gemm(src, lin, dst, seg_len=seg_len, precision=precision, site=site)
             src = dst
-        ops.gemm(src, self.layers[-1], out, seg_len=seg_len, residual=x, precision=precision)
+        ops.gemm(src, self.layers[-1], out, seg_len=seg_len, residual=x, precision=precision, site=site)
 
 
 class SelfAttentionStack:
@@ -160,6 +160,7 @@ class SelfAttentionStack:
     def run(self, ws, B, L, key_mask, precision, return_attention, causal=False):
         """Input in ws['xc'][:, :d]; output left there.  Returns {name: attention weights} (empty if not requested)."""
         d = self.d
+        precision = ops.scoped(precision, 'encoder' if 'Encoder' in self.name else 'decoder')
         xc, attn_out = ws['xc'], {}
         for (sa, ff), name in zip(self.blocks, self.names):
             attn = None
@@ -189,14 +190,14 @@ class CrossAttentionLayer:
 
     def project_kv(self, enc, kv, precision):
         """enc [B*N, E] -> kv [B*N, 2d] (keys | values); depends on the encoder output only."""
-        ops.gemm(enc, self.wkv, kv, precision=precision)
+        ops.gemm(enc, self.wkv, kv, precision=precision, site='cross_kv')
 
     def run(self, xc, q, kv, y, out, B, Lq, Lk, enc_mask, attn, precision):
         d = self.d
-        ops.gemm(xc[:, :d], self.wq, q, precision=precision)
+        ops.gemm(xc[:, :d], self.wq, q, precision=precision, site='cross_q')
         ops.attention(q, kv[:, :d], kv[:, d:], xc[:, d:], B, self.heads, Lq, Lk, d // self.heads, key_mask=enc_mask,
                       attn=attn, precision=precision)
-        ops.gemm(xc, self.out, y, precision=precision)
+        ops.gemm(xc, self.out, y, precision=precision, site='attn_out')
         ops.rownorm(y, out, residual=xc[:, :d], ln_b=self.ln)
 
 
@@ -228,6 +229,7 @@ class CrossAttentionStack:
                 'kv': [torch.empty(enc_rows, 2 * d, **f32) for _ in self.blocks]}
 
     def project_kv(self, ws, enc, precision):
+        precision = ops.scoped(precision, 'encoder' if 'Encoder' in self.name else 'decoder')
         for (_, ca, _), kv in zip(self.blocks, ws['kv']):
             ca.project_kv(enc, kv, precision)
 
@@ -235,6 +237,7 @@ class CrossAttentionStack:
         """Input in ws['xc'][:, :d]; output left there.  Self-attention is causal (look-ahead mask) and masks padded
         decoder frames; returns {name: cross-attention weights}."""
         d = self.d
+        precision = ops.scoped(precision, 'encoder' if 'Encoder' in self.name else 'decoder')
         xc, xc2, attn_out = ws['xc'], ws['xc2'], {}
         for (sa, ca, ff), kv, name in zip(self.blocks, ws['kv'], self.names):
             attn = None

@@ -528,19 +528,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
         else a_row[i] = make_arow(p, m0 + a_r0 + 32 * i);
     }
 
-    // one register set: the loads of K-step kt + 1 are issued while step kt is being multiplied
-    float4 a_reg[AI];
-    bool a_ok[AI];
+    // two register sets: the loads of K-step kt + 2 are issued while step kt is being multiplied, so a set has two
+    // multiply phases (of this workgroup and of the one sharing the CU) to arrive before it is split and stored to LDS;
+    // with one set in flight the memory latency of a large launch (over 2000 clocks) showed in every K-step
+    // (plain locals handed over by reference: gathered in a struct, or as an array of W registers, the compiler keeps them in
+    // scratch memory)
     static_assert(TN == 1 || TN == 2, "one or two 16-byte W units per thread");
-    uint4 wh0, wh1, wl0, wl1;
     KCursor kcur = make_kcursor(p, a_ch * 4);   // load_tiles is called for kt = 0, 1, 2, ... in order
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](float4 (&ga)[AI], bool (&gok)[AI], uint4& gwh0, uint4& gwh1, uint4& gwl0, uint4& gwl1, int kt) {
         if (KIND == 1) {
             const bool ok = kt * 32 + a_ch * 4 < p.K;
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
-                a_reg[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? kt * 32 : -a_ch * 4));
-                a_ok[i] = ok;
+                ga[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? kt * 32 : -a_ch * 4));
+                gok[i] = ok;
             }
         } else if (KIND == 2) {
             const int dw = kcur.tap - p.conv_pl;
@@ -550,16 +551,15 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
                 const bool ok = kok && (unsigned)(a_pos[i] + dw) < (unsigned)p.conv_w;
-                a_reg[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? off : 0L));
-                a_ok[i] = ok;
+                ga[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? off : 0L));
+                gok[i] = ok;
             }
         } else {
             const ATap tp = atap_from(p, kcur.kk, kcur.tap, kcur.c);
             advance(p, kcur, 32);
 #pragma unroll
-            for (int i = 0; i < AI; ++i) a_reg[i] = load_a_raw(p, a_row[i], tp, a_ok[i]);
+            for (int i = 0; i < AI; ++i) ga[i] = load_a_raw(p, a_row[i], tp, gok[i]);
         }
-        // (named registers, not an array: with an array of two the compiler keeps the fragments in scratch memory)
         auto w_off = [&](int i) {
             // W holds ceil(N / 64) * 64 rows, so the last tile may reach past it: read the last block again instead
             // (those columns are >= N and never stored); no load sits under a condition (see load_a_raw)
@@ -568,30 +568,31 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
             return ((long)nb * KS + kt) * 512 + (idx & 63) * 8;
         };
         const long o0 = w_off(0);
-        wh0 = *reinterpret_cast<const uint4*>(p.W_hi + o0);
-        if (NS == 2) wl0 = *reinterpret_cast<const uint4*>(p.W_lo + o0);
+        gwh0 = *reinterpret_cast<const uint4*>(p.W_hi + o0);
+        if (NS == 2) gwl0 = *reinterpret_cast<const uint4*>(p.W_lo + o0);
         if (TN == 2) {
             const long o1 = w_off(1);
-            wh1 = *reinterpret_cast<const uint4*>(p.W_hi + o1);
-            if (NS == 2) wl1 = *reinterpret_cast<const uint4*>(p.W_lo + o1);
+            gwh1 = *reinterpret_cast<const uint4*>(p.W_hi + o1);
+            if (NS == 2) gwl1 = *reinterpret_cast<const uint4*>(p.W_lo + o1);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](const float4 (&ga)[AI], const bool (&gok)[AI], const uint4& gwh0, const uint4& gwh1, const uint4& gwl0,
+                           const uint4& gwl1, int buf) {
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int o = (a_r0 + 32 * i) * BG_LD + a_ch * 4;
             // KIND 1 needs no zeroing: a K index past the end re-reads valid data of the row, and W is zero-padded there
-            const float4 az = KIND == 1 ? a_reg[i] : zero_unless(a_ok[i], a_reg[i]);
+            const float4 az = KIND == 1 ? ga[i] : zero_unless(gok[i], ga[i]);
             bf16x4 hi, lo;
             split_bf16x4(az, hi, lo);
             *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = hi;
             if (NS == 2) *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = lo;
         }
-        *reinterpret_cast<uint4*>(&Ws[buf][0][tid * 8]) = wh0;
-        if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][tid * 8]) = wl0;
+        *reinterpret_cast<uint4*>(&Ws[buf][0][tid * 8]) = gwh0;
+        if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][tid * 8]) = gwl0;
         if (TN == 2) {
-            *reinterpret_cast<uint4*>(&Ws[buf][0][(tid + 256) * 8]) = wh1;
-            if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][(tid + 256) * 8]) = wl1;
+            *reinterpret_cast<uint4*>(&Ws[buf][0][(tid + 256) * 8]) = gwh1;
+            if (NS == 2) *reinterpret_cast<uint4*>(&Ws[buf][NS - 1][(tid + 256) * 8]) = gwl1;
         }
     };
 
@@ -640,13 +641,22 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
         }
     };
 
-    load_tiles(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        store_tiles(buf);
+    float4 a0[AI], a1[AI];
+    bool ok0[AI], ok1[AI];
+    uint4 u0, u1, u2, u3, v0, v1, v2, v3;
+    load_tiles(a0, ok0, u0, u1, u2, u3, 0);
+    if (nk > 1) load_tiles(a1, ok1, v0, v1, v2, v3, 1);
+    for (int kt = 0; kt < nk; kt += 2) {
+        store_tiles(a0, ok0, u0, u1, u2, u3, 0);
         __syncthreads();
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        multiply(buf);
+        if (kt + 2 < nk) load_tiles(a0, ok0, u0, u1, u2, u3, kt + 2);
+        multiply(0);
+        if (kt + 1 < nk) {
+            store_tiles(a1, ok1, v0, v1, v2, v3, 1);
+            __syncthreads();
+            if (kt + 3 < nk) load_tiles(a1, ok1, v0, v1, v2, v3, kt + 3);
+            multiply(1);
+        }
     }
 
 #pragma unroll

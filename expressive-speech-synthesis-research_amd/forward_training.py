@@ -214,7 +214,8 @@ def _register_forward_params(store, w, cfg):
 
 
 class ForwardTransformerTrainer:
-    def __init__(self, weights, config, device='cuda', precision='bf16x3', seed=0, process_group=None, bucket_mb=25):
+    def _init_common(self, config, device, precision, seed, process_group, bucket_mb):
+        """What every trainer built on these layer passes shares: device, random streams, data-parallel group, Adam settings."""
         if not torch.cuda.is_available():
             raise RuntimeError('training needs a GPU: the hot path has no CPU implementation')
         ops._lib.load()
@@ -235,9 +236,19 @@ class ForwardTransformerTrainer:
         self._pack_plan = None
         self.drop_n_heads = 0
         self.learning_rate = 1e-4
-        self.loss_weights = [3., 1.]
         self.beta1, self.beta2, self.eps = 0.9, 0.98, 1e-9          # utils/config_manager.py:172-176
         self.iterations = 0
+        self._infer = None
+        # tests: set to a list and train_step appends, in forward order, the branch every ReLU took ([rows, channels] bool
+        # tensors) and then the signs (pred - target) of the MAE losses, so that an oracle can differentiate the same
+        # piecewise-linear function the device did
+        self.gate_log = None
+        self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+
+    def __init__(self, weights, config, device='cuda', precision='bf16x3', seed=0, process_group=None, bucket_mb=25):
+        self._init_common(config, device, precision, seed, process_group, bucket_mb)
+        cfg = self.config
+        self.loss_weights = [3., 1.]
         self._pos_scalars = {k: float(np.asarray(weights[k + '.pos_encoding_scalar'])) for k in ('encoder', 'decoder')}
         dev = self.device
         st = self.store = ParamStore(dev)
@@ -268,12 +279,6 @@ class ForwardTransformerTrainer:
         for blk in self.enc_blocks + self.dec_blocks:
             self._linears += blk[0].linears() + blk[1].linears()
         self._linears += self.dur.linears() + [self.prenet1.lin, self.prenet2.lin, self.out.lin] + self.postnet.linears()
-        self._infer = None
-        # tests: set to a list and train_step appends, in forward order, the branch every ReLU took ([rows, channels] bool
-        # tensors) and then the signs (pred - target) of the two MAE losses, so that an oracle can differentiate the same
-        # piecewise-linear function the device did
-        self.gate_log = None
-        self._comm = torch.cuda.Stream(device=dev) if self.world > 1 else None
 
     # ------------------------------------------------------------------ construction helpers
     def _make_stack(self, p, d, heads, dense_blocks, k):
@@ -318,14 +323,14 @@ class ForwardTransformerTrainer:
             ops.gemm(dy, L.lin.bwd, dx, M=M, seg_len=sl, precision=self.precision, residual=dx if accumulate else residual)
         return dx
 
-    def _sarn_fwd(self, S, cat, B, L, key_mask, out, tape):
+    def _sarn_fwd(self, S, cat, B, L, key_mask, out, tape, causal=False):
         M, d, H = B * L, S.d, S.H
         qkv = self._empty(M, 3 * d)
         self._lin_fwd(cat[:, :d], S.wqkv, qkv, M)
         attn = self._empty(B, H, L, L)
         ctx = cat[:, d:]
-        ops.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], ctx, B, H, L, L, d // H, key_mask=key_mask, attn=attn,
-                      precision=self.precision)
+        ops.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], ctx, B, H, L, L, d // H, key_mask=key_mask, causal=causal,
+                      attn=attn, precision=self.precision)
         hscale = hinv = None
         if self.drop_n_heads > 0 and H > 1:
             keep = np.ones((B, H), np.float32)

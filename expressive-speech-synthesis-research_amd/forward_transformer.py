@@ -33,7 +33,7 @@ class ForwardTransformer:
             raise TypeError(f'unexpected keywords beside a config dict: {sorted(keywords)}')
         self.config = dict(config)
         self.device = torch.device(device)
-        self.precision = precision
+        self.precision = ops.as_precision(precision)
         self.drop_n_heads = 0
         self.decoder_prenet_dropout = 0.0
         self.dropout_seed = 0
@@ -92,9 +92,9 @@ class ForwardTransformer:
         ops.embed_posenc(tokens, self.emb, self.pe_enc, None, e['xc'], ws['key_mask'], math.sqrt(np.float32(de)))
         attn = self.encoder.run(e, B, N, ws['key_mask'], self.precision, return_attention)
         x = e['xc'][:, :de]
-        ops.gemm(x, self.dp_conv0, ws['dp_a'], seg_len=N, precision=self.precision)
+        ops.gemm(x, self.dp_conv0, ws['dp_a'], seg_len=N, precision=self.precision, site='dur_pred')
         ops.rownorm(ws['dp_a'], ws['dp_b'], ln_a=self.dp_ln[0], act='relu')
-        ops.gemm(ws['dp_b'], self.dp_conv1, ws['dp_a'], seg_len=N, precision=self.precision)
+        ops.gemm(ws['dp_b'], self.dp_conv1, ws['dp_a'], seg_len=N, precision=self.precision, site='dur_pred')
         ops.rownorm(ws['dp_a'], None, ln_a=self.dp_ln[1], act='relu', residual=x, ln_b=self.dp_ln[2],
                     dot_w=self.dp_w, dot_b=self.dp_b, dot_scale=float(durations_scalar),
                     dot_mask=ws['key_mask'].view(-1), dot_out=ws['dur'].view(-1))
@@ -115,13 +115,13 @@ class ForwardTransformer:
             seed = (self.dropout_seed * 1000003 + self._calls * 7919 + 12345) & 0xFFFFFFFF
             self._calls += 1
             drop1, drop2 = (rate, seed, 1000, 0), (rate, seed, 1001, 0)
-        ops.gemm(ws['mels_in'], self.prenet1, ws['p1'], precision=self.precision, dropout=drop1)
+        ops.gemm(ws['mels_in'], self.prenet1, ws['p1'], precision=self.precision, dropout=drop1, site='prenet')
         ops.gemm(ws['p1'], self.prenet2, d['xc'][:, :dd], alpha=math.sqrt(np.float32(dd)), residual=self.pe_dec,
-                 r_mod=T, precision=self.precision, dropout=drop2)
+                 r_mod=T, precision=self.precision, dropout=drop2, site='prenet')
         attn = self.decoder.run(d, B, T, ws['frame_mask'], self.precision, return_attention)
-        ops.gemm(d['xc'][:, :dd], self.out, ws['mel0'], precision=self.precision)
+        ops.gemm(d['xc'][:, :dd], self.out, ws['mel0'], precision=self.precision, site='out')
         mel = torch.empty(B * T, self.mel_channels, dtype=torch.float32, device=self.device)
-        self.postnet.run(ws['mel0'], ws['pn_a'], ws['pn_b'], mel, T, self.precision)
+        self.postnet.run(ws['mel0'], ws['pn_a'], ws['pn_b'], mel, T, self.precision, site='postnet')
         return mel.view(B, T, self.mel_channels), attn
 
     # ------------------------------------------------------------------ reference surface

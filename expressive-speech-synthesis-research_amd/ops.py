@@ -16,6 +16,47 @@ from ._lib import ACT, AttentionArgs, GemmArgs, RownormArgs, check
 
 PRECISION = {'bf16': 1, 'bf16x3': 3}
 
+
+class PrecisionPolicy:
+    """Operand precision per call site.  `table` maps a site ('qkv', 'attention', 'attn_out', 'ffn', 'conv', 'cross_q',
+    'cross_kv', 'dur_pred', 'prenet', 'out', 'stop', 'postnet', 'gst'), optionally prefixed by the stack it sits in
+    ('encoder.qkv', 'decoder.conv'), to 'bf16' or 'bf16x3'; 'default' covers the rest.  Look-up order:
+    '<scope>.<site>', '<site>', 'default'."""
+
+    def __init__(self, table, scope=''):
+        bad = {k: v for k, v in table.items() if v not in PRECISION}
+        if bad:
+            raise ValueError(f'PrecisionPolicy: unknown precision in {bad}')
+        self.table, self.scope = dict(table), scope
+        self.table.setdefault('default', 'bf16x3')
+
+    def scoped(self, scope):
+        return PrecisionPolicy(self.table, scope.lower())
+
+    def at(self, site):
+        t = self.table
+        return t.get(f'{self.scope}.{site}') or t.get(site) or t['default']
+
+    def __repr__(self):
+        return f'PrecisionPolicy({self.table})'
+
+
+def as_precision(precision):
+    """'bf16' / 'bf16x3' stay strings; a dict becomes a PrecisionPolicy."""
+    if isinstance(precision, dict):
+        return PrecisionPolicy(precision)
+    if not isinstance(precision, PrecisionPolicy) and precision not in PRECISION:
+        raise ValueError(f'precision must be one of {sorted(PRECISION)} or a site table, got {precision!r}')
+    return precision
+
+
+def scoped(precision, scope):
+    return precision.scoped(scope) if isinstance(precision, PrecisionPolicy) else precision
+
+
+def precision_at(precision, site):
+    return precision.at(site) if isinstance(precision, PrecisionPolicy) else precision
+
 # When set to a list, every op appends (kind, info dict, relaunch callable): used by bench.py to time
 # individual kernels with events and to price them against the roofline.
 _trace = None
@@ -186,13 +227,15 @@ def new_gemm_workspace(device, nbytes=4 << 20):
 
 
 def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
-         split=True, conv2d=None, dropout=None, batch=None, workspace=None):
+         split=True, conv2d=None, dropout=None, batch=None, workspace=None, site=None):
     """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary).
     dropout = (rate, seed, site, row0): keep/scale after the activation, generator row = row0 + output row.
     batch = (count, stride_a, stride_w, stride_c, stride_v): that many products of this shape in one launch; x / lin / out
     describe product 0 and the strides (elements) lead to the others (see estts_gemm_args.batch).
     workspace = (float32 scratch, zeroed int32 tickets): split-K scratch of its own for launches on a second stream that may
-    run beside launches using the shared one (new_gemm_workspace())."""
+    run beside launches using the shared one (new_gemm_workspace()).
+    precision: 'bf16' / 'bf16x3', or a PrecisionPolicy resolved at `site`."""
+    precision = precision_at(precision, site)
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
     a = GemmArgs()
@@ -239,8 +282,9 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
 
 
 def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, attn=None, precision='bf16x3',
-              kv_shared=False, variant=0):
+              kv_shared=False, variant=0, site='attention'):
     """q: [B*Lq, >=H*depth] view, k/v: [B*Lk, ...] views, ctx: [B*Lq, ...] view; attn: [B,H,Lq,Lk] or None."""
+    precision = precision_at(precision, site)
     for t, n in ((q, 'q'), (k, 'k'), (v, 'v'), (ctx, 'ctx')):
         _check_f32(t, n)
     a = AttentionArgs()

@@ -1,4 +1,4 @@
-"""CPU oracle for one ForwardTransformer training step (float64 PyTorch autograd).
+"""CPU oracle for one ForwardTransformer / AutoregressiveTransformer training step (float64 PyTorch autograd).
 
 TEST INFRASTRUCTURE ONLY (tests/, bench.py's cpu_baseline leg).
 
@@ -11,6 +11,11 @@ moves the moving statistics with momentum 0.99; the CNNResNorm inside a SelfAtte
 1 - rate and scales by 1 / (1 - rate); HeadDrop (layers.py:74-97) zeroes whole heads per sample and rescales.
 Random masks are INPUTS here (`masks`: list consumed in call order; `head_keep`: list of [B, H] arrays), so that the
 device path and this oracle can be run on identical draws.
+
+autoregressive_train_step restates the TTS half of train_models_step (TransformerTTS/model/traning_steps.py:22-56) with the
+three `training=` flags True (the shipped configuration): model/AutoregressiveTransformer.py:124-181 on top of
+model/layers.py:258-376 (cross-attention blocks), :526-585 (reference encoder: its BatchNormalization layers are called
+without `training=` and inherit the style encoder's), utils/losses.py:4-21,41-47.
 
 PARITY STATUS vs TensorFlow: unpinned (TensorFlow is not installable here); gradients come from autograd over the
 same forward restatement as oracle/tts_torch.py.
@@ -182,6 +187,151 @@ def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=Non
     return {'loss': float(loss.detach()), 'mel_loss': float(l_mel.detach()), 'dur_loss': float(l_dur.detach()), 'mel': y.detach().numpy(),
             'duration': dur.detach().numpy(), 'grads': grads, 'new_stats': c.new_stats,
             'encoder_attention': [a.detach().numpy() for a in enc_attn], 'decoder_attention': [a.detach().numpy() for a in dec_attn]}
+
+
+def _mha_cross(kv_in, q_in, mask, w, p, H, c):
+    """MultiHeadAttention.call(v, k, q_in, mask) (layers.py:127-147) with k = v = kv_in, head drop from the context."""
+    B, Lq, _ = q_in.shape
+    q = F.linear(q_in, w[p + '.wq.kernel'].t(), w[p + '.wq.bias'])
+    k = F.linear(kv_in, w[p + '.wk.kernel'].t(), w[p + '.wk.bias'])
+    v = F.linear(kv_in, w[p + '.wv.kernel'].t(), w[p + '.wv.bias'])
+    d = q.shape[-1]
+    dh = d // H
+    q = q.view(B, Lq, H, dh).permute(0, 2, 1, 3)
+    k = k.view(B, -1, H, dh).permute(0, 2, 3, 1)
+    v = v.view(B, -1, H, dh).permute(0, 2, 1, 3)
+    logits = torch.matmul(q, k) / math.sqrt(dh)
+    if mask is not None:
+        logits = logits + mask * -1e9
+    pw = torch.softmax(logits, dim=-1)
+    ctx = c.heads(torch.matmul(pw, v)).permute(0, 2, 1, 3).reshape(B, Lq, d)
+    return F.linear(torch.cat([q_in, ctx], dim=-1), w[p + '.dense.kernel'].t(), w[p + '.dense.bias']), pw
+
+
+def _bn_train_nd(x, w, p, c, dims):
+    """Keras BatchNormalization(training=True) with statistics over `dims` (channels last)."""
+    mean = x.mean(dim=dims)
+    var = x.var(dim=dims, unbiased=False)
+    c.new_stats[p + '.moving_mean'] = (w[p + '.moving_mean'] * 0.99 + mean.detach() * 0.01).numpy()
+    c.new_stats[p + '.moving_variance'] = (w[p + '.moving_variance'] * 0.99 + var.detach() * 0.01).numpy()
+    return (x - mean) / torch.sqrt(var + 1e-3) * w[p + '.gamma'] + w[p + '.beta']
+
+
+def _gst_train(x, w, p, n_convs, stride, H, c):
+    """ReferenceEncoderGST.call (layers.py:561-585) in training mode; x (B, T, mel)."""
+    from .tts_torch import _conv2d_same_s2
+    B = x.shape[0]
+    y = x[:, None, :, :]
+    for i in range(n_convs):
+        y = _conv2d_same_s2(y, w[f'{p}.conv{i}.kernel'], w[f'{p}.conv{i}.bias'], stride)       # (B, C, H, W)
+        y = _bn_train_nd(y.permute(0, 2, 3, 1), w, f'{p}.norm{i}', c, (0, 1, 2)).permute(0, 3, 1, 2)
+        y = c.relu(y)
+    y = y.permute(0, 2, 3, 1).reshape(B, y.shape[2], -1)
+    u = w[p + '.gru.recurrent_kernel'].shape[0]
+    h = torch.zeros(B, u, dtype=y.dtype)
+    for t in range(y.shape[1]):
+        xm = y[:, t] @ w[p + '.gru.kernel'] + w[p + '.gru.bias'][0]
+        hm = h @ w[p + '.gru.recurrent_kernel'] + w[p + '.gru.bias'][1]
+        z = torch.sigmoid(xm[:, :u] + hm[:, :u])
+        rr = torch.sigmoid(xm[:, u:2 * u] + hm[:, u:2 * u])
+        hh = torch.tanh(xm[:, 2 * u:] + rr * hm[:, 2 * u:])
+        h = z * h + (1 - z) * hh
+    proj = torch.tanh(F.linear(h, w[p + '.rnn_proj.kernel'].t(), w[p + '.rnn_proj.bias']))[:, None, :]
+    tok = torch.tanh(w[p + '.gst_tokens'])[None].expand(B, -1, -1)
+    return _mha_cross(tok, proj, None, w, p + '.mha', H, c)
+
+
+def scaled_crossentropy(targets, logits, index=2, scaling=1.0):
+    """utils/losses.py:4-21: SparseCategoricalCrossentropy(from_logits) with sample weights (target != 0) + (target == index)
+    (scaling - 1), SUM_OVER_BATCH_SIZE."""
+    ce = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), targets.reshape(-1).long(), reduction='none')
+    wgt = (targets != 0).to(logits.dtype) + (targets == index).to(logits.dtype) * (scaling - 1.0)
+    return (ce * wgt.reshape(-1)).sum() / ce.numel()
+
+
+def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_embed=None, r=1, masks=None, head_keep=None,
+                              prenet_masks=None, gates=None, stop_scaling=1.0, dtype=torch.float64):
+    """One forward + backward of the TTS half of train_models_step.  tar_mel: the decoder input (every r-th frame of
+    tar[:, :-1]), tar_real / tar_stop: tar[:, 1:] / stop[:, 1:] (AutoregressiveTransformer.input_reshape).
+    masks / head_keep / prenet_masks / gates as in forward_train_step; gates end with the sign arrays of the two MAE losses
+    (post-net output, linear output).  Returns losses, outputs, grads {name: ndarray} and the new moving statistics."""
+    dt = dtype
+    wt = {}
+    for k, v in w.items():
+        t = torch.as_tensor(np.asarray(v)).to(dt)
+        trainable = not (k.endswith('moving_mean') or k.endswith('moving_variance') or k.endswith('pos_encoding_scalar'))
+        wt[k] = t.clone().requires_grad_(trainable)
+    signs = None
+    if gates is not None:
+        gates, signs = list(gates[:-2]), gates[-2:]
+    c = _Ctx(masks, head_keep, {}, gates)
+    st = cfg['system_type']
+    tokens = torch.as_tensor(np.asarray(tokens)).long()
+    tar_mel = torch.as_tensor(np.asarray(tar_mel)).to(dt)
+    tar_real = torch.as_tensor(np.asarray(tar_real)).to(dt)
+    tar_stop = torch.as_tensor(np.asarray(tar_stop)).long()
+    B, N = tokens.shape
+    pad = (tokens == 0).to(dt)
+    x = F.embedding(tokens, wt['text_encoder_prenet.embeddings'])
+    text_out, text_attn = _sa_blocks(x, pad[:, None, None, :], wt, 'text_encoder', cfg['encoder_model_dimension'],
+                                     cfg['encoder_num_heads'], cfg['encoder_dense_blocks'], cfg['encoder_max_position_encoding'], c)
+    parts, gst_out = [text_out], None
+    if st in ('speaker_style_text', 'style_text'):
+        gst_out, _ = _gst_train(tar_mel, wt, 'style_encoder', len(cfg['ref_encoder_filters']), cfg['ref_encoder_strides'],
+                                cfg['gst_multi_num_heads'], c)
+        parts.append(gst_out.expand(-1, N, -1))
+    if st in ('speaker_style_text', 'speaker_text'):
+        parts.append(torch.as_tensor(np.asarray(spk_embed)).to(dt).reshape(B, 1, -1).expand(-1, N, -1))
+    enc = torch.cat(parts, dim=2)
+    enc_mask = (enc.detach().abs().sum(-1) == 0).to(dt)[:, None, None, :]
+    Tq = tar_mel.shape[1]
+    dec_pad = (tar_mel.abs().sum(-1) == 0).to(dt)[:, None, None, :]
+    look = torch.triu(torch.ones(Tq, Tq, dtype=dt), diagonal=1)
+    combined = torch.maximum(dec_pad, look)
+    y = c.relu(F.linear(tar_mel, wt['decoder_prenet.d1.kernel'].t(), wt['decoder_prenet.d1.bias']))
+    if prenet_masks is not None:
+        y = y * torch.as_tensor(np.asarray(prenet_masks[0]), dtype=dt).reshape(y.shape)
+    y = c.relu(F.linear(y, wt['decoder_prenet.d2.kernel'].t(), wt['decoder_prenet.d2.bias']))
+    if prenet_masks is not None:
+        y = y * torch.as_tensor(np.asarray(prenet_masks[1]), dtype=dt).reshape(y.shape)
+    d = cfg['decoder_model_dimension']
+    pe = _pe(cfg['decoder_max_position_encoding'], d, dt)
+    y = y * math.sqrt(float(np.float32(d))) + wt['decoder.pos_encoding_scalar'] * pe[None, :Tq * r:r, :]
+    y = c.dropout(y)
+    dec_attn = []
+    for i, H in enumerate(cfg['decoder_num_heads']):
+        b = f'decoder.block{i}'
+        a, _ = _mha(y, combined, wt, b + '.sarn.mha', H, c)
+        y = _ln(c.dropout(_ln(a, wt, b + '.sarn.ln')) + y, wt, b + '.sarn.last_ln')
+        a, pw = _mha_cross(enc, y, enc_mask, wt, b + '.carn.mha', H, c)
+        y = _ln(c.dropout(a) + y, wt, b + '.carn.layernorm')
+        if i < cfg['decoder_dense_blocks']:
+            z = F.linear(y, wt[b + '.ffn.d1.kernel'].t(), wt[b + '.ffn.d1.bias'])
+            z = F.linear(z, wt[b + '.ffn.d2.kernel'].t(), wt[b + '.ffn.d2.bias'])
+            z = c.dropout(c.relu(_ln(z, wt, b + '.ffn.ln')))
+            y = _ln(z + y, wt, b + '.ffn.last_ln')
+        else:
+            y = _cnn_res_norm(y, wt, b + '.conv', 2, 'relu', 'relu', 'causal', 'batch', c)
+        dec_attn.append(pw)
+    mc = cfg['mel_channels']
+    proj = F.linear(y, wt['final_proj_mel.kernel'].t(), wt['final_proj_mel.bias'])[:, :, :r * mc]
+    mel = proj.reshape(B, Tq * r, mc)
+    stop = F.linear(mel, wt['decoder_postnet.stop_linear.kernel'].t(), wt['decoder_postnet.stop_linear.bias'])
+    final = _cnn_res_norm(mel, wt, 'decoder_postnet.conv_blocks', cfg['postnet_conv_layers'], 'tanh', 'linear', 'causal', 'batch', c)
+    L = tar_real.shape[1]
+    l_out = masked_mae(tar_real, final[:, :L], None if signs is None else signs[0])
+    l_stop = scaled_crossentropy(tar_stop, stop[:, :L], 2, stop_scaling)
+    l_lin = masked_mae(tar_real, mel[:, :L], None if signs is None else signs[1])
+    if c.gates:
+        raise ValueError(f'{len(c.gates)} gate arrays left over: the gate list does not match this model')
+    loss = l_out + l_stop + l_lin
+    loss.backward()
+    grads = {k: (t.grad.numpy() if t.grad is not None else np.zeros(t.shape)) for k, t in wt.items() if t.requires_grad}
+    return {'loss': float(loss.detach()), 'losses': {'output': float(l_out.detach()), 'stop_prob': float(l_stop.detach()),
+                                                      'mel_linear': float(l_lin.detach())},
+            'final_output': final.detach().numpy(), 'mel_linear': mel.detach().numpy(), 'stop_prob': stop.detach().numpy(),
+            'gst_output': None if gst_out is None else gst_out.detach().numpy(), 'text_enc_output': text_out.detach().numpy(),
+            'decoder_attention': [a.detach().numpy() for a in dec_attn], 'grads': grads, 'new_stats': c.new_stats}
 
 
 def adam_update(w, grads, state, lr, t, beta1=0.9, beta2=0.98, eps=1e-9):

@@ -1,0 +1,210 @@
+"""AutoregressiveTransformer training step on the GPU (autoregressive_training.AutoregressiveTransformerTrainer, every kernel
+through the C ABI) against the float64 autograd oracle (oracle/tts_train_torch.autoregressive_train_step) on the same weights,
+batch and random draws.
+
+The oracle is handed the branch the device took at every ReLU and the sign of every MAE term (trainer.gate_log), so both
+differentiate the same piecewise-linear function and every gradient tensor must agree to 1e-3 of its largest entry; the
+query / key projections of the self-attentions get 1e-2 (measured: median 3e-5, all others below 2e-4; the first decoder
+self-attention's wq / wk reach 2e-3 .. 4e-3, varying from run to run with the order of the float atomics, when the reduction
+factor leaves 7 decoder steps: its logits are large, the softmax is peaked and dS = P o (dP - delta) cancels).
+Losses 2e-5 relative, outputs 1e-3 absolute (batch-statistics BatchNorm over few rows amplifies the split-bf16 error)."""
+import numpy as np
+import pytest
+import torch
+
+import estts  # noqa: F401
+from estts import configs, weights
+from oracle import tts_train_torch as OT
+
+pytestmark = pytest.mark.gpu
+
+
+def small_cfg(system_type, dropout_rate, dense_blocks=(1, 1)):
+    return configs.autoregressive_config(
+        system_type=system_type, encoder_model_dimension=64, decoder_model_dimension=128, encoder_num_heads=[2, 2],
+        decoder_num_heads=[2, 4], encoder_dense_blocks=dense_blocks[0], decoder_dense_blocks=dense_blocks[1],
+        encoder_feed_forward_dimension=128, decoder_feed_forward_dimension=160, encoder_prenet_dimension=64,
+        decoder_prenet_dimension=80, encoder_attention_conv_filters=96, decoder_attention_conv_filters=112,
+        postnet_conv_filters=48, postnet_conv_layers=3, ref_encoder_filters=[8, 8, 16], ref_encoder_gru_cell_units=32,
+        gst_style_embed_dim=64, gst_multi_num_heads=2, gst_heads=5, speaker_embed_dim=32, max_r=3, vocab_size=30,
+        encoder_max_position_encoding=64, decoder_max_position_encoding=256, dropout_rate=dropout_rate, mel_channels=80)
+
+
+def batch(cfg, B, N, T, seed):
+    """tokens [B, N], mel [B, T + 1, 80] with the start / end vectors, stop [B, T + 1] (1 = frame, 2 = end, 0 = padding)."""
+    rng = np.random.default_rng(seed)
+    tokens = rng.integers(1, cfg['vocab_size'], size=(B, N)).astype(np.int32)
+    mel = np.clip(rng.normal(0, 1.5, size=(B, T + 1, 80)), -4, 4).astype(np.float32)
+    stop = np.ones((B, T + 1), np.int32)
+    for b in range(B):
+        n_tok, n_mel = N - 2 * b, T + 1 - 3 * b
+        tokens[b, n_tok:] = 0
+        mel[b, 0] = cfg['mel_start_value']
+        mel[b, n_mel - 1] = cfg['mel_end_value']
+        mel[b, n_mel:] = 0
+        stop[b, n_mel - 1] = 2
+        stop[b, n_mel:] = 0
+    spk = rng.normal(0, 1, size=(B, 1, cfg['speaker_embed_dim'])).astype(np.float32)
+    return tokens, mel, stop, spk
+
+
+def grads_by_name(model):
+    """Device gradients under the oracle's names (fused projections split, conv kernels reshaped, stop head un-padded)."""
+    st = model.store
+    g = st.grad.cpu().numpy()
+    out = {}
+    for k, (o, sh) in st.table.items():
+        n = int(np.prod(sh)) if len(sh) else 1
+        v = g[o:o + n].reshape(sh)
+        fused = 'wqkv' if '.wqkv.' in k else 'wkv' if '.wkv.' in k else None
+        if fused:
+            names = ('wq', 'wk', 'wv') if fused == 'wqkv' else ('wk', 'wv')
+            d = v.shape[-1] // len(names)
+            for j, nm in enumerate(names):
+                out[k.replace(fused, nm)] = v[..., j * d:(j + 1) * d]
+        elif k.startswith('decoder_postnet.stop_linear'):
+            out[k] = v[..., :3]
+        else:
+            out[k] = v
+    return out
+
+
+def tight_compare(model, ref, tol=1e-3, tol_qk=1e-2, floor_qk=1e-4):
+    """Every tensor within tol of its largest entry; the self-attention query / key projections within tol_qk + an absolute
+    floor: when a softmax saturates (the first decoder block sees prenet outputs times sqrt(d)) their true gradient vanishes
+    and what the device returns is the rounding of delta = <dctx, ctx> against dP, ~1e-6 of quantities that are large."""
+    mine = grads_by_name(model)
+    errs = []
+    assert set(ref['grads']) == set(mine), set(ref['grads']) ^ set(mine)
+    for k, r in ref['grads'].items():
+        a = mine[k].astype(np.float64)
+        r = np.asarray(r).reshape(a.shape)
+        scale = np.abs(r).max()
+        diff = float(np.abs(a - r).max())
+        if '.sarn.mha.wq.' in k or '.sarn.mha.wk.' in k:
+            assert diff < tol_qk * scale + floor_qk, (k, diff, scale)
+            continue
+        if scale < 1e-7:
+            assert np.abs(a).max() < 1e-5, k
+            continue
+        errs.append((diff / scale, k))
+    errs.sort(reverse=True)
+    print(f'tight gradient check: worst {errs[:3]}, median {errs[len(errs) // 2][0]:.1e}')
+    assert errs[0][0] < tol, errs[:5]
+    return errs
+
+
+def reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prenet_rate, head_drop, seed):
+    """The oracle on the draws and branches of the device step that just ran."""
+    from estts import train_ops as T
+    B, N = tokens.shape
+    tar_real, tar_mel, tar_stop = mel[:, 1:], mel[:, :-1][:, 0::r], stop[:, 1:]
+    Tq = tar_mel.shape[1]
+    de, dd = cfg['encoder_model_dimension'], cfg['decoder_model_dimension']
+    seed_now = (seed * 1000003 + 0 * 7919 + 12345) & 0xFFFFFFFF
+    masks = None
+    if dropout_rate > 0:
+        shapes = [(B * N, de)]
+        for i in range(len(cfg['encoder_num_heads'])):
+            shapes += [(B * N, de)] * (2 if i < cfg['encoder_dense_blocks'] else 1)
+        shapes += [(B * Tq, dd)]
+        for i in range(len(cfg['decoder_num_heads'])):
+            shapes += [(B * Tq, dd)] * (3 if i < cfg['decoder_dense_blocks'] else 2)
+        masks = []
+        for site, sh in enumerate(shapes):
+            ones = torch.ones(*sh, device='cuda')
+            T.dropout(ones, ones, dropout_rate, seed_now, site)
+            masks.append(ones.cpu().numpy().reshape(B, -1, sh[1]))
+    pm = None
+    if prenet_rate > 0:
+        pm = []
+        for site, width in ((1000, cfg['decoder_prenet_dimension']), (1001, dd)):
+            ones = torch.ones(B * Tq, width, device='cuda')
+            T.dropout(ones, ones, prenet_rate, seed_now, site)
+            pm.append(ones.cpu().numpy().reshape(B, Tq, width))
+    head_keep = None
+    if head_drop:
+        rng = np.random.default_rng(seed_now)
+        head_keep = []
+        heads = list(cfg['encoder_num_heads'])
+        for H in cfg['decoder_num_heads']:
+            heads += [H, H]
+        for H in heads:
+            keep = np.ones((B, H))
+            for b in range(B):
+                keep[b, rng.permutation(H)[:head_drop]] = 0.0
+            head_keep.append(keep * (H / (H - head_drop)))
+    gates = [g.cpu().numpy().astype(np.float64) for g in model.gate_log]
+    return OT.autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_embed=spk, r=r, masks=masks,
+                                        head_keep=head_keep, prenet_masks=pm, gates=gates, stop_scaling=8.0)
+
+
+def check_step(system_type, r, dropout_rate=0.0, prenet_rate=0.0, head_drop=0, dense_blocks=(1, 1), seed=3, trainer=None):
+    from estts.autoregressive_training import AutoregressiveTransformerTrainer
+    cfg = small_cfg(system_type, dropout_rate, dense_blocks)
+    w = weights.init_autoregressive_transformer(cfg, seed=11)
+    tokens, mel, stop, spk = batch(cfg, 3, 13, 20, seed=5)
+    if 'speaker' not in system_type:
+        spk = None
+    model = (trainer or AutoregressiveTransformerTrainer)(w, cfg, seed=seed)
+    model._compile(stop_scaling=8.0)
+    model.set_constants(reduction_factor=r, decoder_prenet_dropout=prenet_rate, drop_n_heads=head_drop)
+    model.gate_log = []
+    out = model.train_step(mel, tokens, stop, spk, apply=False)
+    ref = reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prenet_rate, head_drop, seed)
+    assert abs(float(out['loss']) - ref['loss']) < 2e-5 * max(1.0, abs(ref['loss'])), (float(out['loss']), ref['loss'])
+    for k in ('output', 'stop_prob', 'mel_linear'):
+        assert abs(float(out['losses'][k]) - ref['losses'][k]) < 2e-5 * max(1.0, ref['losses'][k]), k
+    for k in ('final_output', 'mel_linear', 'stop_prob'):
+        assert np.abs(out[k].cpu().numpy() - ref[k]).max() < 1e-3, k
+    tight_compare(model, ref)
+    return model, ref, out
+
+
+@pytest.mark.parametrize('system_type,r', [('text', 1), ('speaker_text', 3), ('speaker_text', 2)])
+def test_train_step_gradients(system_type, r):
+    check_step(system_type, r)
+
+
+def test_train_step_with_conv_blocks_dropout_head_drop_and_prenet_dropout():
+    check_step('speaker_text', 2, dropout_rate=0.1, prenet_rate=0.5, head_drop=1, dense_blocks=(1, 1))
+
+
+def test_weights_round_trip_and_adam_step():
+    """weights() gives back what the trainer was built from; one applied step follows Keras Adam on the oracle's gradients;
+    a few more reduce the loss; the trained variables load into the inference class."""
+    from estts.autoregressive_training import AutoregressiveTransformerTrainer
+    from estts.autoregressive_transformer import AutoregressiveTransformer
+    cfg = small_cfg('speaker_text', 0.0)
+    w = weights.init_autoregressive_transformer(cfg, seed=2)
+    tokens, mel, stop, spk = batch(cfg, 2, 11, 16, seed=9)
+    model = AutoregressiveTransformerTrainer(w, cfg)
+    back = model.weights()
+    assert set(back) == set(w)
+    for k in w:
+        assert np.array_equal(np.asarray(w[k], np.float32), back[k]), k
+    model._compile(stop_scaling=8.0, optimizer={'learning_rate': 1e-3})
+    model.set_constants(reduction_factor=2)
+    model.gate_log = []
+    first = model.train_step(mel, tokens, stop, spk)
+    ref = reference_step(model, w, cfg, tokens, mel, stop, spk, 2, 0.0, 0.0, 0, 0)
+    model.gate_log = None
+    w1 = OT.adam_update(w, ref['grads'], {}, 1e-3, 1)
+    mine = model.weights()
+    checked = 0
+    for k, g in ref['grads'].items():
+        big = np.abs(g) > 0.25 * np.abs(g).max()
+        if np.abs(g).max() < 1e-7 or not big.any():
+            continue
+        assert np.abs(np.asarray(mine[k], np.float64) - w1[k])[big].max() < 2e-5, k
+        checked += 1
+    assert checked > 40
+    losses = [float(first['loss'])]
+    for _ in range(20):
+        losses.append(float(model.train_step(mel, tokens, stop, spk)['loss']))
+    assert model.step == 21 and losses[-1] < 0.8 * losses[0], losses
+    infer = AutoregressiveTransformer(model.weights(), cfg)
+    infer._compile(stop_scaling=8.0)
+    infer.set_constants(reduction_factor=2)
+    val = infer.val_step(tokens, mel, stop, spk)
+    assert np.isfinite(float(val['tts_loss']))
