@@ -21,6 +21,7 @@ import torch
 from . import ops, parallel, train_ops as T
 from .forward_training import (ForwardTransformerTrainer, ParamStore, _CnnResNorm, _Ffn, _Layer, _Norm, _Sarn)
 from .train_ops import TrainLinear
+from .ops import same_pad
 from .weights import encoder_output_dim
 
 
@@ -40,6 +41,48 @@ class _Carn:
 
     def linears(self):
         return [self.wq.lin, self.wkv.lin, self.wo.lin, self.wo_x, self.wo_c]
+
+
+def gru_gate_swap(a):
+    """[..., 3u] with gate blocks [z | r | h] <-> [r | z | n]."""
+    u = a.shape[-1] // 3
+    return np.concatenate([a[..., u:2 * u], a[..., :u], a[..., 2 * u:]], axis=-1)
+
+
+class _Gst:
+    """ReferenceEncoderGST (layers.py:526-585): the layers of its training pass."""
+
+    def __init__(self, store, p, cfg):
+        n = len(cfg['ref_encoder_filters'])
+        self.stride = cfg['ref_encoder_strides']
+        if cfg['ref_encoder_kernel_size'] != 3:
+            raise NotImplementedError('reference encoder kernels other than 3x3')
+        self.convs = [_Layer(store, f'{p}.conv{i}', need_bwd=i > 0) for i in range(n)]
+        self.norms = [_Norm(store, f'{p}.norm{i}', True) for i in range(n)]
+        self.u = cfg['ref_encoder_gru_cell_units']
+        self.sd, self.H = cfg['gst_style_embed_dim'], cfg['gst_multi_num_heads']
+        self.gru_ih = _bias_layer(store, p + '.gru.kernel', p + '.gru.bias_i')
+        self.gru_hh = _bias_layer(store, p + '.gru.recurrent_kernel', p + '.gru.bias_h')
+        self.rnn_proj = _Layer(store, p + '.rnn_proj', act='tanh')
+        self.wq = _Layer(store, p + '.mha.wq')
+        self.wkv = _Layer(store, p + '.mha.wkv')
+        self.wo = _Layer(store, p + '.mha.dense')
+        self.tokens, self.dtokens = store.p[p + '.gst_tokens'], store.g[p + '.gst_tokens']
+
+    def linears(self):
+        return [c.lin for c in self.convs] + [self.gru_ih.lin, self.gru_hh.lin, self.rnn_proj.lin, self.wq.lin, self.wkv.lin,
+                                              self.wo.lin]
+
+
+def _bias_layer(store, kernel_name, bias_name):
+    """A dense layer whose kernel and bias have names of their own (the two halves of the Keras GRU bias)."""
+    class _L:
+        pass
+    L = _L()
+    L.lin = TrainLinear(store.p[kernel_name], store.p[bias_name])
+    L.dk, L.db = store.g[kernel_name], store.g[bias_name]
+    L.taps, L.lpad, L.N, L.K = 1, 0, L.lin.N, L.lin.K
+    return L
 
 
 def _register_autoregressive_params(store, w, cfg, shapes):
@@ -104,6 +147,30 @@ def _register_autoregressive_params(store, w, cfg, shapes):
         b = f'text_encoder.block{i}'
         sarn(b + '.sarn')
         tail(b, i < cfg['encoder_dense_blocks'])
+    if cfg['system_type'] in ('speaker_style_text', 'style_text'):
+        p = 'style_encoder'
+        for i in range(len(cfg['ref_encoder_filters'])):
+            k = np.asarray(w[f'{p}.conv{i}.kernel'])                    # (3, 3, cin, cout)
+            shapes[f'{p}.conv{i}.kernel'] = k.shape
+            rows = k.shape[0] * k.shape[1] * k.shape[2]
+            k2 = np.zeros(((rows + 3) // 4 * 4, k.shape[3]), np.float32)    # rows padded to a multiple of 4 (cin = 1 gives 9)
+            k2[:rows] = k.reshape(rows, k.shape[3])
+            add(f'{p}.conv{i}.kernel', k2)
+            add(f'{p}.conv{i}.bias', w[f'{p}.conv{i}.bias'])
+            norm(f'{p}.norm{i}', True)
+        # Keras gate order [z | r | h] -> the kernels' [r | z | n] (swapping the first two blocks; the swap undoes itself)
+        add(p + '.gru.kernel', gru_gate_swap(np.asarray(w[p + '.gru.kernel'])))
+        add(p + '.gru.recurrent_kernel', gru_gate_swap(np.asarray(w[p + '.gru.recurrent_kernel'])))
+        bias = gru_gate_swap(np.asarray(w[p + '.gru.bias']))
+        add(p + '.gru.bias_i', bias[0])
+        add(p + '.gru.bias_h', bias[1])
+        dense(p + '.rnn_proj')
+        m = p + '.mha'
+        dense(m + '.wq')
+        add(m + '.wkv.kernel', np.concatenate([w[m + '.wk.kernel'], w[m + '.wv.kernel']], axis=1))
+        add(m + '.wkv.bias', np.concatenate([w[m + '.wk.bias'], w[m + '.wv.bias']]))
+        dense(m + '.dense')
+        add(p + '.gst_tokens', w[p + '.gst_tokens'])
     dense('decoder_prenet.d1')
     dense('decoder_prenet.d2')
     for i in range(len(cfg['decoder_num_heads'])):
@@ -129,8 +196,6 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         self._init_common(config, device, precision, seed, process_group, bucket_mb)
         cfg, dev = self.config, self.device
         self.system_type = cfg['system_type']
-        if self.system_type in ('speaker_style_text', 'style_text'):
-            raise NotImplementedError("training the style systems runs through StyleTrainer (system types with a reference encoder)")
         self.max_r = int(cfg['max_r'])
         self.r = self.max_r
         self.loss_weights = [1., 1., 1.]
@@ -161,6 +226,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         nd = cfg['decoder_dense_blocks']
         self.dec_names = [f'Decoder_DenseBlock{i + 1}_CrossAttention' if i < nd else f'Decoder_ConvBlock{i - nd + 1}_CrossAttention'
                           for i in range(len(cfg['decoder_num_heads']))]
+        self.gst = _Gst(st, 'style_encoder', cfg) if self.system_type in ('speaker_style_text', 'style_text') else None
         self.prenet1 = _Layer(st, 'decoder_prenet.d1', act='relu')
         self.prenet2 = _Layer(st, 'decoder_prenet.d2', act='relu')
         self.stop = _Layer(st, 'decoder_postnet.stop_linear')
@@ -175,6 +241,8 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         for S, C, tail in self.dec_blocks:
             self._base_linears += S.linears() + C.linears() + tail.linears()
         self._base_linears += [self.prenet1.lin, self.prenet2.lin, self.stop.lin] + self.postnet.linears()
+        if self.gst is not None:
+            self._base_linears += self.gst.linears()
         self._linears = list(self._base_linears)
 
     # ------------------------------------------------------------------ reference surface
@@ -220,7 +288,18 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
 
     def weights(self):
         """Current variables as a dict name -> ndarray in the layouts of weights.py."""
-        raw, out = self.store.numpy(), {}
+        out = self._named(self.store.numpy())
+        for k, s in self._pos_scalars.items():
+            out[k + '.pos_encoding_scalar'] = np.array(s, np.float32)
+        return out
+
+    def gradients(self):
+        """The gradients of the last step under the same names and layouts as weights() (tests, logging)."""
+        out = self._named(self.store.numpy(self.store.grad))
+        return {k: v for k, v in out.items() if not k.endswith(('moving_mean', 'moving_variance'))}
+
+    def _named(self, raw):
+        out = {}
         for k, v in raw.items():
             if k.endswith('.mha.wqkv.kernel') or k.endswith('.mha.wkv.kernel'):
                 names = ('wq', 'wk', 'wv') if 'wqkv' in k else ('wk', 'wv')
@@ -232,6 +311,15 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 d = v.shape[0] // len(names)
                 for j, n in enumerate(names):
                     out[k.replace('wqkv' if 'wqkv' in k else 'wkv', n)] = v[j * d:(j + 1) * d].copy()
+            elif k.startswith('style_encoder.conv') and k.endswith('.kernel'):
+                sh = self._orig_shapes[k]
+                out[k] = v[:sh[0] * sh[1] * sh[2]].reshape(sh)
+            elif k in ('style_encoder.gru.kernel', 'style_encoder.gru.recurrent_kernel'):
+                out[k] = gru_gate_swap(v)
+            elif k == 'style_encoder.gru.bias_i':
+                out['style_encoder.gru.bias'] = gru_gate_swap(np.stack([v, raw['style_encoder.gru.bias_h']]))
+            elif k == 'style_encoder.gru.bias_h':
+                pass
             elif k == 'decoder_postnet.stop_linear.kernel':
                 out[k] = v[:, :3].copy()
             elif k == 'decoder_postnet.stop_linear.bias':
@@ -240,8 +328,6 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 out[k] = v.reshape(self._orig_shapes[k])
             else:
                 out[k] = v
-        for k, s in self._pos_scalars.items():
-            out[k + '.pos_encoding_scalar'] = np.array(s, np.float32)
         return out
 
     # ------------------------------------------------------------------ layer passes
@@ -293,6 +379,125 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
 
         tape.append(backward)
         return attn
+
+    def _gst_fwd(self, x, B, Tq, tape):
+        """ReferenceEncoderGST.call(training=True) (layers.py:561-585) on x [B, Tq, mel] -> (style embedding [B, sd],
+        attention [B, heads, 1, tokens]); appends ONE closure to `tape` that takes the gradient of the embedding.
+        Every Conv2D runs as patches (estts_im2col) times a dense kernel, which its two gradients need anyway."""
+        G, s = self.gst, self.gst.stride
+        y, H, W, Cin = x.contiguous(), Tq, self.mel_channels, 1
+        saved = []
+        for conv, norm in zip(G.convs, G.norms):
+            Ho, pt = same_pad(H, 3, s)
+            Wo, pl = same_pad(W, 3, s)
+            M = B * Ho * Wo
+            patches = self._empty(M, conv.K)
+            T.im2col(y, patches, B, H, W, Cin, Ho, Wo, 3, s, pt, pl)
+            z = self._empty(M, conv.N)
+            self._lin_fwd(patches, conv, z, M)
+            st = self._bn_train(z, norm, M, conv.N)
+            nxt = self._empty(M, conv.N)
+            T.affine_act(z, nxt, st[2], st[3], 'relu', M=M, C=conv.N)
+            if self.gate_log is not None:
+                self.gate_log.append(nxt > 0)
+            saved.append((patches, z, st, (H, W, Cin, Ho, Wo, pt, pl)))
+            y, H, W, Cin = nxt, Ho, Wo, conv.N
+        steps, feat, u, sd, Hh = H, W * Cin, G.u, G.sd, G.H
+        Ms = B * steps
+        seq = y.view(Ms, feat)                                   # rows (b, t); features (w, c) as Keras' reshape gives them
+        gi = self._empty(Ms, 3 * u)
+        self._lin_fwd(seq, G.gru_ih, gi, Ms)
+        gi3 = gi.view(B, steps, 3 * u)
+        hs = self._empty(steps + 1, B, u)
+        hs[0].zero_()
+        ghs = self._empty(steps, B, 3 * u)
+        for t in range(steps):
+            self._lin_fwd(hs[t], G.gru_hh, ghs[t], B)
+            T.gru_step_fwd(gi3[:, t], ghs[t], hs[t], hs[t + 1])
+        cat = self._empty(B, u + sd)
+        proj, ctx = cat[:, :u], cat[:, u:]
+        self._lin_fwd(hs[steps], G.rnn_proj, proj, B)
+        q = self._empty(B, sd)
+        self._lin_fwd(proj, G.wq, q, B)
+        n_tok, tokdim = G.tokens.shape
+        tok_t = self._empty(n_tok, tokdim)
+        T.affine_act(G.tokens, tok_t, None, None, 'tanh', M=n_tok, C=tokdim)
+        kv = self._empty(n_tok, 2 * sd)
+        self._lin_fwd(tok_t, G.wkv, kv, n_tok)
+        kvb = kv[None].expand(B, n_tok, 2 * sd).contiguous().view(B * n_tok, 2 * sd)     # every sample attends to the same tokens
+        attn = self._empty(B, Hh, 1, n_tok)
+        ops.attention(q, kvb[:, :sd], kvb[:, sd:], ctx, B, Hh, 1, n_tok, sd // Hh, attn=attn, precision=self.precision)
+        hscale = hinv = None
+        if self.drop_n_heads > 0 and Hh > 1:
+            keep = np.ones((B, Hh), np.float32)
+            for b in range(B):
+                keep[b, self._host_rng.permutation(Hh)[:self.drop_n_heads]] = 0.0
+            sc = Hh / (Hh - self.drop_n_heads)
+            hscale = torch.from_numpy(keep * sc).to(self.device).view(-1)
+            hinv = torch.from_numpy(keep / sc).to(self.device).view(-1)
+            T.head_scale(ctx, hscale, B, 1, Hh, sd // Hh)
+        out = self._empty(B, sd)
+        self._lin_fwd(cat, G.wo, out, B)
+
+        def backward(d_out):
+            dcat = self._empty(B, u + sd)
+            self._lin_bwd(cat, G.wo, d_out, B, dx=dcat)
+            dproj, dctx = dcat[:, :u], dcat[:, u:]
+            ctx_b = ctx
+            if hscale is not None:
+                ctx_b = ctx.clone()
+                T.head_scale(ctx_b, hinv, B, 1, Hh, sd // Hh)
+                T.head_scale(dctx, hscale, B, 1, Hh, sd // Hh)
+            delta = self._empty(B * Hh)
+            dq, dkvb = self._empty(B, sd), self._empty(B * n_tok, 2 * sd)
+            T.attention_bwd(q, kvb[:, :sd], kvb[:, sd:], ctx_b, dctx, attn, delta, dq, dkvb[:, :sd], dkvb[:, sd:], B, Hh, 1, n_tok,
+                            sd // Hh, precision=self.precision)
+            dkv = torch.zeros(n_tok * 2 * sd, dtype=torch.float32, device=self.device)
+            T.colreduce(1, dkv, g=dkvb.view(B, n_tok * 2 * sd), M=B, C=n_tok * 2 * sd)      # the tokens are shared: sum over the batch
+            dtok_t = self._empty(n_tok, tokdim)
+            self._lin_bwd(tok_t, G.wkv, dkv.view(n_tok, 2 * sd), n_tok, dx=dtok_t)
+            unused = torch.zeros(tokdim, dtype=torch.float32, device=self.device)
+            T.colreduce(1, unused, g=dtok_t, a=tok_t, act='tanh', dy_out=G.dtokens, M=n_tok, C=tokdim)
+            self._lin_bwd(proj, G.wq, dq, B, dx=dproj, accumulate=True)
+            dpre = self._empty(B, u)
+            T.colreduce(1, G.rnn_proj.db, g=dproj, a=proj, act='tanh', dy_out=dpre, M=B, C=u)
+            T.wgrad(hs[steps], dpre, G.rnn_proj.dk, M=B, precision=self.precision)
+            dh = self._empty(B, u)
+            ops.gemm(dpre, G.rnn_proj.lin.bwd, dh, M=B, precision=self.precision)
+            # GRU through time: only the last state feeds the output
+            dgi = self._empty(B, steps, 3 * u)
+            dgh = self._empty(steps, B, 3 * u)
+            zero = torch.zeros(B, u, dtype=torch.float32, device=self.device)
+            rec = None
+            for t in reversed(range(steps)):
+                dprev = self._empty(B, u)
+                T.gru_step_bwd(gi3[:, t], ghs[t], hs[t], dh if t == steps - 1 else zero, rec, dgi[:, t], dgh[t], dprev)
+                ops.gemm(dgh[t], G.gru_hh.lin.bwd, dprev, M=B, precision=self.precision, residual=dprev)
+                rec = dprev
+            T.wgrad(hs[:steps].view(steps * B, u), dgh.view(steps * B, 3 * u), G.gru_hh.dk, M=steps * B, precision=self.precision,
+                    db=G.gru_hh.db)
+            dseq = self._empty(Ms, feat)
+            self._lin_bwd(seq, G.gru_ih, dgi.view(Ms, 3 * u), Ms, dx=dseq)
+            g = dseq                                             # NHWC gradient of the last convolution's output
+            for i in reversed(range(len(G.convs))):
+                conv, norm = G.convs[i], G.norms[i]
+                patches, z, st, (Hi, Wi, Ci, Ho, Wo, pt, pl) = saved[i]
+                M = B * Ho * Wo
+                dz = self._empty(M, conv.N)
+                T.colreduce(2, norm.dbeta, norm.dgamma, z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz,
+                            M=M, C=conv.N, scale=st[2], shift=st[3])
+                T.bn_bwd(dz, z, st[0], st[1], norm.gamma, norm.dgamma, norm.dbeta, dz, M=M, C=conv.N)
+                if i == 0:
+                    self._lin_bwd(patches, conv, dz, M)
+                else:
+                    dp = self._empty(M, conv.K)
+                    self._lin_bwd(patches, conv, dz, M, dx=dp)
+                    g = self._empty(B * Hi * Wi, Ci)
+                    T.col2im(dp, g, B, Hi, Wi, Ci, Ho, Wo, 3, s, pt, pl)
+            return None
+
+        tape.append(backward)
+        return out, attn
 
     # ------------------------------------------------------------------ the training step
     def _encode(self, tokens, B, N, tape, enc_attn):
@@ -346,11 +551,18 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         text_out, _ = self._encode(tokens, B, N, enc_tape, enc_attn)
         enc = self._empty(Me, self.enc_dim)
         enc[:, :de].copy_(text_out)
+        gst_tape, gst_out, gst_attn, sd = [], None, None, 0
+        if self.gst is not None:
+            if not train_style_encoder:
+                raise NotImplementedError('sub-networks in inference mode inside a training step are not implemented')
+            gst_out, gst_attn = self._gst_fwd(tar_mel, B, Tq, gst_tape)
+            sd = self.gst.sd
+            enc.view(B, N, self.enc_dim)[:, :, de:de + sd].copy_(gst_out[:, None, :].expand(B, N, sd))
         if self.system_type in ('speaker_style_text', 'speaker_text'):
             spk = torch.as_tensor(tts_speaker, dtype=torch.float32, device=dev).reshape(B, 1, -1)
-            if spk.shape[2] != self.enc_dim - de:
-                raise ValueError(f'speaker embedding has {spk.shape[2]} values, the model expects {self.enc_dim - de}')
-            enc.view(B, N, self.enc_dim)[:, :, de:].copy_(spk.expand(B, N, spk.shape[2]))
+            if spk.shape[2] != self.enc_dim - de - sd:
+                raise ValueError(f'speaker embedding has {spk.shape[2]} values, the model expects {self.enc_dim - de - sd}')
+            enc.view(B, N, self.enc_dim)[:, :, de + sd:].copy_(spk.expand(B, N, spk.shape[2]))
         enc_mask = self._empty(B, N)
         ops.row_zero_mask(enc, enc_mask.view(-1))
         d_enc = torch.zeros(Me, self.enc_dim, dtype=torch.float32, device=dev)
@@ -455,6 +667,12 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         for bw in reversed(dec_tape):
             g = bw(g)
         prenet_backward(g)
+        if self.gst is not None:           # the style embedding was tiled over the tokens: its gradient is the sum over them
+            d_gst = torch.zeros(B, sd, dtype=torch.float32, device=dev)
+            d_enc3 = d_enc.view(B, N, self.enc_dim)
+            for b in range(B):
+                T.colreduce(1, d_gst[b], g=d_enc3[b][:, de:de + sd], M=N, C=sd)
+            gst_tape[0](d_gst)
         g = d_enc[:, :de].contiguous()
         for bw in reversed(enc_tape):
             g = bw(g)
@@ -464,7 +682,8 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             self._apply_gradients()
         return {'final_output': final.view(B, Tt, C), 'mel_linear': mel.view(B, Tt, C), 'stop_prob': stop4.view(B, Tt, 4)[:, :, :3],
                 'decoder_attention': dec_attn, 'text_encoder_attention': enc_attn, 'text_enc_output': text_out.reshape(B, N, de),
-                'gst_output': None, 'decoder_output': dec_out.reshape(B, Tq, dd), 'linear': mel.view(B, Tt, C),
+                'gst_output': None if gst_out is None else gst_out.view(B, 1, sd),
+                'gst_encoder_attention': None if gst_attn is None else {'RefEncoderGST_attention': gst_attn}, 'decoder_output': dec_out.reshape(B, Tq, dd), 'linear': mel.view(B, Tt, C),
                 'tts_loss': tts_loss, 'style_loss': 0, 'loss': tts_loss,
                 'losses': {'output': loss_vals[0], 'stop_prob': loss_vals[1], 'mel_linear': loss_vals[2]},
                 'reduced_target': tar_mel}

@@ -670,6 +670,83 @@ extern "C" int estts_axpby(const float* x, int32_t ldx, float alpha, float* out,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Patches of a 2-D convolution over NHWC images (training of the GST reference encoder: the weight gradient and the data
+// gradient of Conv2D become a dense wgrad / GEMM over these rows).  One thread per patch value / per input value.
+// ------------------------------------------------------------------------------------------------------
+__global__ void im2col_kernel(const float* __restrict__ x, float* __restrict__ out, int ldo, int B, int H, int W, int C, int Ho,
+                              int Wo, int kh_n, int kw_n, int stride, int pad_t, int pad_l) {
+    const long K = (long)kh_n * kw_n * C;
+    const long total = (long)B * Ho * Wo * ldo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / ldo;
+        const int col = (int)(i - m * ldo);
+        float v = 0.0f;
+        if (col < K) {
+            const int c = col % C, tap = col / C;
+            const int kw = tap % kw_n, kh = tap / kw_n;
+            const int wo = (int)(m % Wo);
+            const long t = m / Wo;
+            const int ho = (int)(t % Ho), b = (int)(t / Ho);
+            const int h = ho * stride + kh - pad_t, w = wo * stride + kw - pad_l;
+            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = x[(((long)b * H + h) * W + w) * C + c];
+        }
+        out[i] = v;
+    }
+}
+
+// gather form of the transposed scatter: every input value sums the patch entries it was copied to (no atomics)
+__global__ void col2im_kernel(const float* __restrict__ dp, int ldp, float* __restrict__ dx, int B, int H, int W, int C, int Ho,
+                              int Wo, int kh_n, int kw_n, int stride, int pad_t, int pad_l) {
+    const long total = (long)B * H * W * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H), b = (int)(t / H);
+        float acc = 0.0f;
+        for (int kh = 0; kh < kh_n; ++kh) {
+            const int hn = h + pad_t - kh;
+            if (hn < 0 || hn % stride) continue;
+            const int ho = hn / stride;
+            if (ho >= Ho) continue;
+            for (int kw = 0; kw < kw_n; ++kw) {
+                const int wn = w + pad_l - kw;
+                if (wn < 0 || wn % stride) continue;
+                const int wo = wn / stride;
+                if (wo >= Wo) continue;
+                acc += dp[(((long)b * Ho + ho) * Wo + wo) * ldp + (kh * kw_n + kw) * C + c];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+extern "C" int estts_im2col(const float* x, float* out, int32_t ldo, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho,
+                            int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad_t, int32_t pad_l, void* stream) {
+    ESTTS_CHECK_ARG(x && out && B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && kh > 0 && kw > 0 && stride > 0 &&
+                        pad_t >= 0 && pad_l >= 0 && ldo >= kh * kw * C,
+                    "estts_im2col: bad arguments");
+    ESTTS_CHECK_ARG((Ho - 1) * stride + kh - pad_t <= H + kh - 1 && (Wo - 1) * stride + kw - pad_l <= W + kw - 1,
+                    "estts_im2col: output size does not fit the padded input");
+    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid((long)B * Ho * Wo * ldo)), dim3(256), 0, (hipStream_t)stream, x, out, ldo, B, H,
+                       W, C, Ho, Wo, kh, kw, stride, pad_t, pad_l);
+    ESTTS_CHECK_LAUNCH("estts_im2col");
+    return 0;
+}
+
+extern "C" int estts_col2im(const float* dp, int32_t ldp, float* dx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho,
+                            int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad_t, int32_t pad_l, void* stream) {
+    ESTTS_CHECK_ARG(dp && dx && B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && kh > 0 && kw > 0 && stride > 0 &&
+                        pad_t >= 0 && pad_l >= 0 && ldp >= kh * kw * C,
+                    "estts_col2im: bad arguments");
+    hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dp, ldp, dx, B, H, W,
+                       C, Ho, Wo, kh, kw, stride, pad_t, pad_l);
+    ESTTS_CHECK_LAUNCH("estts_col2im");
+    return 0;
+}
+
 extern "C" int estts_head_scale(float* x, int32_t ldx, const float* scale, int32_t B, int32_t L, int32_t H, int32_t depth,
                                 void* stream) {
     ESTTS_CHECK_ARG(x && scale && B > 0 && L > 0 && H > 0 && depth > 0 && (depth & 3) == 0 && (ldx & 3) == 0 && ldx >= H * depth,

@@ -217,6 +217,20 @@ def head_scale(x, scale, B, L, H, depth):
     return x
 
 
+def im2col(x, out, B, H, W, C, Ho, Wo, k, stride, pad_t, pad_l):
+    """x: NHWC [B, H, W, C] contiguous -> out [B * Ho * Wo, >= k * k * C] patches (estts_im2col)."""
+    check(_lib.load().estts_im2col(x.data_ptr(), out.data_ptr(), out.stride(0), B, H, W, C, Ho, Wo, k, k, stride, pad_t, pad_l,
+                                   _stream()), 'estts_im2col')
+    return out
+
+
+def col2im(dp, dx, B, H, W, C, Ho, Wo, k, stride, pad_t, pad_l):
+    """dp [B * Ho * Wo, >= k * k * C] patch gradients -> dx NHWC [B, H, W, C] contiguous (estts_col2im)."""
+    check(_lib.load().estts_col2im(dp.data_ptr(), dp.stride(0), dx.data_ptr(), B, H, W, C, Ho, Wo, k, k, stride, pad_t, pad_l,
+                                   _stream()), 'estts_col2im')
+    return dx
+
+
 def embed_bwd(tokens, dx, demb, scale):
     B, N = tokens.shape
     check(_lib.load().estts_embed_bwd(tokens.data_ptr(), dx.data_ptr(), dx.stride(0), demb.data_ptr(), B, N, demb.shape[1], scale,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 21
+#define ESTTS_ABI_VERSION 22
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -515,6 +515,18 @@ int estts_dropout(const float* x, int32_t ldx, float* out, int32_t ldo, int32_t 
 /* out[m, c] = beta * out[m, c] + alpha * x[m, c]   (gradient accumulation on residual paths) */
 int estts_axpby(const float* x, int32_t ldx, float alpha, float* out, int32_t ldo, float beta, int32_t M, int32_t D,
                 void* stream);
+
+/* Patches of a 2-D convolution over an NHWC image x [B, H, W, C] (TensorFlow 'SAME' geometry: pad_t / pad_l on the low
+ * side): out[(b, ho, wo), (kh_i * kw + kw_i) * C + c] = x[b, ho * stride + kh_i - pad_t, wo * stride + kw_i - pad_l, c], zero
+ * outside the image; columns from kh * kw * C up to ldo are zeroed too (K rounded up for estts_gemm).
+ * estts_col2im is its transpose: dx[b, h, w, c] = the sum of the patch entries that value was copied to.
+ * With them the gradients of Conv2D(3 x 3, stride 2, 'same') in ReferenceEncoderGST.call_convs (TransformerTTS/model/layers.py:554-559)
+ * are estts_gemm_wgrad(patches, dZ) and estts_col2im(estts_gemm(dZ, W^T)); the reference gets them from tf.GradientTape
+ * (model/traning_steps.py:54). */
+int estts_im2col(const float* x, float* out, int32_t ldo, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                 int32_t kh, int32_t kw, int32_t stride, int32_t pad_t, int32_t pad_l, void* stream);
+int estts_col2im(const float* dp, int32_t ldp, float* dx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
+                 int32_t kh, int32_t kw, int32_t stride, int32_t pad_t, int32_t pad_l, void* stream);
 
 /* Per-(batch, head) scaling of the attention context (HeadDrop, layers.py:74-97): x[b*L + t, h*depth + f] *= scale[b*H + h]. */
 int estts_head_scale(float* x, int32_t ldx, const float* scale, int32_t B, int32_t L, int32_t H, int32_t depth, void* stream);

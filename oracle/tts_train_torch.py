@@ -224,8 +224,7 @@ def _gst_train(x, w, p, n_convs, stride, H, c):
     y = x[:, None, :, :]
     for i in range(n_convs):
         y = _conv2d_same_s2(y, w[f'{p}.conv{i}.kernel'], w[f'{p}.conv{i}.bias'], stride)       # (B, C, H, W)
-        y = _bn_train_nd(y.permute(0, 2, 3, 1), w, f'{p}.norm{i}', c, (0, 1, 2)).permute(0, 3, 1, 2)
-        y = c.relu(y)
+        y = c.relu(_bn_train_nd(y.permute(0, 2, 3, 1), w, f'{p}.norm{i}', c, (0, 1, 2))).permute(0, 3, 1, 2)   # (gates are NHWC)
     y = y.permute(0, 2, 3, 1).reshape(B, y.shape[2], -1)
     u = w[p + '.gru.recurrent_kernel'].shape[0]
     h = torch.zeros(B, u, dtype=y.dtype)

@@ -49,24 +49,8 @@ def batch(cfg, B, N, T, seed):
 
 
 def grads_by_name(model):
-    """Device gradients under the oracle's names (fused projections split, conv kernels reshaped, stop head un-padded)."""
-    st = model.store
-    g = st.grad.cpu().numpy()
-    out = {}
-    for k, (o, sh) in st.table.items():
-        n = int(np.prod(sh)) if len(sh) else 1
-        v = g[o:o + n].reshape(sh)
-        fused = 'wqkv' if '.wqkv.' in k else 'wkv' if '.wkv.' in k else None
-        if fused:
-            names = ('wq', 'wk', 'wv') if fused == 'wqkv' else ('wk', 'wv')
-            d = v.shape[-1] // len(names)
-            for j, nm in enumerate(names):
-                out[k.replace(fused, nm)] = v[..., j * d:(j + 1) * d]
-        elif k.startswith('decoder_postnet.stop_linear'):
-            out[k] = v[..., :3]
-        else:
-            out[k] = v
-    return out
+    """Device gradients under the oracle's names and layouts."""
+    return model.gradients()
 
 
 def tight_compare(model, ref, tol=1e-3, tol_qk=1e-2, floor_qk=1e-4):
@@ -127,6 +111,8 @@ def reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prene
         rng = np.random.default_rng(seed_now)
         head_keep = []
         heads = list(cfg['encoder_num_heads'])
+        if 'style' in cfg['system_type']:
+            heads.append(cfg['gst_multi_num_heads'])
         for H in cfg['decoder_num_heads']:
             heads += [H, H]
         for H in heads:
@@ -161,13 +147,23 @@ def check_step(system_type, r, dropout_rate=0.0, prenet_rate=0.0, head_drop=0, d
     return model, ref, out
 
 
-@pytest.mark.parametrize('system_type,r', [('text', 1), ('speaker_text', 3), ('speaker_text', 2)])
+@pytest.mark.parametrize('system_type,r', [('text', 1), ('speaker_text', 3), ('speaker_text', 2), ('style_text', 1),
+                                           ('speaker_style_text', 2)])
 def test_train_step_gradients(system_type, r):
     check_step(system_type, r)
 
 
 def test_train_step_with_conv_blocks_dropout_head_drop_and_prenet_dropout():
     check_step('speaker_text', 2, dropout_rate=0.1, prenet_rate=0.5, head_drop=1, dense_blocks=(1, 1))
+
+
+def test_style_system_with_dropout_and_head_drop():
+    """The reference encoder's own attention drops heads too (layers.py:577-578)."""
+    model, ref, out = check_step('speaker_style_text', 1, dropout_rate=0.1, prenet_rate=0.25, head_drop=1)
+    assert np.abs(out['gst_output'].cpu().numpy() - ref['gst_output']).max() < 1e-4
+    state = model.store.numpy()
+    for k, v in ref['new_stats'].items():
+        assert np.abs(state[k] - v).max() < 1e-4 * max(1.0, np.abs(v).max()), k
 
 
 def test_weights_round_trip_and_adam_step():
