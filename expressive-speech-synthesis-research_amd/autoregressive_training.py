@@ -688,5 +688,24 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 'losses': {'output': loss_vals[0], 'stop_prob': loss_vals[1], 'mel_linear': loss_vals[2]},
                 'reduced_target': tar_mel}
 
+    def encode(self, phonemes, reduced_mel, speaker=None):
+        """call_encoder in training mode without gradients (train_models_step's separate batch for the mutual-information
+        heads, traning_steps.py:62-68): -> (gst_output [B, 1, sd] or None, text_enc_output [B, N, de])."""
+        dev = self.device
+        tokens = torch.as_tensor(phonemes, device=dev).to(torch.int32).contiguous()
+        B, N = tokens.shape
+        self._site = 0
+        self._seed_now = (self.seed * 1000003 + self.iterations * 7919 + 54321 + self.rank * 0x9E3779B1) & 0xFFFFFFFF
+        self._host_rng = np.random.default_rng(self._seed_now)
+        log, self.gate_log = self.gate_log, None
+        text_out, _ = self._encode(tokens, B, N, [], {})
+        gst_out = None
+        if self.gst is not None:
+            mel = torch.as_tensor(reduced_mel, dtype=torch.float32, device=dev).contiguous()
+            gst_out, _ = self._gst_fwd(mel, B, mel.shape[1], [])
+            gst_out = gst_out.view(B, 1, -1)
+        self.gate_log = log
+        return gst_out, text_out.reshape(B, N, self.de)
+
     def val_step(self, *a, **kw):
         raise NotImplementedError('validation runs through AutoregressiveTransformer.val_step on weights()')

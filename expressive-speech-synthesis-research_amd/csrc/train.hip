@@ -747,6 +747,146 @@ extern "C" int estts_col2im(const float* dp, int32_t ldp, float* dx, int32_t B, 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Mutual-information estimators over the scores of one batch (a few hundred values at most): one workgroup.
+// ------------------------------------------------------------------------------------------------------
+constexpr int MI_THREADS = 256;
+
+__device__ float mi_block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int w = 0; w < MI_THREADS / 64; ++w) t += red[w];
+    return t;
+}
+
+__device__ float mi_block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int w = 1; w < MI_THREADS / 64; ++w) t = fmaxf(t, red[w]);
+    return t;
+}
+
+// log(s * mean(exp(a x - max(a x))) + (1 - s) * prev) + max(a x) with its gradient coef * d/dx added to g:
+// d/dx_i = a * [ (s / E) * exp(a x_i - mx) / n + [i == argmax] * (1 - s * e / E) ]   (the maximum carries gradient too, as
+// tf.reduce_max does; with s = 1 that part vanishes).  Returns the value; *e_out receives E.
+__device__ float mi_smoothed_lme(const float* x, int n, float a, float s, float prev, float coef, float* g, float* red, float* e_out) {
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += MI_THREADS) mx = fmaxf(mx, a * x[i]);
+    mx = mi_block_max(mx, red);
+    float e = 0.0f;
+    for (int i = threadIdx.x; i < n; i += MI_THREADS) e += __expf(a * x[i] - mx);
+    e = mi_block_sum(e, red) / n;
+    const float E = s * e + (1.0f - s) * prev;
+    // the first index that attains the maximum takes its gradient
+    int arg = n;
+    for (int i = threadIdx.x; i < n; i += MI_THREADS)
+        if (a * x[i] == mx) { arg = i; break; }
+    arg = -(int)mi_block_max(-(float)arg, red);
+    for (int i = threadIdx.x; i < n; i += MI_THREADS) {
+        float d = (s / E) * __expf(a * x[i] - mx) / n;
+        if (i == arg) d += 1.0f - s * e / E;
+        g[i] += coef * a * d;
+    }
+    *e_out = E;
+    return logf(E) + mx;
+}
+
+// MINE.measure_mi (TransformerTTS/model/MINE.py:40-95).  out[0] = mi, d_joint / d_marginal = gscale * d mi / d score.
+__global__ __launch_bounds__(MI_THREADS) void mine_divergence_kernel(const float* __restrict__ joint, const float* __restrict__ marginal,
+                                                                     int n, int div_type, const float* __restrict__ betas, int n_beta,
+                                                                     float s, const float* __restrict__ prev, float* __restrict__ next,
+                                                                     float* __restrict__ out, float* __restrict__ dj,
+                                                                     float* __restrict__ dm, float gscale) {
+    __shared__ float red[MI_THREADS / 64];
+    for (int i = threadIdx.x; i < n; i += MI_THREADS) { dj[i] = 0.0f; dm[i] = 0.0f; }
+    __syncthreads();
+    float mean_j = 0.0f, mean_m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += MI_THREADS) { mean_j += joint[i]; mean_m += marginal[i]; }
+    mean_j = mi_block_sum(mean_j, red) / n;
+    mean_m = mi_block_sum(mean_m, red) / n;
+    float loss = 0.0f;
+    if (div_type == 0) {   // KL: mean(joint) - log(smoothed mean(exp(marginal))), no maximum taken out (MINE.py:46-55)
+        float e = 0.0f;
+        for (int i = threadIdx.x; i < n; i += MI_THREADS) e += __expf(marginal[i]);
+        e = mi_block_sum(e, red) / n;
+        const float E = s * e + (1.0f - s) * prev[1];
+        for (int i = threadIdx.x; i < n; i += MI_THREADS) {
+            dj[i] += gscale / n;
+            dm[i] -= gscale * (s / E) * __expf(marginal[i]) / n;
+        }
+        loss = mean_j - logf(E);
+        if (threadIdx.x == 0) { next[0] = 0.0f; next[1] = E; }
+    } else {               // Renyi divergences, one term per beta (MINE.py:56-93)
+        for (int b = 0; b < n_beta; ++b) {
+            const float beta = betas[b];
+            float term1, term2, e1 = 0.0f, e2 = 0.0f;
+            if (beta == 0.0f) {
+                term1 = mean_j;
+                for (int i = threadIdx.x; i < n; i += MI_THREADS) dj[i] += gscale / n;
+            } else {
+                term1 = -(1.0f / beta) * mi_smoothed_lme(joint, n, -beta, s, prev[2 * b], -gscale / beta, dj, red, &e1);
+            }
+            if (beta == 1.0f) {
+                term2 = mean_m;
+                for (int i = threadIdx.x; i < n; i += MI_THREADS) dm[i] -= gscale / n;
+            } else {
+                term2 = (1.0f / (1.0f - beta)) * mi_smoothed_lme(marginal, n, 1.0f - beta, s, prev[2 * b + 1], -gscale / (1.0f - beta), dm,
+                                                                 red, &e2);
+            }
+            loss += term1 - term2;
+            if (threadIdx.x == 0) { next[2 * b] = e1; next[2 * b + 1] = e2; }
+        }
+    }
+    if (threadIdx.x == 0) out[0] = loss;
+}
+
+// CLUB.call (TransformerTTS/model/MINE.py:160-200): positive = -(mu - y)^2 / 2 / exp(log_var), negative the same against the
+// shuffled y; lld = mean_b sum_c positive; bound = mean_b (sum_c positive - sum_c negative).  d_mu / d_lv = gscale * d lld / d(.)
+__global__ __launch_bounds__(MI_THREADS) void club_terms_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                                const float* __restrict__ y, const float* __restrict__ ys, int B, int D,
+                                                                float* __restrict__ out, float* __restrict__ dmu, float* __restrict__ dlv,
+                                                                float gscale) {
+    __shared__ float red[MI_THREADS / 64];
+    float pos = 0.0f, neg = 0.0f;
+    for (int i = threadIdx.x; i < B * D; i += MI_THREADS) {
+        const float iv = __expf(-lv[i]);
+        const float dp = mu[i] - y[i], dn = mu[i] - ys[i];
+        pos += -0.5f * dp * dp * iv;
+        neg += -0.5f * dn * dn * iv;
+        dmu[i] = gscale * (-dp * iv) / B;
+        dlv[i] = gscale * (0.5f * dp * dp * iv) / B;
+    }
+    pos = mi_block_sum(pos, red);
+    neg = mi_block_sum(neg, red);
+    if (threadIdx.x == 0) { out[0] = pos / B; out[1] = (pos - neg) / B; }
+}
+
+extern "C" int estts_mine_divergence(const float* joint, const float* marginal, int32_t n, int32_t div_type, const float* betas,
+                                     int32_t n_beta, float smoothing, const float* prev_exp, float* next_exp, float* mi,
+                                     float* d_joint, float* d_marginal, float gscale, void* stream) {
+    ESTTS_CHECK_ARG(joint && marginal && prev_exp && next_exp && mi && d_joint && d_marginal && n > 0, "estts_mine_divergence: bad arguments");
+    ESTTS_CHECK_ARG(div_type == 0 || (div_type == 1 && betas && n_beta > 0), "estts_mine_divergence: divergence 0 (KL) or 1 (Renyi with betas)");
+    hipLaunchKernelGGL(mine_divergence_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, joint, marginal, n, div_type, betas,
+                       n_beta, smoothing, prev_exp, next_exp, mi, d_joint, d_marginal, gscale);
+    ESTTS_CHECK_LAUNCH("estts_mine_divergence");
+    return 0;
+}
+
+extern "C" int estts_club_terms(const float* mu, const float* log_var, const float* y, const float* y_shuffled, int32_t B, int32_t D,
+                                float* out, float* d_mu, float* d_log_var, float gscale, void* stream) {
+    ESTTS_CHECK_ARG(mu && log_var && y && y_shuffled && out && d_mu && d_log_var && B > 0 && D > 0, "estts_club_terms: bad arguments");
+    hipLaunchKernelGGL(club_terms_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, mu, log_var, y, y_shuffled, B, D, out,
+                       d_mu, d_log_var, gscale);
+    ESTTS_CHECK_LAUNCH("estts_club_terms");
+    return 0;
+}
+
 extern "C" int estts_head_scale(float* x, int32_t ldx, const float* scale, int32_t B, int32_t L, int32_t H, int32_t depth,
                                 void* stream) {
     ESTTS_CHECK_ARG(x && scale && B > 0 && L > 0 && H > 0 && depth > 0 && (depth & 3) == 0 && (ldx & 3) == 0 && ldx >= H * depth,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 22
+#define ESTTS_ABI_VERSION 23
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -527,6 +527,26 @@ int estts_im2col(const float* x, float* out, int32_t ldo, int32_t B, int32_t H, 
                  int32_t kh, int32_t kw, int32_t stride, int32_t pad_t, int32_t pad_l, void* stream);
 int estts_col2im(const float* dp, int32_t ldp, float* dx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                  int32_t kh, int32_t kw, int32_t stride, int32_t pad_t, int32_t pad_l, void* stream);
+
+/* Mutual-information estimate of MINE from the statistics network's scores on the joint and the marginal samples of one
+ * batch (contiguous [n] each), with its gradient, in one single-workgroup launch.
+ *   div_type 0 (KL):    mi = mean(joint) - log(E),  E = s * mean(exp(marginal)) + (1 - s) * prev_exp[1]
+ *   div_type 1 (Renyi): mi = sum over betas of term1 - term2 with the max-shifted, smoothed log-mean-exp terms of
+ *                       TransformerTTS/model/MINE.py:56-93 (beta == 0 / beta == 1 use the plain means there)
+ * prev_exp / next_exp: [n_beta][2] device floats, the smoothed exponential terms of the previous / this step (KL uses row 0);
+ * mi: device float; d_joint / d_marginal [n] = gscale * d mi / d score (gscale = -1: the ascent direction's negative loss).
+ * Replaces: MINE.measure_mi, TransformerTTS/model/MINE.py:40-95, and its tape gradient (model/traning_steps.py:78-81). */
+int estts_mine_divergence(const float* joint, const float* marginal, int32_t n, int32_t div_type, const float* betas,
+                          int32_t n_beta, float smoothing, const float* prev_exp, float* next_exp, float* mi, float* d_joint,
+                          float* d_marginal, float gscale, void* stream);
+
+/* CLUB's log-likelihood and upper bound from mu, log_var, y and the batch-shuffled y (contiguous [B, D] each):
+ *   positive = -(mu - y)^2 / 2 / exp(log_var);  negative = -(mu - y_shuffled)^2 / 2 / exp(log_var)
+ *   out[0] = lld = mean_b sum_d positive;  out[1] = bound = mean_b (sum_d positive - sum_d negative)
+ *   d_mu / d_log_var = gscale * d lld / d(mu / log_var)
+ * Replaces: CLUB.call after its two networks, TransformerTTS/model/MINE.py:181-200, and the tape gradient of lld. */
+int estts_club_terms(const float* mu, const float* log_var, const float* y, const float* y_shuffled, int32_t B, int32_t D,
+                     float* out, float* d_mu, float* d_log_var, float gscale, void* stream);
 
 /* Per-(batch, head) scaling of the attention context (HeadDrop, layers.py:74-97): x[b*L + t, h*depth + f] *= scale[b*H + h]. */
 int estts_head_scale(float* x, int32_t ldx, const float* scale, int32_t B, int32_t L, int32_t H, int32_t depth, void* stream);
