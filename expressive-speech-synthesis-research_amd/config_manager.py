@@ -103,8 +103,11 @@ class ConfigManager:
     def get_model(self, ignore_hash=False, weights=None, seed=1234, training=False, **kw):
         cfg = self.model_config_dict()
         if self.model_kind == 'autoregressive':
-            from .autoregressive_transformer import AutoregressiveTransformer
             w = weights if weights is not None else _weights.init_autoregressive_transformer(cfg, seed=seed)
+            if training:
+                from .autoregressive_training import AutoregressiveTransformerTrainer
+                return AutoregressiveTransformerTrainer(w, cfg, seed=seed, **kw)
+            from .autoregressive_transformer import AutoregressiveTransformer
             return AutoregressiveTransformer(w, cfg, **kw)
         w = weights if weights is not None else _weights.init_forward_transformer(cfg, seed=seed)
         if training:
@@ -181,6 +184,8 @@ class ConfigManager:
                     model.load_optimizer_state(opt)
         if verbose and path:
             print(f'restored weights from {path} at step {step}')
+        if training and self.model_kind == 'autoregressive':
+            return model                     # the training loop sets the schedules' values before every step
         const = {}
         if 'decoder_prenet_dropout_schedule' in self.config:
             const['decoder_prenet_dropout'] = float(piecewise_linear_schedule(step, self.config['decoder_prenet_dropout_schedule']))

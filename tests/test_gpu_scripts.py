@@ -33,6 +33,31 @@ def test_extract_durations_then_train_forward(tmp_path):
         f'pytest_{os.getpid()}')
 
 
+def test_train_autoregressive(tmp_path):
+    """scripts/train_autoregressive.py on the shipped configuration (speaker_text, reduction factor 10), then on a copy with a
+    style system and the mutual-information heads switched on (MINE, a batch of their own)."""
+    import shutil
+    import yaml
+    session = f'pytest_{os.getpid()}'
+    log = run('scripts/train_autoregressive.py', '--config', 'config/wavernn', '--synthetic', '--max-steps', '2', '--session_name', session)
+    cfg_dir = tmp_path / 'wavernn'
+    shutil.copytree(os.path.join(ROOT, 'config', 'wavernn'), cfg_dir)
+    with open(cfg_dir / 'autoregressive_config.yaml') as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(system_type='speaker_style_text', use_mine=True, mine_sep_call=True,
+               mine_batch_size_schedule=[[0, 6], [80000, 4]], tts_batch_size=4, mine_dense_hidden_units=[64, 32])
+    with open(cfg_dir / 'autoregressive_config.yaml', 'w') as f:
+        yaml.safe_dump(cfg, f)
+    with open(cfg_dir / 'data_config.yaml') as f:
+        data = yaml.safe_load(f)
+    data['log_directory'] = str(tmp_path / 'logs')
+    with open(cfg_dir / 'data_config.yaml', 'w') as f:
+        yaml.safe_dump(data, f)
+    run('scripts/train_autoregressive.py', '--config', str(cfg_dir), '--synthetic', '--max-steps', '2', '--session_name', session)
+    saved = sorted(p.name for p in (tmp_path / 'logs').rglob('*.npz'))
+    assert 'ckpt-2.npz' in saved and sum(n.startswith('mine') for n in saved) == 3, saved
+
+
 def test_gen_wavernn(tmp_path):
     rng = np.random.default_rng(0)
     mels = tmp_path / 'mels'
