@@ -466,6 +466,37 @@ def predict_bench(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def config1_cpu_seconds(args):
+    """BASELINE config 1: the DSP chain of gst_tacotron's eval path (one LJSpeech-length utterance -> spectrogram / 80-bin mel
+    -> Griffin-Lim, 60 iterations -> end-point detection) on the host CPU.  Plumbing with no GPU part: only its seconds are
+    reported, from the float64 NumPy restatement that the tests check (oracle/audio_numpy.py)."""
+    from oracle import audio_numpy as A
+    hp = A.GST_HPARAMS
+    sr = hp['sample_rate']
+    rng = np.random.default_rng(0)
+    t = np.arange(int(6.5 * sr)) / sr                        # an LJSpeech sentence is about 6.5 s
+    wav = 0.3 * np.sin(2 * np.pi * 180 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.02 * rng.normal(size=t.shape)
+    times = []
+    for _ in range(max(1, min(args.steps, 5))):
+        t0 = time.perf_counter()
+        spec = A.gst_spectrogram(wav, hp)
+        mel = A.gst_melspectrogram(wav, hp)
+        out = A.gst_inv_spectrogram(spec, hp, rng=np.random.default_rng(1))
+        out = out[:A.find_endpoint(out, sr)]
+        times.append(time.perf_counter() - t0)
+    sec = float(np.median(times))
+    print(json.dumps({
+        'metric': 'seconds per utterance (gst_tacotron eval DSP chain on the CPU)', 'value': sec, 'unit': 's', 'n_gpus': 0,
+        'steps': len(times), 'warmup': 0, 'ms_per_step': sec * 1e3, 'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': f'BASELINE config 1: {len(wav) / sr:.1f} s utterance at {sr} Hz -> linear + {mel.shape[0]}-bin mel '
+                               f'spectrogram ({mel.shape[1]} frames) -> Griffin-Lim {hp["griffin_lim_iters"]} iterations -> end point; '
+                               'the Tacotron network itself (TF 1.14 tf.contrib) is out of scope'},
+        'roofline': None,
+        'cpu_baseline': {'value': sec, 'unit': 's', 'cores': 1, 'kind': 'port',
+                         'sample': 'the whole workload: one utterance, float64 NumPy (oracle/audio_numpy.py)'}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -482,7 +513,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel timing pass (clean kernel statistics under rocprofv3); roofline is then null')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
-    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn', 'predict'],
+    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn', 'predict', 'config1'],
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
                          "AutoregressiveTransformer (config 3; use --batch 32); train: ForwardTransformer training step, "
                          "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
@@ -491,6 +522,8 @@ def main():
     global NO_ROOFLINE
     NO_ROOFLINE = args.no_roofline
 
+    if args.workload == 'config1':
+        return config1_cpu_seconds(args)
     from estts import parallel
     rank, world, local_rank = parallel.env_ranks()
     # (ESTTS_DIST_BACKEND=gloo with more ranks than GPUs rehearses the multi-rank paths on a one-GPU box; with gloo the
