@@ -6,17 +6,18 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_new
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
+P=${ROUND:-r02}
 say() { echo "[collect] $*"; }
 
 say default bench
-timeout -k 10 400 python3 -u bench.py > $O/r01_bench_default.json 2> $O/default.err
+timeout -k 10 400 python3 -u bench.py > $O/${P}_bench_default.json 2> $O/default.err
 
 prof() {   # name, bench arguments...
   name=$1; shift
   say rocprof $name
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tmp_$name -o p -- python3 bench.py "$@" > $O/tmp_$name.log 2>&1
-  cp $O/tmp_$name/p_kernel_stats.csv $O/r01_bench_${name}_kernel_stats.csv
-  grep '^{' $O/tmp_$name.log | tail -n 1 > $O/r01_bench_${name}_under_rocprof.json
+  cp $O/tmp_$name/p_kernel_stats.csv $O/${P}_bench_${name}_kernel_stats.csv
+  grep '^{' $O/tmp_$name.log | tail -n 1 > $O/${P}_bench_${name}_under_rocprof.json
   rm -rf $O/tmp_$name $O/tmp_$name.log
 }
 prof forward_b1 --steps 200 --warmup 20 --no-wavernn --no-cpu-baseline
@@ -29,7 +30,7 @@ prof wavernn_c4 --steps 20 --warmup 2 --no-cpu-baseline --no-roofline
 table() {  # name, bench arguments...
   name=$1; shift
   say kernel table $name
-  timeout -k 10 400 python3 -u bench.py "$@" --kernel-table --no-cpu-baseline > $O/r01_bench_${name}_kernel_table.txt 2>&1
+  timeout -k 10 400 python3 -u bench.py "$@" --kernel-table --no-cpu-baseline > $O/${P}_bench_${name}_kernel_table.txt 2>&1
 }
 table forward_b1 --no-wavernn
 table gst --workload gst --batch 32
@@ -39,8 +40,12 @@ table train_wavernn --workload train_wavernn --batch 32 --steps 5 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do
   say pmc $c
   timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/tmp_pmc -o p -- python3 bench.py --steps 20 --warmup 2 --no-wavernn --no-cpu-baseline --no-roofline > $O/tmp_pmc.log 2>&1
-  cp $O/tmp_pmc/p_counter_collection.csv $O/r01_pmc_forward_b1_$c.csv
+  cp $O/tmp_pmc/p_counter_collection.csv $O/${P}_pmc_forward_b1_$c.csv
   rm -rf $O/tmp_pmc $O/tmp_pmc.log
 done
+say precision sweep
+timeout -k 10 400 python3 -u tests/precision_sweep.py --out $O/${P}_precision_sweep.json > $O/${P}_precision_sweep.txt 2>&1
+say config 1
+timeout -k 10 200 python3 -u bench.py --workload config1 --steps 3 > $O/${P}_bench_config1_cpu.json 2>/dev/null
 say done
 ls -la $O
