@@ -466,6 +466,22 @@ def predict_bench(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def secondary_pass(argv, precision):
+    """Runs this script for another workload in a child process and returns the essentials of its JSON line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ['--precision', precision, '--no-cpu-baseline', '--no-wavernn']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    except Exception as e:            # the headline line must survive a failing extra
+        return {'error': f'{type(e).__name__}: {e}'}
+    keep = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'algorithmic_tflops', 'steps_per_s', 'roofline')
+    out = {k: d[k] for k in keep if k in d}
+    out['workload'] = d['config']['workload']
+    out['launches_per_step'] = d['config'].get('launches_per_step')
+    return out
+
+
 def config1_cpu_seconds(args):
     """BASELINE config 1: the DSP chain of gst_tacotron's eval path (one LJSpeech-length utterance -> spectrogram / 80-bin mel
     -> Griffin-Lim, 60 iterations -> end-point detection) on the host CPU.  Plumbing with no GPU part: only its seconds are
@@ -517,7 +533,9 @@ def main():
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
                          "AutoregressiveTransformer (config 3; use --batch 32); train: ForwardTransformer training step, "
                          "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
-    ap.add_argument('--no-wavernn', action='store_true', help='skip the WaveRNN (config 4) pass reported under "wavernn"')
+    ap.add_argument('--no-wavernn', action='store_true',
+                    help='skip the secondary passes of the default run: WaveRNN (config 4, reported under "wavernn") and the '
+                         'child runs of configs 3 and 5 on one GPU ("config3", "config5_one_gpu")')
     args = ap.parse_args()
     global NO_ROOFLINE
     NO_ROOFLINE = args.no_roofline
@@ -665,6 +683,11 @@ def main():
         }
         if world == 1 and not args.no_wavernn:
             line['wavernn'] = wavernn_pass(args.precision, cpu_leg=not args.no_cpu_baseline, kernel_table=args.kernel_table)
+            if args.workload == 'forward' and B == 1:
+                # the other single-GPU configurations, each in a child process of its own (fresh allocator and graphs)
+                line['config3'] = secondary_pass(['--workload', 'gst', '--batch', '32', '--steps', '20', '--warmup', '3'], args.precision)
+                line['config5_one_gpu'] = secondary_pass(['--workload', 'train', '--batch', '32', '--steps', '10', '--warmup', '3'],
+                                                         args.precision)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
