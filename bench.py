@@ -350,6 +350,77 @@ def train_bench(args, rank, world, dist):
         dist.destroy_process_group()
 
 
+def train_ar_bench(args, rank, world, dist):
+    """The TTS half of train_models_step (traning_steps.py:22-56) plus one MINE head: AutoregressiveTransformer training step,
+    style_text system (reference encoder + style tokens), reduction factor 1, `--batch` utterances per GPU (the shipped
+    tts_batch_size is 8), N tokens, T frames."""
+    from estts.autoregressive_training import AutoregressiveTransformerTrainer
+    from estts.mine import MINE
+    from estts.training_steps import train_models_step
+    B, N, T = args.batch, args.tokens, args.frames
+    cfg = configs.autoregressive_config(system_type='style_text')
+    w = weights.init_autoregressive_transformer(cfg, seed=1234)
+    rng = np.random.default_rng(7 + rank)
+    tokens = rng.integers(1, cfg['vocab_size'], size=(B, N)).astype(np.int32)
+    mel = np.clip(rng.normal(0, 1.5, size=(B, T + 1, cfg['mel_channels'])), -3.9, 3.9).astype(np.float32)
+    mel[:, 0], mel[:, -1] = cfg['mel_start_value'], cfg['mel_end_value']
+    stop = np.ones((B, T + 1), np.int32)
+    stop[:, -1] = 2
+    model = AutoregressiveTransformerTrainer(w, cfg, precision=args.precision, seed=1234)
+    model._compile(stop_scaling=8.0, optimizer={'learning_rate': 1e-4})
+    model.set_constants(reduction_factor=1, decoder_prenet_dropout=0.0, drop_n_heads=0)
+    heads = [MINE(dense_hidden_units=[512, 64], divergence_type='KL', pair_type='style_text', seed=1)]
+    holder = {'use_mine': True, 'mine_sep_call': False, 'mi_loss': 0.0, 'exp_terms': np.zeros((3, 2), np.float32),
+              'weight_factor': 0.1, 'smoothing_factor': 1.0}
+    mel_d, tok_d, stop_d = torch.from_numpy(mel).cuda(), torch.from_numpy(tokens).cuda(), torch.from_numpy(stop).cuda()
+
+    def step():
+        return train_models_step(mel_d, tok_d, stop_d, None, 0, 0, 0, 0, model, heads, holder, True, True, True, False)
+
+    out = step()
+    torch.cuda.synchronize()
+    loss0 = float(out['loss'])
+    roofline, launches = None, None
+    if rank == 0 or world > 1:
+        ops.start_trace()
+        traced = step()
+        trace = ops.stop_trace()
+        torch.cuda.synchronize()
+        roofline, launches = roofline_from_trace(trace, args.kernel_table, rank)
+        del traced, trace
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'mel-frames/sec (AutoregressiveTransformer training step)', 'value': world * B * T / (dt / args.steps),
+            'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3 / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'train_models_step: AutoregressiveTransformer (style_text, r=1) forward + three losses + backward + '
+                                   f'Adam, then one MINE head (KL, style_text) ascent step; batch={B} per GPU, N={N}, T={T}; '
+                                   f'{args.precision} MFMA operands, fp32 accumulate, fp32 master weights',
+                       'global_batch': world * B, 'parallelism': f'dp{world}', 'hip_graph': False, 'launches_per_step': launches},
+            'steps_per_s': args.steps / dt, 'loss_first_step': loss0, 'loss_last_step': float(out['loss']),
+            'roofline': roofline, 'cpu_baseline': None}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def train_wavernn_bench(args, rank, world, dist):
     """WaveRNN training step (train_wavernn.py): `--batch` windows of 5 hops per GPU, RAW 9-bit, shipped hparams
     (hop 200, 16 kHz): teacher-forced forward, cross-entropy, BPTT, all-reduce, Adam."""
@@ -529,7 +600,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel timing pass (clean kernel statistics under rocprofv3); roofline is then null')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
-    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn', 'predict', 'config1'],
+    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn', 'train_ar', 'predict', 'config1'],
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
                          "AutoregressiveTransformer (config 3; use --batch 32); train: ForwardTransformer training step, "
                          "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
@@ -560,6 +631,8 @@ def main():
         return train_bench(args, rank, world, dist)
     if args.workload == 'train_wavernn':
         return train_wavernn_bench(args, rank, world, dist)
+    if args.workload == 'train_ar':
+        return train_ar_bench(args, rank, world, dist)
     if args.workload == 'predict':
         return predict_bench(args, rank, world, dist)
     if args.workload == 'forward':

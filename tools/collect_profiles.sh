@@ -36,6 +36,7 @@ table forward_b1 --no-wavernn
 table gst --workload gst --batch 32
 table train --workload train --batch 32
 table train_wavernn --workload train_wavernn --batch 32 --steps 5 --warmup 2
+table train_ar --workload train_ar --batch 8 --steps 10 --warmup 3
 
 for c in FETCH_SIZE WRITE_SIZE; do
   say pmc $c
