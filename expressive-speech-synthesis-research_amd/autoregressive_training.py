@@ -707,5 +707,13 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         self.gate_log = log
         return gst_out, text_out.reshape(B, N, self.de)
 
-    def val_step(self, *a, **kw):
-        raise NotImplementedError('validation runs through AutoregressiveTransformer.val_step on weights()')
+    def val_step(self, inp, tar, stop_prob, spk_embed=None):
+        """AutoregressiveTransformer._val_step (AutoregressiveTransformer.py:220-222): the teacher-forced pass with every
+        sub-network in inference mode and the three losses, through the inference class on the current variables."""
+        from .autoregressive_transformer import AutoregressiveTransformer
+        if self._infer is None:
+            self._infer = AutoregressiveTransformer(self.weights(), self.config, device=self.device, precision=self.precision,
+                                                    fold_ffn=False)
+            self._infer._compile(stop_scaling=self.stop_scaling)
+        self._infer.set_constants(reduction_factor=self.r, decoder_prenet_dropout=self.decoder_prenet_dropout)
+        return self._infer.val_step(inp, tar, stop_prob, spk_embed)

@@ -1,0 +1,60 @@
+"""One rank of the data-parallel AutoregressiveTransformer training check (started by tests/test_gpu_dp_train.py under
+torch.distributed.run, every rank on GPU 0 with the gloo backend): the gradient buffer after a step equals the sum over ranks
+of the gradients the ranks compute alone on their own batches, and the weights stay identical across ranks after the update."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+
+import estts  # noqa: E402,F401
+from estts import parallel, weights  # noqa: E402
+from estts.autoregressive_training import AutoregressiveTransformerTrainer  # noqa: E402
+from test_gpu_autoregressive_training import batch, small_cfg  # noqa: E402
+
+
+def gathered(t):
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return out
+
+
+def main():
+    rank, world, _ = parallel.env_ranks()
+    torch.cuda.set_device(0)
+    parallel.init_distributed('gloo')
+    solo = [dist.new_group([r]) for r in range(world)][rank]
+    cfg = small_cfg('speaker_style_text', 0.0)
+    w = weights.init_autoregressive_transformer(cfg, seed=3)
+    tokens, mel, stop, spk = batch(cfg, 3, 13, 20, seed=40 + rank)
+
+    def make(group):
+        m = AutoregressiveTransformerTrainer(w, cfg, process_group=group) if group is not None else AutoregressiveTransformerTrainer(w, cfg)
+        m._compile(stop_scaling=8.0, optimizer={'learning_rate': 1e-3})
+        m.set_constants(reduction_factor=2)
+        return m
+
+    alone = make(solo)
+    assert alone.world == 1
+    alone.rank = rank
+    alone.train_step(mel, tokens, stop, spk, apply=False)
+    expected = sum(gathered(alone.store.grad.cpu()))
+    model = make(None)
+    assert model.world == world
+    model.train_step(mel, tokens, stop, spk)
+    got = model.store.grad.cpu()
+    scale, err = float(expected.norm()), float((got - expected).norm())
+    assert err <= 5e-3 * scale, (err, scale)
+    assert float((got - alone.store.grad.cpu()).norm()) > 0.1 * scale
+    flats = gathered(model.store.flat.cpu())
+    assert all(torch.equal(flats[0], f) for f in flats[1:])
+    print(f'rank {rank}: autoregressive data-parallel step OK (gradient error {err:.2e} of {scale:.2e})', flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

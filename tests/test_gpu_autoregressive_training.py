@@ -53,10 +53,11 @@ def grads_by_name(model):
     return model.gradients()
 
 
-def tight_compare(model, ref, tol=1e-3, tol_qk=1e-2, floor_qk=1e-4):
+def tight_compare(model, ref, tol=1e-3, tol_qk=1e-2, floor_qk=5e-4):
     """Every tensor within tol of its largest entry; the self-attention query / key projections within tol_qk + an absolute
     floor: when a softmax saturates (the first decoder block sees prenet outputs times sqrt(d)) their true gradient vanishes
-    and what the device returns is the rounding of delta = <dctx, ctx> against dP, ~1e-6 of quantities that are large."""
+    and what the device returns is the rounding of delta = <dctx, ctx> against dP, ~1e-5 of quantities that are large
+    (measured 5e-5 .. 1.2e-4 absolute from run to run, against 1e-2 .. 1e-1 for the gradients that matter)."""
     mine = grads_by_name(model)
     errs = []
     assert set(ref['grads']) == set(mine), set(ref['grads']) ^ set(mine)
@@ -204,3 +205,7 @@ def test_weights_round_trip_and_adam_step():
     infer.set_constants(reduction_factor=2)
     val = infer.val_step(tokens, mel, stop, spk)
     assert np.isfinite(float(val['tts_loss']))
+    val2 = model.val_step(tokens, mel, stop, spk)               # the trainer's own validation pass: the same model
+    assert abs(float(val2['tts_loss']) - float(val['tts_loss'])) < 1e-4
+    model.train_step(mel, tokens, stop, spk)
+    assert abs(float(model.val_step(tokens, mel, stop, spk)['tts_loss']) - float(val['tts_loss'])) > 1e-6   # rebuilt after a step

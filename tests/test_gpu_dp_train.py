@@ -24,3 +24,11 @@ def test_two_ranks_sum_gradients_and_stay_in_step():
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count('data-parallel step OK') == 2, r.stdout[-2000:]
+
+
+def test_two_ranks_autoregressive_trainer():
+    cmd = [sys.executable, '-u', '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join('tests', 'dp_train_ar_worker.py')]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count('autoregressive data-parallel step OK') == 2, r.stdout[-2000:]
