@@ -279,6 +279,8 @@ def train_bench(args, rank, world, dist):
     rng = np.random.default_rng(99 + rank)
     mel = np.clip(rng.normal(0, 1.5, size=(B, T, cfg['mel_channels'])), -4, 4).astype(np.float32)
     model = ForwardTransformerTrainer(w, cfg, precision=args.precision, seed=1234)
+    if args.backward_precision:
+        model.backward_precision = args.backward_precision
     model.set_constants(learning_rate=1e-4, decoder_prenet_dropout=0.0, drop_n_heads=0)
     tok_d = torch.from_numpy(tokens).cuda()
     mel_d = torch.from_numpy(mel).cuda()
@@ -338,7 +340,7 @@ def train_bench(args, rank, world, dist):
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'ForwardTransformer train_step: forward (dropout 0.1, BatchNorm batch statistics) + backward + '
                                    f'gradient all-reduce + Adam, batch={B} per GPU, N={N}, T={T} (BASELINE config 5); '
-                                   f'{args.precision} MFMA operands, fp32 accumulate, fp32 master weights',
+                                   f'{args.precision} MFMA operands (backward products: {args.backward_precision or args.precision}), fp32 accumulate, fp32 master weights',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'hip_graph': False,
                        'launches_per_step': launches},
             'steps_per_s': args.steps / dt, 'algorithmic_tflops': world * flops / (dt / args.steps) / 1e12,
@@ -593,6 +595,8 @@ def main():
     ap.add_argument('--tokens', type=int, default=100)
     ap.add_argument('--frames', type=int, default=600)
     ap.add_argument('--precision', default='bf16x3', choices=['bf16', 'bf16x3'])
+    ap.add_argument('--backward-precision', default=None, choices=['bf16', 'bf16x3'],
+                    help='training workloads: operands of the backward products (default: the same as --precision)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-attention-weights', action='store_true',
                     help='skip materialising the attention maps the reference returns')

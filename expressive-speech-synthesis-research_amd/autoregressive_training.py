@@ -359,11 +359,11 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         def backward(dout):
             da, dx = self._empty(Mq, d), self._empty(Mq, d)
             T.rownorm_bwd(fa, dout=dout, dy=da, dx=dx, dln_b=Cx.ln.dpair)
-            T.wgrad(cat, da, Cx.wo.dk, M=Mq, precision=self.precision)
+            T.wgrad(cat, da, Cx.wo.dk, M=Mq, precision=self.backward_precision)
             T.colreduce(1, Cx.wo.db, g=da, M=Mq, C=d)
             dctx = self._empty(Mq, d)
-            ops.gemm(da, Cx.wo_c.bwd, dctx, M=Mq, precision=self.precision)
-            ops.gemm(da, Cx.wo_x.bwd, dx, M=Mq, precision=self.precision, residual=dx)
+            ops.gemm(da, Cx.wo_c.bwd, dctx, M=Mq, precision=self.backward_precision)
+            ops.gemm(da, Cx.wo_x.bwd, dx, M=Mq, precision=self.backward_precision, residual=dx)
             delta = self._empty(B * H * Lq)
             dq, dkv = self._empty(Mq, d), self._empty(Mk, 2 * d)
             ctx_b = ctx
@@ -372,7 +372,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 T.head_scale(ctx_b, hinv, B, Lq, H, d // H)
                 T.head_scale(dctx, hscale, B, Lq, H, d // H)
             T.attention_bwd(q, kv[:, :d], kv[:, d:], ctx_b, dctx, attn, delta, dq, dkv[:, :d], dkv[:, d:], B, H, Lq, Lk, d // H,
-                            precision=self.precision)
+                            precision=self.backward_precision)
             self._lin_bwd(cat[:, :d], Cx.wq, dq, Mq, dx=dx, accumulate=True)
             self._lin_bwd(enc, Cx.wkv, dkv, Mk, dx=d_enc, accumulate=True)
             return dx
@@ -451,7 +451,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             delta = self._empty(B * Hh)
             dq, dkvb = self._empty(B, sd), self._empty(B * n_tok, 2 * sd)
             T.attention_bwd(q, kvb[:, :sd], kvb[:, sd:], ctx_b, dctx, attn, delta, dq, dkvb[:, :sd], dkvb[:, sd:], B, Hh, 1, n_tok,
-                            sd // Hh, precision=self.precision)
+                            sd // Hh, precision=self.backward_precision)
             dkv = torch.zeros(n_tok * 2 * sd, dtype=torch.float32, device=self.device)
             T.colreduce(1, dkv, g=dkvb.view(B, n_tok * 2 * sd), M=B, C=n_tok * 2 * sd)      # the tokens are shared: sum over the batch
             dtok_t = self._empty(n_tok, tokdim)
@@ -461,9 +461,9 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             self._lin_bwd(proj, G.wq, dq, B, dx=dproj, accumulate=True)
             dpre = self._empty(B, u)
             T.colreduce(1, G.rnn_proj.db, g=dproj, a=proj, act='tanh', dy_out=dpre, M=B, C=u)
-            T.wgrad(hs[steps], dpre, G.rnn_proj.dk, M=B, precision=self.precision)
+            T.wgrad(hs[steps], dpre, G.rnn_proj.dk, M=B, precision=self.backward_precision)
             dh = self._empty(B, u)
-            ops.gemm(dpre, G.rnn_proj.lin.bwd, dh, M=B, precision=self.precision)
+            ops.gemm(dpre, G.rnn_proj.lin.bwd, dh, M=B, precision=self.backward_precision)
             # GRU through time: only the last state feeds the output
             dgi = self._empty(B, steps, 3 * u)
             dgh = self._empty(steps, B, 3 * u)
@@ -472,9 +472,9 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             for t in reversed(range(steps)):
                 dprev = self._empty(B, u)
                 T.gru_step_bwd(gi3[:, t], ghs[t], hs[t], dh if t == steps - 1 else zero, rec, dgi[:, t], dgh[t], dprev)
-                ops.gemm(dgh[t], G.gru_hh.lin.bwd, dprev, M=B, precision=self.precision, residual=dprev)
+                ops.gemm(dgh[t], G.gru_hh.lin.bwd, dprev, M=B, precision=self.backward_precision, residual=dprev)
                 rec = dprev
-            T.wgrad(hs[:steps].view(steps * B, u), dgh.view(steps * B, 3 * u), G.gru_hh.dk, M=steps * B, precision=self.precision,
+            T.wgrad(hs[:steps].view(steps * B, u), dgh.view(steps * B, 3 * u), G.gru_hh.dk, M=steps * B, precision=self.backward_precision,
                     db=G.gru_hh.db)
             dseq = self._empty(Ms, feat)
             self._lin_bwd(seq, G.gru_ih, dgi.view(Ms, 3 * u), Ms, dx=dseq)
@@ -590,11 +590,11 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             T.dropout(dy0, dy0, self.dropout_rate, self._seed_now, site1, M=Md, D=dd)
             T.axpby(dy0, dy0, alpha=math.sqrt(np.float32(dd)) * inv_keep, beta=0.0, M=Md, D=dd)
             T.colreduce(1, self.prenet2.db, g=dy0, a=p2, act='relu', dy_out=dy0, M=Md, C=dd)
-            T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.precision)
+            T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.backward_precision)
             dp1 = self._empty(Md, self.prenet1.N)
-            ops.gemm(dy0, self.prenet2.lin.bwd, dp1, M=Md, precision=self.precision, alpha=inv_keep)
+            ops.gemm(dy0, self.prenet2.lin.bwd, dp1, M=Md, precision=self.backward_precision, alpha=inv_keep)
             T.colreduce(1, self.prenet1.db, g=dp1, a=p1, act='relu', dy_out=dp1, M=Md, C=self.prenet1.N)
-            T.wgrad(tg2, dp1, self.prenet1.dk, M=Md, precision=self.precision)
+            T.wgrad(tg2, dp1, self.prenet1.dk, M=Md, precision=self.backward_precision)
 
         # ---- decoder blocks (layers.py:357-376)
         dec_tape = []

@@ -222,6 +222,9 @@ class ForwardTransformerTrainer:
         cfg = self.config = dict(config)
         self.device = torch.device(device)
         self.precision = precision
+        # operands of the backward products (data and weight gradients, attention backward); 'bf16' trades gradient accuracy
+        # (about 3e-3 per product instead of 1e-5) for one MFMA per product instead of three
+        self.backward_precision = precision
         self.seed = int(seed)
         self.pg = process_group
         self.world, self.rank = 1, 0
@@ -318,9 +321,9 @@ class ForwardTransformerTrainer:
         """Kernel and bias gradients of layer L (input x, output gradient dy); optionally the input gradient into dx
         (added to dx when accumulate, or to `residual`)."""
         sl = seg if L.taps > 1 else 0
-        T.wgrad(x, dy, L.dk, taps=L.taps, lpad=L.lpad, M=M, seg_len=sl, precision=self.precision, db=L.db)
+        T.wgrad(x, dy, L.dk, taps=L.taps, lpad=L.lpad, M=M, seg_len=sl, precision=self.backward_precision, db=L.db)
         if dx is not None:
-            ops.gemm(dy, L.lin.bwd, dx, M=M, seg_len=sl, precision=self.precision, residual=dx if accumulate else residual)
+            ops.gemm(dy, L.lin.bwd, dx, M=M, seg_len=sl, precision=self.backward_precision, residual=dx if accumulate else residual)
         return dx
 
     def _sarn_fwd(self, S, cat, B, L, key_mask, out, tape, causal=False):
@@ -349,18 +352,18 @@ class ForwardTransformerTrainer:
         def backward(dout):
             da, dx = self._empty(M, d), self._empty(M, d)
             T.rownorm_bwd(fa, dout=dout, dy=da, dx=dx, dln_a=S.ln.dpair, dln_b=S.last_ln.dpair)
-            T.wgrad(cat, da, S.wo.dk, M=M, precision=self.precision)
+            T.wgrad(cat, da, S.wo.dk, M=M, precision=self.backward_precision)
             T.colreduce(1, S.wo.db, g=da, M=M, C=d)
             dctx = self._empty(M, d)
-            ops.gemm(da, S.wo_c.bwd, dctx, M=M, precision=self.precision)
-            ops.gemm(da, S.wo_x.bwd, dx, M=M, precision=self.precision, residual=dx)
+            ops.gemm(da, S.wo_c.bwd, dctx, M=M, precision=self.backward_precision)
+            ops.gemm(da, S.wo_x.bwd, dx, M=M, precision=self.backward_precision, residual=dx)
             delta = self._empty(B * H * L)
             dqkv = self._empty(M, 3 * d)
             if hscale is not None:
                 self._attention_bwd_headdrop(qkv, ctx, dctx, attn, delta, dqkv, B, H, L, d, hscale, hinv)
             else:
                 T.attention_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], ctx, dctx, attn, delta, dqkv[:, :d], dqkv[:, d:2 * d],
-                                dqkv[:, 2 * d:], B, H, L, L, d // H, precision=self.precision)
+                                dqkv[:, 2 * d:], B, H, L, L, d // H, precision=self.backward_precision)
             self._lin_bwd(cat[:, :d], S.wqkv, dqkv, M, dx=dx, accumulate=True)
             return dx
 
@@ -374,7 +377,7 @@ class ForwardTransformerTrainer:
         T.head_scale(ctx_pre, hinv, B, L, H, d // H)
         T.head_scale(dctx, hscale, B, L, H, d // H)
         T.attention_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], ctx_pre, dctx, attn, delta, dqkv[:, :d], dqkv[:, d:2 * d],
-                        dqkv[:, 2 * d:], B, H, L, L, d // H, precision=self.precision)
+                        dqkv[:, 2 * d:], B, H, L, L, d // H, precision=self.backward_precision)
 
     def _ffn_fwd(self, Fb, x, M, out, tape):
         h1 = self._empty(M, Fb.d1.N)
@@ -655,13 +658,13 @@ class ForwardTransformerTrainer:
             T.dropout(dy0, dy0, self.dropout_rate, self._seed_now, site1, M=Md, D=dd)
             T.axpby(dy0, dy0, alpha=math.sqrt(np.float32(dd)) * inv_keep, beta=0.0, M=Md, D=dd)
             T.colreduce(1, self.prenet2.db, g=dy0, a=p2, act='relu', dy_out=dy0, M=Md, C=dd)
-            T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.precision)
+            T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.backward_precision)
             dp1 = self._empty(Md, self.prenet1.N)
-            ops.gemm(dy0, self.prenet2.lin.bwd, dp1, M=Md, precision=self.precision, alpha=inv_keep)
+            ops.gemm(dy0, self.prenet2.lin.bwd, dp1, M=Md, precision=self.backward_precision, alpha=inv_keep)
             T.colreduce(1, self.prenet1.db, g=dp1, a=p1, act='relu', dy_out=dp1, M=Md, C=self.prenet1.N)
-            T.wgrad(mels_in, dp1, self.prenet1.dk, M=Md, precision=self.precision)
+            T.wgrad(mels_in, dp1, self.prenet1.dk, M=Md, precision=self.backward_precision)
             dmels = self._empty(Md, de)
-            ops.gemm(dp1, self.prenet1.lin.bwd, dmels, M=Md, precision=self.precision)
+            ops.gemm(dp1, self.prenet1.lin.bwd, dmels, M=Md, precision=self.backward_precision)
             d_enc = self._empty(Me, de)
             T.expand_bwd(dmels, cum, d_enc, B, N, Tm, de)
             return d_enc

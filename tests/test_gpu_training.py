@@ -377,3 +377,25 @@ def test_train_step_gradients_tight_on_the_device_branches(dropout):
     assert abs(float(out['loss']) - ref['loss']) < 2e-5 * max(1.0, abs(ref['loss']))
     assert np.abs(out['mel'].cpu().numpy() - ref['mel']).max() < 5e-4
     tight_compare(model, ref)
+
+
+def test_backward_products_in_plain_bf16():
+    """backward_precision='bf16': the forward pass (loss, outputs) is untouched, the gradient keeps its direction (cosine against
+    the float64 oracle > 0.9995) with errors of the size of one bf16 rounding per product."""
+    from estts.forward_training import ForwardTransformerTrainer
+    cfg = small_cfg(0.0)
+    w = weights.init_forward_transformer(cfg, seed=7)
+    tokens, mel, durs = batch(cfg, 3, 19, seed=2)
+    ref = OT.forward_train_step(w, cfg, tokens, mel, durs)
+    model = ForwardTransformerTrainer(w, cfg)
+    model.backward_precision = 'bf16'
+    out = model.train_step(tokens, mel, durs)
+    assert abs(float(out['loss']) - ref['loss']) < 1e-5 * max(1.0, abs(ref['loss']))
+    mine = grads_by_name(model)
+    dot = n1 = n2 = 0.0
+    for k, r in ref['grads'].items():
+        a, r = mine[k].reshape(-1).astype(np.float64), np.asarray(r).reshape(-1)
+        dot, n1, n2 = dot + float(a @ r), n1 + float(a @ a), n2 + float(r @ r)
+    cosine = dot / np.sqrt(n1 * n2)
+    print(f'bf16 backward products: gradient cosine {cosine:.6f}')
+    assert 0.9995 < cosine < 0.9999999
