@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -154,6 +154,7 @@ SIGNATURES = {
     'estts_axpby': (_i32, [_vp, _i32, _f32, _vp, _i32, _f32, _i32, _i32, _vp]),
     'estts_head_scale': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     'estts_mine_divergence': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _f32, _vp]),
+    'estts_mse': (_i32, [_vp, _vp, _i32, _vp, _vp, _f32, _vp]),
     'estts_club_terms': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _f32, _vp]),
     'estts_im2col': (_i32, [_vp, _vp, _i32] + [_i32] * 11 + [_vp]),
     'estts_col2im': (_i32, [_vp, _i32, _vp] + [_i32] * 11 + [_vp]),

@@ -57,7 +57,7 @@ class _Gst:
         self.stride = cfg['ref_encoder_strides']
         if cfg['ref_encoder_kernel_size'] != 3:
             raise NotImplementedError('reference encoder kernels other than 3x3')
-        self.convs = [_Layer(store, f'{p}.conv{i}', need_bwd=i > 0) for i in range(n)]
+        self.convs = [_Layer(store, f'{p}.conv{i}') for i in range(n)]      # (the first one's data gradient: style loss only)
         self.norms = [_Norm(store, f'{p}.norm{i}', True) for i in range(n)]
         self.u = cfg['ref_encoder_gru_cell_units']
         self.sd, self.H = cfg['gst_style_embed_dim'], cfg['gst_multi_num_heads']
@@ -380,9 +380,10 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         tape.append(backward)
         return attn
 
-    def _gst_fwd(self, x, B, Tq, tape):
+    def _gst_fwd(self, x, B, Tq, tape, input_grad=False):
         """ReferenceEncoderGST.call(training=True) (layers.py:561-585) on x [B, Tq, mel] -> (style embedding [B, sd],
-        attention [B, heads, 1, tokens]); appends ONE closure to `tape` that takes the gradient of the embedding.
+        attention [B, heads, 1, tokens]); appends ONE closure to `tape` that takes the gradient of the embedding (and returns
+        the gradient of x when input_grad, else None).
         Every Conv2D runs as patches (estts_im2col) times a dense kernel, which its two gradients need anyway."""
         G, s = self.gst, self.gst.stride
         y, H, W, Cin = x.contiguous(), Tq, self.mel_channels, 1
@@ -456,8 +457,12 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             T.colreduce(1, dkv, g=dkvb.view(B, n_tok * 2 * sd), M=B, C=n_tok * 2 * sd)      # the tokens are shared: sum over the batch
             dtok_t = self._empty(n_tok, tokdim)
             self._lin_bwd(tok_t, G.wkv, dkv.view(n_tok, 2 * sd), n_tok, dx=dtok_t)
+            # (this encoder may run twice in a step, see use_style_loss: whatever is written rather than accumulated goes
+            # through a buffer of this call and is then added to the gradient)
             unused = torch.zeros(tokdim, dtype=torch.float32, device=self.device)
-            T.colreduce(1, unused, g=dtok_t, a=tok_t, act='tanh', dy_out=G.dtokens, M=n_tok, C=tokdim)
+            dtok = self._empty(n_tok, tokdim)
+            T.colreduce(1, unused, g=dtok_t, a=tok_t, act='tanh', dy_out=dtok, M=n_tok, C=tokdim)
+            T.axpby(dtok, G.dtokens, alpha=1.0, beta=1.0, M=n_tok, D=tokdim)
             self._lin_bwd(proj, G.wq, dq, B, dx=dproj, accumulate=True)
             dpre = self._empty(B, u)
             T.colreduce(1, G.rnn_proj.db, g=dproj, a=proj, act='tanh', dy_out=dpre, M=B, C=u)
@@ -484,17 +489,20 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 patches, z, st, (Hi, Wi, Ci, Ho, Wo, pt, pl) = saved[i]
                 M = B * Ho * Wo
                 dz = self._empty(M, conv.N)
-                T.colreduce(2, norm.dbeta, norm.dgamma, z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz,
+                sums = self.store.zeros(2, conv.N)           # this call's own sum(dy) and sum(dy * xhat): bn_bwd reads them
+                T.colreduce(2, sums[0], sums[1], z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz,
                             M=M, C=conv.N, scale=st[2], shift=st[3])
-                T.bn_bwd(dz, z, st[0], st[1], norm.gamma, norm.dgamma, norm.dbeta, dz, M=M, C=conv.N)
-                if i == 0:
+                T.bn_bwd(dz, z, st[0], st[1], norm.gamma, sums[1], sums[0], dz, M=M, C=conv.N)
+                T.axpby(sums[0].view(1, -1), norm.dbeta.view(1, -1), alpha=1.0, beta=1.0, M=1, D=conv.N)
+                T.axpby(sums[1].view(1, -1), norm.dgamma.view(1, -1), alpha=1.0, beta=1.0, M=1, D=conv.N)
+                if i == 0 and not input_grad:
                     self._lin_bwd(patches, conv, dz, M)
                 else:
                     dp = self._empty(M, conv.K)
                     self._lin_bwd(patches, conv, dz, M, dx=dp)
                     g = self._empty(B * Hi * Wi, Ci)
                     T.col2im(dp, g, B, Hi, Wi, Ci, Ho, Wo, 3, s, pt, pl)
-            return None
+            return g if input_grad else None
 
         tape.append(backward)
         return out, attn
@@ -519,8 +527,10 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         return self._stack_fwd(self.enc_blocks, cat0, B, N, key_mask, de, tape, enc_attn, self.enc_names), key_mask
 
     def train_step(self, tts_mel, tts_phonemes, tts_stop, tts_speaker=None, train_text_encoder=True, train_style_encoder=True,
-                   train_decoder=True, apply=True):
-        """The TTS half of train_models_step (traning_steps.py:22-56) without the style loss.
+                   train_decoder=True, apply=True, use_style_loss=False):
+        """The TTS half of train_models_step (traning_steps.py:22-56).  use_style_loss: the style encoder runs a second time
+        over the model's own post-net output and the mean squared distance of the two style embeddings joins the loss
+        (traning_steps.py:41-49).
         tts_mel [B, T + 1, C] (start / end vectors included), tts_phonemes [B, N] int, tts_stop [B, T + 1] int,
         tts_speaker [B, 1, speaker_embed_dim] or None.  Returns the reference's model_out entries that exist after the TTS
         half: final_output, mel_linear, stop_prob, decoder_attention, text_encoder_attention, text_enc_output, tts_loss,
@@ -622,6 +632,15 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         final = self._empty(Mt, C)
         post_tape = []
         self._cnn_bn_fwd(self.postnet, mel, Mt, Tt, final, post_tape)
+        style_tape, style_loss, d_g2 = [], None, None
+        if use_style_loss:
+            if self.gst is None:
+                raise ValueError(f"use_style_loss needs a style system, not '{self.system_type}'")
+            g2, _ = self._gst_fwd(final.view(B, Tt, C), B, Tt, style_tape, input_grad=True)
+            style_loss = torch.zeros(1, dtype=torch.float32, device=dev)
+            d_g2 = self._empty(B, sd)
+            ops.check(ops._lib.load().estts_mse(g2.data_ptr(), gst_out.data_ptr(), B * sd, style_loss.data_ptr(), d_g2.data_ptr(), 1.0,
+                                                ops._stream()), 'estts_mse')
 
         # ---- losses over the first mel_len frames (traning_steps.py:33-40, utils/losses.py)
         Ml = B * mel_len
@@ -644,6 +663,8 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         # (scaled_xent was given scale = weight / M for its gradient; its loss value carries the weight too)
         loss_vals = torch.stack([losses[0], losses[1] / lw[1], losses[2]])
         tts_loss = loss_vals[0] * lw[0] + loss_vals[1] * lw[1] + loss_vals[2] * lw[2]
+        if style_loss is not None:
+            tts_loss = tts_loss + style_loss[0]
 
         # ---- backward
         def spread(g_l, width):
@@ -658,7 +679,12 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         T.masked_mae_bwd(target2, final_l, dfinal_l, lw[0])
         dmel_l = self._empty(Ml, C)
         T.masked_mae_bwd(target2, mel_l, dmel_l, lw[2])
-        dmel = post_tape[0](spread(dfinal_l, C))
+        dfinal = spread(dfinal_l, C)
+        if style_loss is not None:             # the second style pass read the whole post-net output
+            if dfinal is dfinal_l:
+                dfinal = dfinal_l.clone()
+            T.axpby(style_tape[0](d_g2).view(Mt, C), dfinal, alpha=1.0, beta=1.0, M=Mt, D=C)
+        dmel = post_tape[0](dfinal)
         T.axpby(spread(dmel_l, C), dmel, alpha=1.0, beta=1.0, M=Mt, D=C)
         self._lin_bwd(mel, self.stop, spread(dstop_l, 4), Mt, dx=dmel, accumulate=True)
         d_dec = self._empty(Md, dd)
@@ -672,6 +698,8 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             d_enc3 = d_enc.view(B, N, self.enc_dim)
             for b in range(B):
                 T.colreduce(1, d_gst[b], g=d_enc3[b][:, de:de + sd], M=N, C=sd)
+            if style_loss is not None:         # d style_loss / d (first embedding) = -d style_loss / d (second embedding)
+                T.axpby(d_g2, d_gst, alpha=-1.0, beta=1.0, M=B, D=sd)
             gst_tape[0](d_gst)
         g = d_enc[:, :de].contiguous()
         for bw in reversed(enc_tape):
@@ -684,7 +712,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 'decoder_attention': dec_attn, 'text_encoder_attention': enc_attn, 'text_enc_output': text_out.reshape(B, N, de),
                 'gst_output': None if gst_out is None else gst_out.view(B, 1, sd),
                 'gst_encoder_attention': None if gst_attn is None else {'RefEncoderGST_attention': gst_attn}, 'decoder_output': dec_out.reshape(B, Tq, dd), 'linear': mel.view(B, Tt, C),
-                'tts_loss': tts_loss, 'style_loss': 0, 'loss': tts_loss,
+                'tts_loss': tts_loss, 'style_loss': 0 if style_loss is None else style_loss[0], 'loss': tts_loss,
                 'losses': {'output': loss_vals[0], 'stop_prob': loss_vals[1], 'mel_linear': loss_vals[2]},
                 'reduced_target': tar_mel}
 

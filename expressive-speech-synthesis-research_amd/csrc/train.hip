@@ -867,6 +867,27 @@ __global__ __launch_bounds__(MI_THREADS) void club_terms_kernel(const float* __r
     if (threadIdx.x == 0) { out[0] = pos / B; out[1] = (pos - neg) / B; }
 }
 
+// l2_loss of the style loss (TransformerTTS/utils/losses.py:65-68): Keras MeanSquaredError over every element, one workgroup.
+__global__ __launch_bounds__(MI_THREADS) void mse_kernel(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                         float* __restrict__ loss, float* __restrict__ da, float scale) {
+    __shared__ float red[MI_THREADS / 64];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += MI_THREADS) {
+        const float d = a[i] - b[i];
+        s += d * d;
+        da[i] = scale * 2.0f * d / n;
+    }
+    s = mi_block_sum(s, red);
+    if (threadIdx.x == 0) loss[0] += s / n;
+}
+
+extern "C" int estts_mse(const float* a, const float* b, int32_t n, float* loss, float* da, float scale, void* stream) {
+    ESTTS_CHECK_ARG(a && b && loss && da && n > 0, "estts_mse: bad arguments");
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, a, b, n, loss, da, scale);
+    ESTTS_CHECK_LAUNCH("estts_mse");
+    return 0;
+}
+
 extern "C" int estts_mine_divergence(const float* joint, const float* marginal, int32_t n, int32_t div_type, const float* betas,
                                      int32_t n_beta, float smoothing, const float* prev_exp, float* next_exp, float* mi,
                                      float* d_joint, float* d_marginal, float gscale, void* stream) {

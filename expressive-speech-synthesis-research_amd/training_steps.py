@@ -12,12 +12,9 @@ def train_models_step(tts_mel, tts_phonemes, tts_stop, tts_speaker,
                       mine_mel, mine_phonemes, mine_stop, mine_speaker,
                       tts_model, mine_model, mi_holder,
                       train_text_encoder=True, train_style_encoder=True, train_decoder=True, use_style_loss=False):
-    if use_style_loss:
-        # (the second pass of the style encoder over the model's own output, traning_steps.py:41-49, needs the gradient of
-        # the reference encoder's first layer with respect to its input as well)
-        raise NotImplementedError('use_style_loss is not implemented')
     model_out = tts_model.train_step(tts_mel, tts_phonemes, tts_stop, tts_speaker, train_text_encoder=train_text_encoder,
-                                     train_style_encoder=train_style_encoder, train_decoder=train_decoder)
+                                     train_style_encoder=train_style_encoder, train_decoder=train_decoder,
+                                     use_style_loss=use_style_loss)
     tts_loss = model_out['tts_loss']
     # the mutual-information term enters the total as a number: mi_holder['mi_loss'] was computed by the heads in the previous
     # step, outside this step's tape, so it moves the reported loss and no gradient (traning_steps.py:52-55)
@@ -37,5 +34,5 @@ def train_models_step(tts_mel, tts_phonemes, tts_stop, tts_speaker,
         model_out.update({'mi_loss': dict(mi_loss_gather)})
         mi_holder.update({'mi_loss': sum(mi_loss_gather.values()), 'exp_terms': exp_terms})
 
-    model_out.update({'tts_loss': tts_loss, 'style_loss': 0, 'loss': total_loss})
+    model_out.update({'tts_loss': tts_loss, 'loss': total_loss})
     return model_out

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 23
+#define ESTTS_ABI_VERSION 24
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -527,6 +527,12 @@ int estts_im2col(const float* x, float* out, int32_t ldo, int32_t B, int32_t H, 
                  int32_t kh, int32_t kw, int32_t stride, int32_t pad_t, int32_t pad_l, void* stream);
 int estts_col2im(const float* dp, int32_t ldp, float* dx, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho, int32_t Wo,
                  int32_t kh, int32_t kw, int32_t stride, int32_t pad_t, int32_t pad_l, void* stream);
+
+/* Mean squared error over n contiguous elements (small tensors: one workgroup): loss[0] += mean((a - b)^2),
+ * da[i] = scale * 2 (a[i] - b[i]) / n (the gradient with respect to a; the one with respect to b is its negative).
+ * Replaces: l2_loss between the two style embeddings, TransformerTTS/utils/losses.py:65-68 as used at
+ * TransformerTTS/model/traning_steps.py:41-49. */
+int estts_mse(const float* a, const float* b, int32_t n, float* loss, float* da, float scale, void* stream);
 
 /* Mutual-information estimate of MINE from the statistics network's scores on the joint and the marginal samples of one
  * batch (contiguous [n] each), with its gradient, in one single-workgroup launch.

@@ -212,8 +212,11 @@ def _bn_train_nd(x, w, p, c, dims):
     """Keras BatchNormalization(training=True) with statistics over `dims` (channels last)."""
     mean = x.mean(dim=dims)
     var = x.var(dim=dims, unbiased=False)
-    c.new_stats[p + '.moving_mean'] = (w[p + '.moving_mean'] * 0.99 + mean.detach() * 0.01).numpy()
-    c.new_stats[p + '.moving_variance'] = (w[p + '.moving_variance'] * 0.99 + var.detach() * 0.01).numpy()
+    # (a layer that runs twice in one step, the style loss's second pass, moves its statistics twice)
+    mm = c.new_stats.get(p + '.moving_mean', w[p + '.moving_mean'].detach().numpy())
+    mv = c.new_stats.get(p + '.moving_variance', w[p + '.moving_variance'].detach().numpy())
+    c.new_stats[p + '.moving_mean'] = np.asarray(mm) * 0.99 + mean.detach().numpy() * 0.01
+    c.new_stats[p + '.moving_variance'] = np.asarray(mv) * 0.99 + var.detach().numpy() * 0.01
     return (x - mean) / torch.sqrt(var + 1e-3) * w[p + '.gamma'] + w[p + '.beta']
 
 
@@ -249,8 +252,8 @@ def scaled_crossentropy(targets, logits, index=2, scaling=1.0):
 
 
 def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_embed=None, r=1, masks=None, head_keep=None,
-                              prenet_masks=None, gates=None, stop_scaling=1.0, dtype=torch.float64):
-    """One forward + backward of the TTS half of train_models_step.  tar_mel: the decoder input (every r-th frame of
+                              prenet_masks=None, gates=None, stop_scaling=1.0, dtype=torch.float64, use_style_loss=False):
+    """One forward + backward of the TTS half of train_models_step (use_style_loss: traning_steps.py:41-49).  tar_mel: the decoder input (every r-th frame of
     tar[:, :-1]), tar_real / tar_stop: tar[:, 1:] / stop[:, 1:] (AutoregressiveTransformer.input_reshape).
     masks / head_keep / prenet_masks / gates as in forward_train_step; gates end with the sign arrays of the two MAE losses
     (post-net output, linear output).  Returns losses, outputs, grads {name: ndarray} and the new moving statistics."""
@@ -317,6 +320,11 @@ def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_e
     mel = proj.reshape(B, Tq * r, mc)
     stop = F.linear(mel, wt['decoder_postnet.stop_linear.kernel'].t(), wt['decoder_postnet.stop_linear.bias'])
     final = _cnn_res_norm(mel, wt, 'decoder_postnet.conv_blocks', cfg['postnet_conv_layers'], 'tanh', 'linear', 'causal', 'batch', c)
+    l_style = None
+    if use_style_loss:
+        gst2, _ = _gst_train(final, wt, 'style_encoder', len(cfg['ref_encoder_filters']), cfg['ref_encoder_strides'],
+                             cfg['gst_multi_num_heads'], c)
+        l_style = ((gst2 - gst_out) ** 2).mean()
     L = tar_real.shape[1]
     l_out = masked_mae(tar_real, final[:, :L], None if signs is None else signs[0])
     l_stop = scaled_crossentropy(tar_stop, stop[:, :L], 2, stop_scaling)
@@ -324,10 +332,12 @@ def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_e
     if c.gates:
         raise ValueError(f'{len(c.gates)} gate arrays left over: the gate list does not match this model')
     loss = l_out + l_stop + l_lin
+    if l_style is not None:
+        loss = loss + l_style
     loss.backward()
     grads = {k: (t.grad.numpy() if t.grad is not None else np.zeros(t.shape)) for k, t in wt.items() if t.requires_grad}
-    return {'loss': float(loss.detach()), 'losses': {'output': float(l_out.detach()), 'stop_prob': float(l_stop.detach()),
-                                                      'mel_linear': float(l_lin.detach())},
+    return {'loss': float(loss.detach()), 'style_loss': None if l_style is None else float(l_style.detach()),
+            'losses': {'output': float(l_out.detach()), 'stop_prob': float(l_stop.detach()), 'mel_linear': float(l_lin.detach())},
             'final_output': final.detach().numpy(), 'mel_linear': mel.detach().numpy(), 'stop_prob': stop.detach().numpy(),
             'gst_output': None if gst_out is None else gst_out.detach().numpy(), 'text_enc_output': text_out.detach().numpy(),
             'decoder_attention': [a.detach().numpy() for a in dec_attn], 'grads': grads, 'new_stats': c.new_stats}
