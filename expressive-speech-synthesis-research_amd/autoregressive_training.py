@@ -11,8 +11,10 @@ decoder step), the stop-token head and the causal post-net.
 The reference's three flags train_text_encoder / train_style_encoder / train_decoder select Keras' `training=` mode of the
 three sub-networks (dropout, head drop, BatchNorm batch statistics), not which variables receive gradients: the tape
 differentiates all trainable variables either way (traning_steps.py:54-55).  The shipped configuration sets all three
-True, and that is the mode implemented here; a False flag raises.
+True; a False flag runs that sub-network as Keras would with training=False (no dropout, no head drop, BatchNormalization on
+its moving statistics) and still differentiates it.
 """
+import contextlib
 import math
 
 import numpy as np
@@ -396,7 +398,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             T.im2col(y, patches, B, H, W, Cin, Ho, Wo, 3, s, pt, pl)
             z = self._empty(M, conv.N)
             self._lin_fwd(patches, conv, z, M)
-            st = self._bn_train(z, norm, M, conv.N)
+            st = self._bn_stats(z, norm, M, conv.N)
             nxt = self._empty(M, conv.N)
             T.affine_act(z, nxt, st[2], st[3], 'relu', M=M, C=conv.N)
             if self.gate_log is not None:
@@ -404,6 +406,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             saved.append((patches, z, st, (H, W, Cin, Ho, Wo, pt, pl)))
             y, H, W, Cin = nxt, Ho, Wo, conv.N
         steps, feat, u, sd, Hh = H, W * Cin, G.u, G.sd, G.H
+        batch = self._bn_batch
         Ms = B * steps
         seq = y.view(Ms, feat)                                   # rows (b, t); features (w, c) as Keras' reshape gives them
         gi = self._empty(Ms, 3 * u)
@@ -492,7 +495,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 sums = self.store.zeros(2, conv.N)           # this call's own sum(dy) and sum(dy * xhat): bn_bwd reads them
                 T.colreduce(2, sums[0], sums[1], z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz,
                             M=M, C=conv.N, scale=st[2], shift=st[3])
-                T.bn_bwd(dz, z, st[0], st[1], norm.gamma, sums[1], sums[0], dz, M=M, C=conv.N)
+                self._bn_input_grad(batch, dz, z, st, norm, sums, dz, M, conv.N)
                 T.axpby(sums[0].view(1, -1), norm.dbeta.view(1, -1), alpha=1.0, beta=1.0, M=1, D=conv.N)
                 T.axpby(sums[1].view(1, -1), norm.dgamma.view(1, -1), alpha=1.0, beta=1.0, M=1, D=conv.N)
                 if i == 0 and not input_grad:
@@ -508,6 +511,18 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         return out, attn
 
     # ------------------------------------------------------------------ the training step
+    @contextlib.contextmanager
+    def _submode(self, training):
+        """Keras' `training=` of a sub-network (traning_steps.py:24-29): False switches its dropout and head drop off and its
+        BatchNormalization layers to their moving statistics; the gradients flow either way."""
+        saved = (self.dropout_rate, self.drop_n_heads, self._bn_batch)
+        if not training:
+            self.dropout_rate, self.drop_n_heads, self._bn_batch = 0.0, 0, False
+        try:
+            yield
+        finally:
+            self.dropout_rate, self.drop_n_heads, self._bn_batch = saved
+
     def _encode(self, tokens, B, N, tape, enc_attn):
         """Text encoder in training mode -> (text_out [Me, de] view, key_mask)."""
         de, Me = self.de, B * N
@@ -515,11 +530,11 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         cat0 = self._empty(Me, 2 * de)
         x0 = cat0[:, :de]
         ops.embed_posenc(tokens, self.emb, self.pe_enc, None, x0, key_mask, math.sqrt(np.float32(de)))
-        site0 = self._next_site()
-        T.dropout(x0, x0, self.dropout_rate, self._seed_now, site0, M=Me, D=de)
+        site0, rate0 = self._next_site(), self.dropout_rate
+        T.dropout(x0, x0, rate0, self._seed_now, site0, M=Me, D=de)
 
         def embed_backward(dx):
-            T.dropout(dx, dx, self.dropout_rate, self._seed_now, site0, M=Me, D=de)
+            T.dropout(dx, dx, rate0, self._seed_now, site0, M=Me, D=de)
             T.embed_bwd(tokens, dx, self.demb, math.sqrt(np.float32(de)))
             return None
 
@@ -535,8 +550,6 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         tts_speaker [B, 1, speaker_embed_dim] or None.  Returns the reference's model_out entries that exist after the TTS
         half: final_output, mel_linear, stop_prob, decoder_attention, text_encoder_attention, text_enc_output, tts_loss,
         loss, losses, reduced_target."""
-        if not (train_text_encoder and train_decoder):
-            raise NotImplementedError('sub-networks in inference mode inside a training step are not implemented')
         dev, C, r = self.device, self.mel_channels, self.r
         tokens = torch.as_tensor(tts_phonemes, device=dev).to(torch.int32).contiguous()
         B, N = tokens.shape
@@ -558,14 +571,14 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         st.clear_gradients()
 
         # ---- encoder output [text | speaker]
-        text_out, _ = self._encode(tokens, B, N, enc_tape, enc_attn)
+        with self._submode(train_text_encoder):
+            text_out, _ = self._encode(tokens, B, N, enc_tape, enc_attn)
         enc = self._empty(Me, self.enc_dim)
         enc[:, :de].copy_(text_out)
         gst_tape, gst_out, gst_attn, sd = [], None, None, 0
         if self.gst is not None:
-            if not train_style_encoder:
-                raise NotImplementedError('sub-networks in inference mode inside a training step are not implemented')
-            gst_out, gst_attn = self._gst_fwd(tar_mel, B, Tq, gst_tape)
+            with self._submode(train_style_encoder):
+                gst_out, gst_attn = self._gst_fwd(tar_mel, B, Tq, gst_tape)
             sd = self.gst.sd
             enc.view(B, N, self.enc_dim)[:, :, de:de + sd].copy_(gst_out[:, None, :].expand(B, N, sd))
         if self.system_type in ('speaker_style_text', 'speaker_text'):
@@ -593,11 +606,12 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         cat = self._empty(Md, 2 * dd)
         y0 = cat[:, :dd]
         T.affine_act(p2, y0, self.dec_scale, self.dec_shift, None, residual=pe, r_mod=Tq, M=Md, C=dd)
-        site1 = self._next_site()
-        T.dropout(y0, y0, self.dropout_rate, self._seed_now, site1, M=Md, D=dd)
+        with self._submode(train_decoder):
+            site1, rate1 = self._next_site(), self.dropout_rate
+        T.dropout(y0, y0, rate1, self._seed_now, site1, M=Md, D=dd)
 
         def prenet_backward(dy0):
-            T.dropout(dy0, dy0, self.dropout_rate, self._seed_now, site1, M=Md, D=dd)
+            T.dropout(dy0, dy0, rate1, self._seed_now, site1, M=Md, D=dd)
             T.axpby(dy0, dy0, alpha=math.sqrt(np.float32(dd)) * inv_keep, beta=0.0, M=Md, D=dd)
             T.colreduce(1, self.prenet2.db, g=dy0, a=p2, act='relu', dy_out=dy0, M=Md, C=dd)
             T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.backward_precision)
@@ -609,17 +623,18 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         # ---- decoder blocks (layers.py:357-376)
         dec_tape = []
         n_blocks = len(self.dec_blocks)
-        for i, (S, Cx, tail) in enumerate(self.dec_blocks):
-            cat2 = self._empty(Md, 2 * dd)
-            self._sarn_fwd(S, cat, B, Tq, dec_mask, cat2[:, :dd], dec_tape, causal=True)
-            x2 = self._empty(Md, dd)
-            dec_attn[self.dec_names[i]] = self._carn_fwd(Cx, cat2, enc, d_enc, B, Tq, N, enc_mask, x2, dec_tape)
-            nxt = self._empty(Md, 2 * dd) if i + 1 < n_blocks else self._empty(Md, dd)
-            if isinstance(tail, _Ffn):
-                self._ffn_fwd(tail, x2, Md, nxt[:, :dd], dec_tape)
-            else:
-                self._cnn_bn_fwd(tail, x2, Md, Tq, nxt[:, :dd], dec_tape)
-            cat = nxt
+        with self._submode(train_decoder):
+            for i, (S, Cx, tail) in enumerate(self.dec_blocks):
+                cat2 = self._empty(Md, 2 * dd)
+                self._sarn_fwd(S, cat, B, Tq, dec_mask, cat2[:, :dd], dec_tape, causal=True)
+                x2 = self._empty(Md, dd)
+                dec_attn[self.dec_names[i]] = self._carn_fwd(Cx, cat2, enc, d_enc, B, Tq, N, enc_mask, x2, dec_tape)
+                nxt = self._empty(Md, 2 * dd) if i + 1 < n_blocks else self._empty(Md, dd)
+                if isinstance(tail, _Ffn):
+                    self._ffn_fwd(tail, x2, Md, nxt[:, :dd], dec_tape)
+                else:
+                    self._cnn_bn_fwd(tail, x2, Md, Tq, nxt[:, :dd], dec_tape)
+                cat = nxt
         dec_out = cat[:, :dd]
 
         # ---- projections: r frames per decoder step, stop head, causal post-net
@@ -631,12 +646,14 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         self._lin_fwd(mel, self.stop, stop4, Mt)
         final = self._empty(Mt, C)
         post_tape = []
-        self._cnn_bn_fwd(self.postnet, mel, Mt, Tt, final, post_tape)
+        with self._submode(train_decoder):
+            self._cnn_bn_fwd(self.postnet, mel, Mt, Tt, final, post_tape)
         style_tape, style_loss, d_g2 = [], None, None
         if use_style_loss:
             if self.gst is None:
                 raise ValueError(f"use_style_loss needs a style system, not '{self.system_type}'")
-            g2, _ = self._gst_fwd(final.view(B, Tt, C), B, Tt, style_tape, input_grad=True)
+            with self._submode(train_style_encoder):
+                g2, _ = self._gst_fwd(final.view(B, Tt, C), B, Tt, style_tape, input_grad=True)
             style_loss = torch.zeros(1, dtype=torch.float32, device=dev)
             d_g2 = self._empty(B, sd)
             ops.check(ops._lib.load().estts_mse(g2.data_ptr(), gst_out.data_ptr(), B * sd, style_loss.data_ptr(), d_g2.data_ptr(), 1.0,

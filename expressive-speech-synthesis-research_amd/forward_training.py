@@ -246,6 +246,7 @@ class ForwardTransformerTrainer:
         # tensors) and then the signs (pred - target) of the MAE losses, so that an oracle can differentiate the same
         # piecewise-linear function the device did
         self.gate_log = None
+        self._bn_batch = True      # BatchNormalization on batch statistics (training=True); False: on its moving statistics
         self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
 
     def __init__(self, weights, config, device='cuda', precision='bf16x3', seed=0, process_group=None, bucket_mb=25):
@@ -410,6 +411,24 @@ class ForwardTransformerTrainer:
         T.bn_finalize(sums[0], sums[1], z, M, C, norm.gamma, norm.beta, norm.mm, norm.mv, st[0], st[1], st[2], st[3])
         return st
 
+    def _bn_eval(self, norm, C):
+        """(mean, rstd, scale, shift) of a BatchNormalization layer in inference mode: its moving statistics, left untouched
+        (estts_bn_finalize on one "row" whose value is the moving mean and whose squared deviation is the moving variance)."""
+        st = self._empty(4, C)
+        T.bn_finalize(self.store.zeros(C), norm.mv, norm.mm, 1, C, norm.gamma, norm.beta, None, None, st[0], st[1], st[2], st[3])
+        return st
+
+    def _bn_stats(self, z, norm, M, C):
+        return self._bn_train(z, norm, M, C) if self._bn_batch else self._bn_eval(norm, C)
+
+    def _bn_input_grad(self, batch, dy, z, st, norm, sums, dz, M, C):
+        """Gradient with respect to the normalised tensor given sum(dy) and sum(dy * xhat) in `sums` (beta, gamma order):
+        the batch-statistics form, or dy * scale when the layer ran on its moving statistics."""
+        if batch:
+            T.bn_bwd(dy, z, st[0], st[1], norm.gamma, sums[1], sums[0], dz, M=M, C=C)
+        else:
+            T.affine_act(dy, dz, st[2], self.store.zeros(C), None, M=M, C=C)
+
     def _cnn_bn_fwd(self, Cb, x, M, seg, out, tape):
         """CNNResNorm with BatchNormalization in training mode (layers.py:35-47); x [M, cin] view, out [M, cout] view."""
         n = len(Cb.convs)
@@ -417,7 +436,7 @@ class ForwardTransformerTrainer:
         for i, (conv, norm, act) in enumerate(zip(Cb.convs, Cb.norms[:n], Cb.acts)):
             z = self._empty(M, conv.N)
             self._lin_fwd(h, conv, z, M, seg)
-            st = self._bn_train(z, norm, M, conv.N)
+            st = self._bn_stats(z, norm, M, conv.N)
             nxt = self._empty(M, conv.N)
             T.affine_act(z, nxt, st[2], st[3], act, residual=x if i == n - 1 else None, M=M, C=conv.N)
             if self.gate_log is not None and act == 'relu':
@@ -431,13 +450,14 @@ class ForwardTransformerTrainer:
         s = h                                           # inputs + last activation
         last = Cb.norms[n]
         C = Cb.convs[-1].N
-        st_last = self._bn_train(s, last, M, C)
+        st_last = self._bn_stats(s, last, M, C)
         T.affine_act(s, out, st_last[2], st_last[3], None, M=M, C=C)
+        batch = self._bn_batch
 
         def backward(dout):
             ds = self._empty(M, C)
             T.colreduce(2, last.dbeta, last.dgamma, z=s, g=dout, mean=st_last[0], rstd=st_last[1], M=M, C=C)
-            T.bn_bwd(dout, s, st_last[0], st_last[1], last.gamma, last.dgamma, last.dbeta, ds, M=M, C=C)
+            self._bn_input_grad(batch, dout, s, st_last, last, (last.dbeta, last.dgamma), ds, M, C)
             g, dx = ds, None
             for i in reversed(range(n)):
                 conv, norm, act = Cb.convs[i], Cb.norms[i], Cb.acts[i]
@@ -445,7 +465,7 @@ class ForwardTransformerTrainer:
                 dz = self._empty(M, conv.N)
                 T.colreduce(2, norm.dbeta, norm.dgamma, z=z, g=g, act=act, mean=st[0], rstd=st[1], dy_out=dz, M=M, C=conv.N,
                             scale=st[2], shift=st[3])
-                T.bn_bwd(dz, z, st[0], st[1], norm.gamma, norm.dgamma, norm.dbeta, dz, M=M, C=conv.N)
+                self._bn_input_grad(batch, dz, z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N)
                 if i > 0:
                     g = self._empty(M, conv.lin.cin)
                     self._lin_bwd(hin, conv, dz, M, seg, dx=g)

@@ -35,6 +35,7 @@ class _Ctx:
         self.head_keep = list(head_keep) if head_keep is not None else None
         self.new_stats = new_stats
         self.gates = list(gates) if gates is not None else None
+        self.training = True        # False: the enclosing sub-network runs with Keras' training=False
 
     def relu(self, x):
         """ReLU, or -- when the branches another implementation took are given -- the linear piece x * gate it evaluated, so
@@ -50,11 +51,13 @@ class _Ctx:
     def dropout(self, x):
         if self.masks is None:
             return x
-        m = self.masks.pop(0)
+        m = self.masks.pop(0)           # (an inference-mode sub-network still owns its place in the mask list)
+        if not self.training:
+            return x
         return x * torch.as_tensor(np.asarray(m), dtype=x.dtype).reshape(x.shape)
 
     def heads(self, ctx4):
-        if self.head_keep is None:
+        if self.head_keep is None or not self.training:
             return ctx4
         k = torch.as_tensor(np.asarray(self.head_keep.pop(0)), dtype=ctx4.dtype)
         return ctx4 * k[:, :, None, None]
@@ -66,6 +69,8 @@ def _ln(x, w, p):
 
 def _bn_train(x, w, p, c):
     """Keras BatchNormalization(training=True) on (B, T, C): statistics over (B, T), eps 1e-3, momentum 0.99."""
+    if not c.training:
+        return (x - w[p + '.moving_mean']) / torch.sqrt(w[p + '.moving_variance'] + 1e-3) * w[p + '.gamma'] + w[p + '.beta']
     mean = x.mean(dim=(0, 1))
     var = x.var(dim=(0, 1), unbiased=False)
     c.new_stats[p + '.moving_mean'] = (w[p + '.moving_mean'] * 0.99 + mean.detach() * 0.01).numpy()
@@ -210,6 +215,8 @@ def _mha_cross(kv_in, q_in, mask, w, p, H, c):
 
 def _bn_train_nd(x, w, p, c, dims):
     """Keras BatchNormalization(training=True) with statistics over `dims` (channels last)."""
+    if not c.training:
+        return (x - w[p + '.moving_mean']) / torch.sqrt(w[p + '.moving_variance'] + 1e-3) * w[p + '.gamma'] + w[p + '.beta']
     mean = x.mean(dim=dims)
     var = x.var(dim=dims, unbiased=False)
     # (a layer that runs twice in one step, the style loss's second pass, moves its statistics twice)
@@ -252,7 +259,8 @@ def scaled_crossentropy(targets, logits, index=2, scaling=1.0):
 
 
 def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_embed=None, r=1, masks=None, head_keep=None,
-                              prenet_masks=None, gates=None, stop_scaling=1.0, dtype=torch.float64, use_style_loss=False):
+                              prenet_masks=None, gates=None, stop_scaling=1.0, dtype=torch.float64, use_style_loss=False,
+                              train_text_encoder=True, train_style_encoder=True, train_decoder=True):
     """One forward + backward of the TTS half of train_models_step (use_style_loss: traning_steps.py:41-49).  tar_mel: the decoder input (every r-th frame of
     tar[:, :-1]), tar_real / tar_stop: tar[:, 1:] / stop[:, 1:] (AutoregressiveTransformer.input_reshape).
     masks / head_keep / prenet_masks / gates as in forward_train_step; gates end with the sign arrays of the two MAE losses
@@ -275,9 +283,11 @@ def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_e
     B, N = tokens.shape
     pad = (tokens == 0).to(dt)
     x = F.embedding(tokens, wt['text_encoder_prenet.embeddings'])
+    c.training = train_text_encoder
     text_out, text_attn = _sa_blocks(x, pad[:, None, None, :], wt, 'text_encoder', cfg['encoder_model_dimension'],
                                      cfg['encoder_num_heads'], cfg['encoder_dense_blocks'], cfg['encoder_max_position_encoding'], c)
     parts, gst_out = [text_out], None
+    c.training = train_style_encoder
     if st in ('speaker_style_text', 'style_text'):
         gst_out, _ = _gst_train(tar_mel, wt, 'style_encoder', len(cfg['ref_encoder_filters']), cfg['ref_encoder_strides'],
                                 cfg['gst_multi_num_heads'], c)
@@ -299,6 +309,7 @@ def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_e
     d = cfg['decoder_model_dimension']
     pe = _pe(cfg['decoder_max_position_encoding'], d, dt)
     y = y * math.sqrt(float(np.float32(d))) + wt['decoder.pos_encoding_scalar'] * pe[None, :Tq * r:r, :]
+    c.training = train_decoder
     y = c.dropout(y)
     dec_attn = []
     for i, H in enumerate(cfg['decoder_num_heads']):
@@ -321,6 +332,7 @@ def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_e
     stop = F.linear(mel, wt['decoder_postnet.stop_linear.kernel'].t(), wt['decoder_postnet.stop_linear.bias'])
     final = _cnn_res_norm(mel, wt, 'decoder_postnet.conv_blocks', cfg['postnet_conv_layers'], 'tanh', 'linear', 'causal', 'batch', c)
     l_style = None
+    c.training = train_style_encoder
     if use_style_loss:
         gst2, _ = _gst_train(final, wt, 'style_encoder', len(cfg['ref_encoder_filters']), cfg['ref_encoder_strides'],
                              cfg['gst_multi_num_heads'], c)

@@ -66,8 +66,10 @@ def tight_compare(model, ref, tol=1e-3, tol_qk=1e-2, floor_qk=5e-4):
         r = np.asarray(r).reshape(a.shape)
         scale = np.abs(r).max()
         diff = float(np.abs(a - r).max())
-        if '.sarn.mha.wq.' in k or '.sarn.mha.wk.' in k:
-            assert diff < tol_qk * scale + floor_qk, (k, diff, scale)
+        if '.sarn.mha.wq.' in k or '.sarn.mha.wk.' in k or k.startswith('decoder_prenet.'):
+            # (the prenet sits behind the first decoder self-attention and inherits the rounding of its query / key gradients:
+            # 1e-4 .. 2e-4 with dropout on, up to 5e-3 when the decoder runs in inference mode)
+            assert diff < tol_qk * scale + (floor_qk if '.sarn.' in k else 0.0), (k, diff, scale)
             continue
         if scale < 1e-7:
             zeros.append((float(np.abs(a).max()), k))
@@ -84,7 +86,8 @@ def tight_compare(model, ref, tol=1e-3, tol_qk=1e-2, floor_qk=5e-4):
     return errs
 
 
-def reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prenet_rate, head_drop, seed, use_style_loss=False):
+def reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prenet_rate, head_drop, seed, use_style_loss=False,
+                   flags=(True, True, True)):
     """The oracle on the draws and branches of the device step that just ran."""
     from estts import train_ops as T
     B, N = tokens.shape
@@ -123,6 +126,10 @@ def reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prene
             heads += [H, H]
         if use_style_loss:
             heads.append(cfg['gst_multi_num_heads'])
+        te, ts, td = flags              # the device draws head masks only where the sub-network is in training mode
+        live = [te] * len(cfg['encoder_num_heads']) + ([ts] if 'style' in cfg['system_type'] else [])
+        live += [td] * (2 * len(cfg['decoder_num_heads'])) + ([ts] if use_style_loss else [])
+        heads = [H for H, on in zip(heads, live) if on]
         for H in heads:
             keep = np.ones((B, H))
             for b in range(B):
@@ -131,11 +138,12 @@ def reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prene
     gates = [g.cpu().numpy().astype(np.float64) for g in model.gate_log]
     return OT.autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_embed=spk, r=r, masks=masks,
                                         head_keep=head_keep, prenet_masks=pm, gates=gates, stop_scaling=8.0,
-                                        use_style_loss=use_style_loss)
+                                        use_style_loss=use_style_loss, train_text_encoder=flags[0], train_style_encoder=flags[1],
+                                        train_decoder=flags[2])
 
 
 def check_step(system_type, r, dropout_rate=0.0, prenet_rate=0.0, head_drop=0, dense_blocks=(1, 1), seed=3, trainer=None,
-               use_style_loss=False):
+               use_style_loss=False, flags=(True, True, True)):
     from estts.autoregressive_training import AutoregressiveTransformerTrainer
     cfg = small_cfg(system_type, dropout_rate, dense_blocks)
     w = weights.init_autoregressive_transformer(cfg, seed=11)
@@ -146,8 +154,8 @@ def check_step(system_type, r, dropout_rate=0.0, prenet_rate=0.0, head_drop=0, d
     model._compile(stop_scaling=8.0)
     model.set_constants(reduction_factor=r, decoder_prenet_dropout=prenet_rate, drop_n_heads=head_drop)
     model.gate_log = []
-    out = model.train_step(mel, tokens, stop, spk, apply=False, use_style_loss=use_style_loss)
-    ref = reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prenet_rate, head_drop, seed, use_style_loss)
+    out = model.train_step(mel, tokens, stop, spk, flags[0], flags[1], flags[2], apply=False, use_style_loss=use_style_loss)
+    ref = reference_step(model, w, cfg, tokens, mel, stop, spk, r, dropout_rate, prenet_rate, head_drop, seed, use_style_loss, flags)
     assert abs(float(out['loss']) - ref['loss']) < 2e-5 * max(1.0, abs(ref['loss'])), (float(out['loss']), ref['loss'])
     for k in ('output', 'stop_prob', 'mel_linear'):
         assert abs(float(out['losses'][k]) - ref['losses'][k]) < 2e-5 * max(1.0, ref['losses'][k]), k
@@ -188,6 +196,22 @@ def test_style_loss(head_drop):
         assert np.abs(state[k] - v).max() < 1e-4 * max(1.0, np.abs(v).max()), k
     with pytest.raises(ValueError):
         check_step('speaker_text', 1, use_style_loss=True)
+
+
+@pytest.mark.parametrize('flags', [(False, True, True), (True, False, True), (True, True, False), (False, False, False)])
+def test_sub_networks_in_inference_mode(flags):
+    """train_text_encoder / train_style_encoder / train_decoder = False (traning_steps.py:24-29): that sub-network runs without
+    dropout and head drop and with BatchNormalization on its moving statistics, and is differentiated all the same."""
+    model, ref, out = check_step('speaker_style_text', 2, dropout_rate=0.1, prenet_rate=0.25, head_drop=1, flags=flags)
+    state = model.store.numpy()
+    moved = {k for k in state if k.endswith('moving_mean') and np.abs(state[k] - np.asarray(model_w0(model)[k])).max() > 0}
+    for name, on in zip(('text_encoder', 'style_encoder', 'decoder'), flags):
+        assert any(k.startswith(name) for k in moved) == on, (name, on)
+
+
+def model_w0(model):
+    """The variables the check_step trainer was built from (seed 11 of small_cfg)."""
+    return weights.init_autoregressive_transformer(model.config, seed=11)
 
 
 def test_weights_round_trip_and_adam_step():

@@ -130,5 +130,5 @@ def test_train_models_step(sep_call):
     assert abs(float(out['loss']) - float(out['tts_loss'])) < 0.1 * abs(float(holder['mi_loss'])) + 1.0
     styled = train_models_step(mel, tokens, stop, spk, mel2, tokens2, stop2, spk2, model, heads, holder, True, True, True, True)
     assert float(styled['style_loss']) > 0 and float(styled['tts_loss']) > float(styled['losses']['output'])
-    with pytest.raises(NotImplementedError):         # a sub-network in inference mode inside the training step
-        train_models_step(mel, tokens, stop, spk, mel2, tokens2, stop2, spk2, model, heads, holder, False, True, True, False)
+    frozen = train_models_step(mel, tokens, stop, spk, mel2, tokens2, stop2, spk2, model, heads, holder, False, True, True, False)
+    assert np.isfinite(float(frozen['loss']))        # the text encoder in inference mode inside the training step
