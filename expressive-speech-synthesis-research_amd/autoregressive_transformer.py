@@ -212,7 +212,7 @@ class AutoregressiveTransformer:
                      return_attention=True):
         """AutoregressiveTransformer.py:124-159."""
         if training_text_encoder or training_style_encoder:
-            raise NotImplementedError('training runs through estts.training')
+            raise NotImplementedError('training runs through estts.autoregressive_training.AutoregressiveTransformerTrainer')
         tokens = torch.as_tensor(inputs, device=self.device).to(torch.int32).contiguous()
         B, N = tokens.shape
         dev, f32, de = self.device, dict(dtype=torch.float32, device=self.device), self.de
@@ -252,7 +252,7 @@ class AutoregressiveTransformer:
         """AutoregressiveTransformer.py:161-181.  dropout_seed: seed of the prenet dropout masks (rows of the generator
         are b * Tq + t); None draws the next one of this model's sequence."""
         if training:
-            raise NotImplementedError('training runs through estts.training')
+            raise NotImplementedError('training runs through estts.autoregressive_training.AutoregressiveTransformerTrainer')
         rate = self.decoder_prenet_dropout
         seed = self._next_dropout_seed() if dropout_seed is None else int(dropout_seed) & 0xFFFFFFFF
         dev, f32, dd, r = self.device, dict(dtype=torch.float32, device=self.device), self.dd, self.r

@@ -134,7 +134,7 @@ class ForwardTransformer:
         `max_frames` (optional) fixes T without that read: frames beyond it are dropped, missing ones are padding.
         """
         if training:
-            raise NotImplementedError('training=True runs through estts.training (dropout, batch statistics)')
+            raise NotImplementedError('training=True runs through estts.forward_training.ForwardTransformerTrainer (dropout, batch statistics)')
         tokens = torch.as_tensor(x, device=self.device).to(torch.int32).contiguous()
         B, N = tokens.shape
         if N > self.pe_enc.shape[0]:
