@@ -351,7 +351,8 @@ class AutoregressiveTransformer:
         causal window that ends at time t0 + j."""
         return torch.as_strided(hist, (rows, k * cin), (cin, 1), hist.storage_offset() + t0 * cin)
 
-    def _predict_incremental(self, inp, targets, spk_embed, max_length, encode, verbose, program=True, dropout_seed=None):
+    def _predict_incremental(self, inp, targets, spk_embed, max_length, encode, verbose, program=True, dropout_seed=None,
+                             stop_check_every=8):
         rate = self.decoder_prenet_dropout
         seed = self._next_dropout_seed() if dropout_seed is None else int(dropout_seed) & 0xFFFFFFFF
         dev, f32 = self.device, dict(dtype=torch.float32, device=self.device)
@@ -447,26 +448,36 @@ class AutoregressiveTransformer:
 
         # every launch argument is affine in i: record steps 0 and 1 once, then issue each step from one C call
         prog = ops.StepProgram(step) if program and S >= 2 else None
-        steps = 0
-        for i in range(S):
-            if prog is not None:
-                prog.run(i)
-            else:
-                step(i)
-            steps = i + 1
-            stop_pred = stop[(i + 1) * r - 1].cpu()                      # host decision every step, as in the reference
-            if verbose:
-                print(f'\rpred text mel: {i} stop out: {float(stop_pred[2])}', end='')
-            if int(torch.argmax(stop_pred)) == self.stop_prob_index:
+        # The reference asks the host after every step whether the stop token won (AutoregressiveTransformer.py:289-293).  Here the
+        # steps are issued in groups and the stop rows of a group are read back together: the answer is the same (the first
+        # step whose stop class wins ends the utterance; what was decoded past it is dropped), with one device-to-host wait
+        # per group instead of per step.
+        group = 1 if verbose else max(1, int(stop_check_every))
+        steps, done, i = 0, False, 0
+        while i < S and not done:
+            n = min(group, S - i)
+            for j in range(i, i + n):
+                if prog is not None:
+                    prog.run(j)
+                else:
+                    step(j)
+            rows = stop[(i + 1) * r - 1:(i + n) * r:r].cpu()               # the last frame's stop logits of every step of the group
+            for j in range(n):
+                steps = i + j + 1
                 if verbose:
-                    print('Stopping')
-                break
+                    print(f'\rpred text mel: {i + j} stop out: {float(rows[j, 2])}', end='')
+                if int(torch.argmax(rows[j])) == self.stop_prob_index:
+                    if verbose:
+                        print('Stopping')
+                    done = True
+                    break
+            i += n
         dec_attn = {name: a[:steps, :h * N].reshape(steps, h, N).permute(1, 0, 2)[None].contiguous()
                     for name, a, h in zip(self.decoder.names, attn, H)}
         return {'mel': final[:steps * r].clone(), 'decoder_attention': dec_attn, 'text_encoder_attention': text_attn,
                 'gst_encoder_attention': gst_attn, 'gst_tokens': gst_tokens}
 
-    def predict(self, inp, targets, spk_embed, max_length=1000, encode=True, verbose=True, kv_cache=True):
+    def predict(self, inp, targets, spk_embed, max_length=1000, encode=True, verbose=True, kv_cache=True, stop_check_every=8):
         """AutoregressiveTransformer.py:265-296.  inp: phoneme string (encode=True) or token ids; targets: reference mel
         (T, 80) for the style encoder or None; spk_embed: (1, D) or None.
 
@@ -475,9 +486,11 @@ class AutoregressiveTransformer:
         which gives the same numbers as the reference's loop (all its masks are causal) in O(T) decoder work.
         kv_cache=False re-runs the whole decoder on the growing output each step, literally as the reference does.
         With decoder_prenet_dropout > 0 the two differ in distribution only: the reference (and kv_cache=False) redraws the
-        prenet dropout masks of every earlier position at each step, the cached decoder draws each position's mask once."""
+        prenet dropout masks of every earlier position at each step, the cached decoder draws each position's mask once.
+        stop_check_every: decoder steps issued between two reads of the stop decision (same output for any value; 1 with
+        verbose=True, which prints every step's stop value as the reference does)."""
         if kv_cache:
-            return self._predict_incremental(inp, targets, spk_embed, max_length, encode, verbose)
+            return self._predict_incremental(inp, targets, spk_embed, max_length, encode, verbose, stop_check_every=stop_check_every)
         dev = self.device
         if targets is not None:
             targets = self.encode_ref(targets)

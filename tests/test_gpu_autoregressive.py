@@ -162,6 +162,46 @@ def test_incremental_predict_matches_full_redecode(system_type, r, conv_blocks):
     assert np.abs(a['mel'].cpu().numpy() - b['mel'].cpu().numpy()).max() < 2e-4
 
 
+def test_grouped_stop_checks_give_the_same_utterance():
+    """predict(stop_check_every=k): the stop decision is read back once per k decoder steps; the utterance ends at the same step
+    whatever k is, also when that step falls inside a group or is the very first one."""
+    cfg = small_cfg('speaker_text', dense=1)
+    w = weights.init_autoregressive_transformer(cfg, seed=21)
+    rng = np.random.default_rng(3)
+    tokens = rng.integers(1, cfg['vocab_size'], size=9)
+    spk = rng.normal(size=(1, cfg['speaker_embed_dim'])).astype(np.float32)
+    def run(delta, k):
+        w['decoder_postnet.stop_linear.bias'] = np.array([0., 0., delta], np.float32)
+        model = AutoregressiveTransformer(w, cfg)
+        model.set_constants(reduction_factor=2)
+        return model.predict(tokens, None, spk, max_length=40, encode=False, verbose=False, stop_check_every=k)
+
+    # a stop head that ends the utterance somewhere in the middle: raising the bias of the stop class ends it at the step
+    # whose stop margin is largest, so stop kernels are drawn until that step is neither the first nor the last, and the bias
+    # is bisected between "never" and "at once"
+    n = 42
+    for seed in range(8):
+        w['decoder_postnet.stop_linear.kernel'] = np.random.default_rng(seed).normal(0, 0.3, size=(80, 3)).astype(np.float32)
+        lo, hi, mid = -200.0, 200.0, None
+        assert run(lo, 1)['mel'].shape[0] == 42 and run(hi, 1)['mel'].shape[0] == 2
+        for _ in range(30):
+            mid = 0.5 * (lo + hi)
+            n = run(mid, 1)['mel'].shape[0]
+            if 2 < n < 42:
+                break
+            lo, hi = (mid, hi) if n == 42 else (lo, mid)
+        if 2 < n < 42:
+            break
+    assert 2 < n < 42, n
+    for delta in (-200.0, mid, 200.0):
+        outs = [run(delta, k) for k in (1, 3, 8, 64)]
+        for o in outs[1:]:
+            assert o['mel'].shape == outs[0]['mel'].shape and torch.equal(o['mel'], outs[0]['mel'])
+            for name in o['decoder_attention']:
+                assert torch.equal(o['decoder_attention'][name], outs[0]['decoder_attention'][name])
+    print(f'stop bias {mid:.4f}: utterance of {n} frames')
+
+
 def test_step_program_equals_eager_launches():
     """The incremental decoder issued through the C step program (launch arguments patched per step) gives bit-identical
     output to the same launches issued one by one."""
