@@ -39,6 +39,14 @@
 #include "common.h"
 #include "wavernn_cond.h"
 
+#ifdef ESTTS_WL_STAMPS
+__device__ unsigned long long wl_stamps[3][2][8];
+#define WL_STAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) wl_stamps[MODE][blockIdx.x ? 1 : 0][i] = wall_clock64(); } while (0)
+extern "C" int estts_debug_wl_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wl_stamps), sizeof(wl_stamps)); }
+#else
+#define WL_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int WL_CK = 4;                       // K-steps per chunk
@@ -73,9 +81,10 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
     constexpr int NAX = NA0 > NA1 ? NA0 : NA1;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2][WL_SLOT];
 
+    WL_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and known to the compiler as such: branches on it are scalar)
     const int mg = wave & 3;
     const int kpar = wave >> 2;
     const int i16 = lane & 15;
@@ -142,73 +151,93 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto multiply = [&](int c, const WlSet<NAX>& set) {
+    // The matrix work of chunk c for this wave: K-steps kpar and 2 + kpar of the chunk.  Per K-step three groups of matrix
+    // instructions, small terms first, consecutive instructions on different accumulators: A hi x B lo, A lo x B hi, A hi x B hi.
+    // B lo is dead after the first group, so the next K-step's B lo is read from LDS into its registers while the other two
+    // groups run, and its B hi while that K-step's first group runs: only the chunk's first reads are waited for with nothing else to do.  Reads are unconditional (a K-step past the
+    // chunk's end reads stale bytes that no instruction uses); the groups of such a K-step are skipped.
+    struct Bfrag { bf16x8 hi[NAX], lo[NAX]; };
+    auto multiply = [&](int c, const WlSet<NAX>& set, auto phase_tag) {
+        constexpr bool P1 = decltype(phase_tag)::value;
+        constexpr int NACT = P1 ? NA1 : NA0;
+        constexpr int first = MODE == 1 ? 1 : 0;
         int ks0;
         bool ph1;
         const int nsteps = chunk_steps(c, ks0, ph1);
-        const unsigned char* slot = lds[c & 1];
-        auto step = [&](int q, auto phase_tag) {
-            constexpr bool P1 = decltype(phase_tag)::value;
-            constexpr int NACT = P1 ? NA1 : NA0;
-            constexpr int first = MODE == 1 ? 1 : 0;
-            const int s = 2 * q + kpar;
-            bf16x8 bhi[NACT], blo[NACT];
+        const unsigned char* blk0 = lds[c & 1] + kpar * NACT * 2048 + lane * 16;
+        const unsigned char* blk1 = blk0 + 2 * NACT * 2048;
+        Bfrag f;
 #pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-                const unsigned char* blk = slot + ((s * NACT + a) * 2) * 1024 + lane * 16;
-                bhi[a] = *reinterpret_cast<const bf16x8*>(blk);
-                blo[a] = *reinterpret_cast<const bf16x8*>(blk + 1024);
-            }
-            bf16x8 ahi[2], alo[2];
+        for (int a = 0; a < NACT; ++a) f.lo[a] = *reinterpret_cast<const bf16x8*>(blk0 + a * 2048 + 1024);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                ahi[mb] = __builtin_bit_cast(bf16x8, set.a[q][mb][0]);
-                alo[mb] = __builtin_bit_cast(bf16x8, set.a[q][mb][1]);
-            }
-            // small terms first; consecutive matrix instructions go to different accumulators
+        for (int a = 0; a < NACT; ++a) f.hi[a] = *reinterpret_cast<const bf16x8*>(blk0 + a * 2048);
+        __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks these reads into the first group one by one)
+        auto group = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[NAX]) {
 #pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-                const int t = P1 ? (a < 2 ? first + a : first + 3) : a;
+            for (int i = 0; i < NACT; ++i) {
+                const int t = P1 ? (i < 2 ? first + i : first + 3) : i;
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[mb], bhi[a], acc[t][mb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-                const int t = P1 ? (a < 2 ? first + a : first + 3) : a;
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[mb], blo[a], acc[t][mb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int a = 0; a < NACT; ++a) {
-                const int t = P1 ? (a < 2 ? first + a : first + 3) : a;
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[mb], bhi[a], acc[t][mb], 0, 0, 0);
+                for (int mb = 0; mb < 2; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mb], b[i], acc[t][mb], 0, 0, 0);
             }
         };
+        bf16x8 ahi[2], alo[2];
 #pragma unroll
-        for (int q = 0; q < WL_CK / 2; ++q) {
-            if (2 * q + kpar < nsteps) {
-                if constexpr (GRU) {
-                    if (ph1) step(q, std::true_type{});
-                    else step(q, std::false_type{});
-                } else {
-                    step(q, std::false_type{});
-                }
+        for (int mb = 0; mb < 2; ++mb) {
+            ahi[mb] = __builtin_bit_cast(bf16x8, set.a[0][mb][0]);
+            alo[mb] = __builtin_bit_cast(bf16x8, set.a[0][mb][1]);
+        }
+        const bool v0 = kpar < nsteps, v1 = 2 + kpar < nsteps;
+        if (v0) group(ahi, f.lo);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) f.lo[a] = *reinterpret_cast<const bf16x8*>(blk1 + a * 2048 + 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        if (v0) {
+            group(alo, f.hi);
+            group(ahi, f.hi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < NACT; ++a) f.hi[a] = *reinterpret_cast<const bf16x8*>(blk1 + a * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+        if (v1) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                ahi[mb] = __builtin_bit_cast(bf16x8, set.a[1][mb][0]);
+                alo[mb] = __builtin_bit_cast(bf16x8, set.a[1][mb][1]);
             }
+            group(ahi, f.lo);
+            group(alo, f.hi);
+            group(ahi, f.hi);
+        }
+    };
+    auto multiply_phase = [&](int c, const WlSet<NAX>& set) {
+        if constexpr (GRU) {
+            if (c >= nc0) multiply(c, set, std::true_type{});
+            else multiply(c, set, std::false_type{});
+        } else {
+            multiply(c, set, std::false_type{});
         }
     };
 
     // iteration c with the register sets of chunks c, c + 1, c + 2
     auto iteration = [&](int c, WlSet<NAX>& cur, WlSet<NAX>& nxt, WlSet<NAX>& far) {
         __syncthreads();                 // chunk c's weights are in slot c & 1; every wave has left chunk c - 1, whose slot is free
+        // The two waves of a SIMD (K parities 0 and 1) take the two halves of the iteration in opposite order: while one
+        // half of the workgroup sends its twelve 1 KiB requests down the CU's one address path -- which takes as long as the
+        // chunk's matrix work -- the other half multiplies.  (With every wave requesting first, all eight queue there and no
+        // one multiplies: the two times add up.)  The requests stay outside the branches, so that every path issues the same
+        // loads and the compiler can count them.
+        if (kpar) multiply_phase(c, cur);
         request(c + 2, far);
-        multiply(c, cur);
+        if (!kpar) multiply_phase(c, cur);
         stage_weights(c + 1, nxt);       // (requested one iteration ago)
     };
     WlSet<NAX> s0, s1, s2;
     request(0, s0);
     request(1, s1);
     stage_weights(0, s0);
+    WL_STAMP(1);
     for (int c = 0; c < nc; c += 3) {
         iteration(c, s0, s1, s2);
         if (c + 1 >= nc) break;
@@ -217,6 +246,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
         iteration(c + 2, s2, s0, s1);
     }
 
+    WL_STAMP(2);
     // Epilogue.  The two waves of a pair swap halves: the wave with K parity q keeps sequence block q (16 sequences) and adds
     // its partner's partial sums for it, so all eight waves share the gate math, the loads and the stores.
     const int unit0 = ug * 16 * (GRU ? 1 : NT);
@@ -253,6 +283,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
             for (int j = 0; j < 4; ++j) sum[t][j] = (mb_own == 0 ? acc[t][0][j] : acc[t][1][j]) + theirs[(t * 4 + j) * 64 + lane];
     }
 
+    WL_STAMP(3);
     // Results per lane: NOUT x 4 values, rows m0 + 16 mb_own + 4 g + j, unit unit0 + 16 o + i16.
     // GRU: output 0 = the new state, output 1 = state + residual (the layer output); dense: output o = unit block o.
     constexpr int NOUT = GRU ? 2 : NT;
@@ -293,6 +324,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
         }
     }
 
+    WL_STAMP(4);
     // panel copies: a wave's 16 sequences x 16 units go through its own 1 KiB of LDS (row-major) so that a lane can pick up
     // eight consecutive units of one sequence, split them and store 16 bytes of hi and 16 bytes of lo (lanes 0..31)
     __syncthreads();              // the exchange area is read: reuse it
@@ -321,6 +353,11 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
             *reinterpret_cast<bf16x8*>(dst + 1024) = lo;
         }
     }
+    WL_STAMP(5);
+#ifdef ESTTS_WL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WL_STAMP(6);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------

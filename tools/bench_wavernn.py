@@ -13,6 +13,10 @@ import estts  # noqa
 from estts import configs, weights
 from estts.wavernn import WaveRNN
 
+if os.environ.get('WL_LIB'):          # A/B runs of two builds on one box (devices differ by several per cent)
+    from estts import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['WL_LIB'])
+
 ap = argparse.ArgumentParser()
 ap.add_argument('--utts', type=int, default=64)
 ap.add_argument('--frames', type=int, default=560)
