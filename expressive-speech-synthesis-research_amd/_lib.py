@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -104,6 +104,7 @@ class WavernnPrepArgs(C.Structure):
 class WavernnLayerArgs(C.Structure):
     _fields_ = [('a0', _vp), ('ks0', _i32), ('kpitch0', _i32), ('a1', _vp), ('ks1', _i32), ('kpitch1', _i32), ('W', _vp),
                 ('bias', _vp), ('n_seq', _i32), ('n_units', _i32), ('mode', _i32), ('act', _i32), ('unit_blocks', _i32),
+                ('seq_tile', _i32),
                 ('h_prev', _vp), ('ldh', _i32), ('x_res', _vp), ('ldr', _i32), ('h_out', _vp), ('ldho', _i32),
                 ('h_panel', _vp), ('h_kpitch', _i32), ('out_f32', _vp), ('ldo', _i32), ('out_panel', _vp), ('out_kpitch', _i32)]
 

@@ -10,12 +10,13 @@
 // loaded fragment-wise are 64 scattered 16-byte pieces per instruction, and splitting them in the K loop costs as many
 // vector instructions as the matrix instructions take cycles: that form ran the two GRU layers at 25 + 18 us per step.)
 //
-// Tiling.  A workgroup owns 128 sequences x one group of 16-unit blocks and keeps NT accumulator tiles per sequence block:
+// Tiling.  A workgroup owns 128 sequences x one group of 16-unit blocks (dense layers also: 64 sequences x 32 units) and keeps
+// NT accumulator tiles per sequence block:
 //   GRU layers: the NT sums of its 16 units, [xI] r z gi_n gh_n; phase 0 (the layer input) feeds [xI] r z gi_n, phase 1
 //               (the previous state) feeds r z gh_n, so r and z are sums over both phases and nothing zero is multiplied;
 //   dense layers: NT consecutive 16-unit blocks, one phase.
 // v_mfma_f32_16x16x32_bf16 leaves D[row 4 (l >> 4) + j][col l & 15] in lane l: a lane ends up with all sums of its (sequence, unit)
-// pairs, so the gate math needs no exchange.  Eight waves: wave w works on sequences 32 (w & 3) .. + 31 and on every second
+// pairs, so the gate math needs no exchange.  Eight waves: wave w works on sequence blocks of group w & 3 and on every second
 // K-step (parity w >> 2), so that each SIMD holds two waves whose loads, LDS reads and matrix instructions overlap; the two
 // partial sums meet in LDS at the end.
 //
@@ -27,13 +28,21 @@
 // fragments and its 16-byte pieces of the weight stream, all into registers: three register sets rotate), multiplies
 // chunk c, and only then writes the weight pieces of chunk c + 1 -- requested one iteration earlier -- into the free LDS
 // slot; one barrier per chunk.  Every request is therefore two chunks of matrix work old when its data is needed.  All
-// loads are unconditional (indices past the end are clamped to valid memory and their data is ignored) so that the
-// compiler can count the outstanding requests and wait for the oldest only.  (With the chunk's loads issued right after
-// the barrier that the next chunk's wait sits in front of -- the direct-to-LDS form drains every outstanding load at
-// each barrier -- every chunk cost one full memory round trip.)  What is left of a layer's time at 832 sequences is mostly
-// not this loop: a dense layer takes 7.3 us of which the loop is ~2 (a variant that requested the layer's whole input at once
-// ran the same 7.2 us: each workgroup's 310 KB of operands arrive at the CU's ~64 B/clk fill rate, ~2 us, whatever the order),
-// the rest being launch, the first round trip, the exchange and the drain of the stores.
+// loads are unconditional (indices past the end are clamped to valid memory and their data is ignored) and sit outside every
+// branch, so that the compiler can count the outstanding requests and wait for the oldest only: a request inside one arm of
+// an if / else is laid out as two skippable blocks with a path past both, and every wait behind it becomes a wait for all.
+// (With the chunk's loads issued right after the barrier that the next chunk's wait sits in front of -- the direct-to-LDS
+// form drains every outstanding load at each barrier -- every chunk cost one full memory round trip.)
+//
+// What bounds the K loop (in-kernel stamps, build with -DESTTS_WL_STAMPS and run tools/wl_stamps.py).  A chunk of a GRU layer
+// is 96 KB of operands for the CU -- 1536 cycles of its 64 B / clock fetch path -- and 72 to 96 matrix instructions per
+// SIMD, 1150 to 1540 cycles: the two are balanced, so they must overlap.  The waves of a SIMD therefore take request and
+// multiply in opposite order (see `iteration`), and a K-step's LDS reads are issued under the previous K-step's matrix
+// instructions (see `multiply`): 1.0 to 1.2 us per chunk where requests first, then multiply in every wave took 1.3 to 1.55.
+// A dense layer has a quarter of the matrix work per byte and runs at the fetch rate: 0.6 us per 72 KB chunk at 128 x 16,
+// which is why its tile is 64 x 32 (48 KB per chunk).  What is left of a layer's time at 832 sequences is mostly not this loop:
+// a dense layer takes ~6.5 us of which the loop is 2 to 3, the rest being dispatch and the end-of-kernel release (~2), the
+// first round trip (1.2), the exchange and the drain of the stores.
 #include <type_traits>
 
 #include "common.h"
@@ -55,9 +64,9 @@ constexpr int WL_SLOT = WL_CK * 4 * 2 * 1024;  // bytes per LDS slot: 4 K-steps 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int NAX>
+template <int NAX, int MB>
 struct WlSet {
-    uint4 a[WL_CK / 2][2][2];   // A: [the wave's K-steps of a chunk][16-row block][hi | lo]
+    uint4 a[WL_CK / 2][MB][2];  // A: [the wave's K-steps of a chunk][16-row block][hi | lo]
     uint4 w[NAX];               // the thread's pieces of the chunk's weight stream (piece i * 512 + tid)
 };
 
@@ -73,7 +82,10 @@ __device__ __forceinline__ float tanh_(float x) {
 // MODE 1: rnn1 (NT 5: xI r z gi_n gh_n; phase 0 feeds 0..3, phase 1 feeds 1, 2, 4)
 // MODE 2: rnn2 (NT 4: r z gi_n gh_n;    phase 0 feeds 0..2, phase 1 feeds 0, 1, 3)
 // MODE 0: dense, NT unit blocks, one phase
-template <int MODE, int NT>
+// MB: 16-sequence blocks per wave.  2: the workgroup owns 128 sequences.  1 (dense with NT 2): 64 sequences x 32 units, which
+//     fetches a third fewer bytes per matrix instruction than 128 x 16 -- a dense layer's K loop runs at the rate its CU
+//     fetches operands (64 KB of A and 8 KB of W per chunk against 24 matrix instructions per wave).
+template <int MODE, int NT, int MB>
 __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_layer_args p) {
     constexpr bool GRU = MODE != 0;
     constexpr int NA0 = MODE == 1 ? 4 : (MODE == 2 ? 3 : NT);   // accumulators fed by phase 0
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
     const int g = lane >> 4;
     const int n_groups = (p.n_units + 16 * (GRU ? 1 : NT) - 1) / (16 * (GRU ? 1 : NT));
     const int ug = blockIdx.x % n_groups;
-    const int m0 = (blockIdx.x / n_groups) * 128 + mg * 32;
+    const int m0 = (blockIdx.x / n_groups) * (64 * MB) + mg * (16 * MB);
     const int n_rb = (p.n_seq + 15) >> 4;
 
     const int nks0 = p.ks0;
@@ -101,11 +113,11 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
     const int nc = nc0 + nc1;
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.W) + (long)ug * (nks0 * NA0 + nks1 * NA1) * 2048;
 
-    // the wave's two sequence blocks in each panel (blocks past the end re-read the last one; their rows are never stored)
-    const unsigned char* a0[2];
-    const unsigned char* a1[2];
+    // the wave's sequence blocks in each panel (blocks past the end re-read the last one; their rows are never stored)
+    const unsigned char* a0[MB];
+    const unsigned char* a1[MB];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < MB; ++mb) {
         const int rb = min((m0 >> 4) + mb, n_rb - 1);
         a0[mb] = reinterpret_cast<const unsigned char*>(p.a0) + (long)rb * p.kpitch0 * 2048 + lane * 16;
         a1[mb] = GRU ? reinterpret_cast<const unsigned char*>(p.a1) + (long)rb * p.kpitch1 * 2048 + lane * 16 : a0[mb];
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
     };
     // request everything chunk c needs.  Unconditional: a K-step past the chunk's end or a chunk past the last one reads
     // valid memory that nobody uses (the panel's last K-step; the stream's following bytes, which the host pads).
-    auto request = [&](int c, WlSet<NAX>& set) {
+    auto request = [&](int c, WlSet<NAX, MB>& set) {
         c = min(c, nc - 1);
         int ks0;
         bool ph1;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
         for (int q = 0; q < WL_CK / 2; ++q) {
             const int ks = min(ks0 + 2 * q + kpar, klast);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < MB; ++mb) {
                 const unsigned char* src = (ph1 ? a1[mb] : a0[mb]) + (long)ks * 2048;
                 set.a[q][mb][0] = *reinterpret_cast<const uint4*>(src);
                 set.a[q][mb][1] = *reinterpret_cast<const uint4*>(src + 1024);
@@ -139,17 +151,17 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
 #pragma unroll
         for (int i = 0; i < NAX; ++i) set.w[i] = *reinterpret_cast<const uint4*>(src + i * 8192);
     };
-    auto stage_weights = [&](int c, const WlSet<NAX>& set) {
+    auto stage_weights = [&](int c, const WlSet<NAX, MB>& set) {
         unsigned char* dst = lds[c & 1] + tid * 16;
 #pragma unroll
         for (int i = 0; i < NAX; ++i) *reinterpret_cast<uint4*>(dst + i * 8192) = set.w[i];
     };
 
-    f32x4 acc[NT][2];
+    f32x4 acc[NT][MB];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mb = 0; mb < MB; ++mb) acc[t][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // The matrix work of chunk c for this wave: K-steps kpar and 2 + kpar of the chunk.  Per K-step three groups of matrix
     // instructions, small terms first, consecutive instructions on different accumulators: A hi x B lo, A lo x B hi, A hi x B hi.
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
     // groups run, and its B hi while that K-step's first group runs: only the chunk's first reads are waited for with nothing else to do.  Reads are unconditional (a K-step past the
     // chunk's end reads stale bytes that no instruction uses); the groups of such a K-step are skipped.
     struct Bfrag { bf16x8 hi[NAX], lo[NAX]; };
-    auto multiply = [&](int c, const WlSet<NAX>& set, auto phase_tag) {
+    auto multiply = [&](int c, const WlSet<NAX, MB>& set, auto phase_tag) {
         constexpr bool P1 = decltype(phase_tag)::value;
         constexpr int NACT = P1 ? NA1 : NA0;
         constexpr int first = MODE == 1 ? 1 : 0;
@@ -172,17 +184,17 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
 #pragma unroll
         for (int a = 0; a < NACT; ++a) f.hi[a] = *reinterpret_cast<const bf16x8*>(blk0 + a * 2048);
         __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks these reads into the first group one by one)
-        auto group = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[NAX]) {
+        auto group = [&](const bf16x8 (&a)[MB], const bf16x8 (&b)[NAX]) {
 #pragma unroll
             for (int i = 0; i < NACT; ++i) {
                 const int t = P1 ? (i < 2 ? first + i : first + 3) : i;
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mb], b[i], acc[t][mb], 0, 0, 0);
+                for (int mb = 0; mb < MB; ++mb) acc[t][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mb], b[i], acc[t][mb], 0, 0, 0);
             }
         };
-        bf16x8 ahi[2], alo[2];
+        bf16x8 ahi[MB], alo[MB];
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < MB; ++mb) {
             ahi[mb] = __builtin_bit_cast(bf16x8, set.a[0][mb][0]);
             alo[mb] = __builtin_bit_cast(bf16x8, set.a[0][mb][1]);
         }
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
         __builtin_amdgcn_sched_barrier(0);
         if (v1) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < MB; ++mb) {
                 ahi[mb] = __builtin_bit_cast(bf16x8, set.a[1][mb][0]);
                 alo[mb] = __builtin_bit_cast(bf16x8, set.a[1][mb][1]);
             }
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
             group(ahi, f.hi);
         }
     };
-    auto multiply_phase = [&](int c, const WlSet<NAX>& set) {
+    auto multiply_phase = [&](int c, const WlSet<NAX, MB>& set) {
         if constexpr (GRU) {
             if (c >= nc0) multiply(c, set, std::true_type{});
             else multiply(c, set, std::false_type{});
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
     };
 
     // iteration c with the register sets of chunks c, c + 1, c + 2
-    auto iteration = [&](int c, WlSet<NAX>& cur, WlSet<NAX>& nxt, WlSet<NAX>& far) {
+    auto iteration = [&](int c, WlSet<NAX, MB>& cur, WlSet<NAX, MB>& nxt, WlSet<NAX, MB>& far) {
         __syncthreads();                 // chunk c's weights are in slot c & 1; every wave has left chunk c - 1, whose slot is free
         // The two waves of a SIMD (K parities 0 and 1) take the two halves of the iteration in opposite order: while one
         // half of the workgroup sends its twelve 1 KiB requests down the CU's one address path -- which takes as long as the
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
         if (!kpar) multiply_phase(c, cur);
         stage_weights(c + 1, nxt);       // (requested one iteration ago)
     };
-    WlSet<NAX> s0, s1, s2;
+    WlSet<NAX, MB> s0, s1, s2;
     request(0, s0);
     request(1, s1);
     stage_weights(0, s0);
@@ -247,17 +259,27 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
     }
 
     WL_STAMP(2);
-    // Epilogue.  The two waves of a pair swap halves: the wave with K parity q keeps sequence block q (16 sequences) and adds
-    // its partner's partial sums for it, so all eight waves share the gate math, the loads and the stores.
+    // Epilogue.  The two waves of a pair swap halves: the wave with K parity q keeps sequence block q (MB 2; with MB 1: unit
+    // block q) of their NT x MB tiles and adds its partner's partial sums for it, so all eight waves share the gate math, the
+    // loads and the stores.  Own tile x of NX: MB 2: accumulator x, sequence block kpar; MB 1: accumulator kpar.
+    static_assert(MB == 2 || (MB == 1 && MODE == 0 && NT == 2), "one sequence block per wave: dense with two unit blocks only");
+    constexpr int NX = NT * MB / 2;
     const int unit0 = ug * 16 * (GRU ? 1 : NT);
-    const int mb_own = kpar;
+    const int row_own = m0 + (MB == 2 ? 16 * kpar : 0);
+    const int tile_own = MB == 2 ? 0 : kpar;     // unit block of own tile x: tile_own + x
+    auto own = [&](int x, int j) {
+        return MB == 2 ? (kpar == 0 ? acc[x][0][j] : acc[x][MB - 1][j]) : (kpar == 0 ? acc[0][0][j] : acc[NT - 1][0][j]);
+    };
+    auto given = [&](int x, int j) {
+        return MB == 2 ? (kpar == 0 ? acc[x][MB - 1][j] : acc[x][0][j]) : (kpar == 0 ? acc[NT - 1][0][j] : acc[0][0][j]);
+    };
     // what the epilogue reads besides the sums, requested before the exchange.  The float32 side arrays of the GRU layers
     // (previous state, residual, and their outputs) are "tile-native": [workgroup][wave][lane] float4 = the four values the
     // lane owns, so that they move as whole 16-byte pieces; only the layer itself (and its twin: rnn2 reads what rnn1 wrote
     // for the same workgroup / wave / lane) ever looks at them.
-    float b[NT];
+    float b[NX];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b[t] = GRU ? p.bias[t * p.n_units + unit0 + i16] : p.bias[unit0 + 16 * t + i16];
+    for (int t = 0; t < NX; ++t) b[t] = GRU ? p.bias[t * p.n_units + unit0 + i16] : p.bias[unit0 + 16 * (tile_own + t) + i16];
     const long native = ((long)blockIdx.x * 8 + wave) * 64 + lane;
     float4 hp = make_float4(0.f, 0.f, 0.f, 0.f), res = hp;
     if (GRU) {
@@ -267,26 +289,26 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
     __syncthreads();              // every wave is done with the weight ring: reuse it for the exchange
     float* red = reinterpret_cast<float*>(&lds[0][0]);
     {
-        float* mine = red + ((mg * 2 + kpar) * NT * 4) * 64;      // what this wave hands to its partner: block 1 - kpar
+        float* mine = red + ((mg * 2 + kpar) * NX * 4) * 64;      // what this wave hands to its partner
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NX; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mine[(t * 4 + j) * 64 + lane] = mb_own == 0 ? acc[t][1][j] : acc[t][0][j];
+            for (int j = 0; j < 4; ++j) mine[(t * 4 + j) * 64 + lane] = given(t, j);
     }
     __syncthreads();
-    f32x4 sum[NT];
+    f32x4 sum[NX];
     {
-        const float* theirs = red + ((mg * 2 + (kpar ^ 1)) * NT * 4) * 64;
+        const float* theirs = red + ((mg * 2 + (kpar ^ 1)) * NX * 4) * 64;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NX; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sum[t][j] = (mb_own == 0 ? acc[t][0][j] : acc[t][1][j]) + theirs[(t * 4 + j) * 64 + lane];
+            for (int j = 0; j < 4; ++j) sum[t][j] = own(t, j) + theirs[(t * 4 + j) * 64 + lane];
     }
 
     WL_STAMP(3);
-    // Results per lane: NOUT x 4 values, rows m0 + 16 mb_own + 4 g + j, unit unit0 + 16 o + i16.
-    // GRU: output 0 = the new state, output 1 = state + residual (the layer output); dense: output o = unit block o.
-    constexpr int NOUT = GRU ? 2 : NT;
+    // Results per lane: NOUT x 4 values, rows row_own + 4 g + j, unit unit0 + 16 (tile_own + o) + i16.
+    // GRU: output 0 = the new state, output 1 = state + residual (the layer output); dense: output o = own unit block o.
+    constexpr int NOUT = GRU ? 2 : NX;
     float val[NOUT][4];
     if constexpr (GRU) {
         constexpr int R = MODE == 1 ? 1 : 0;
@@ -304,7 +326,7 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
         if (p.out_f32) reinterpret_cast<float4*>(p.out_f32)[native] = make_float4(val[1][0], val[1][1], val[1][2], val[1][3]);
     } else {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NX; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = sum[t][j] + b[t];
@@ -313,11 +335,11 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
         // float32 row-major copy (16 lanes = 64 contiguous bytes of a row)
         if (p.out_f32) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int unit = unit0 + 16 * t + i16;
+            for (int t = 0; t < NX; ++t) {
+                const int unit = unit0 + 16 * (tile_own + t) + i16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int row = m0 + 16 * mb_own + 4 * g + j;
+                    const int row = row_own + 4 * g + j;
                     if (row < p.n_seq && unit < p.n_units) p.out_f32[(long)row * p.ldo + unit] = val[t][j];
                 }
             }
@@ -344,8 +366,8 @@ __global__ __launch_bounds__(512) void wavernn_layer_kernel(const estts_wavernn_
         split_bf16x4(v1, h1, l1);
         const bf16x8 hi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
         const bf16x8 lo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-        const int row = m0 + 16 * mb_own + trow;
-        const int col = unit0 + (GRU ? 0 : 16 * o) + 8 * thalf;
+        const int row = row_own + trow;
+        const int col = unit0 + (GRU ? 0 : 16 * (tile_own + o)) + 8 * thalf;
         if (lane < 32 && row < n_rb * 16 && col < p.n_units) {   // whole blocks are kept defined: rows up to the end of the last block
             unsigned char* dst = reinterpret_cast<unsigned char*>(panel) + ((long)(row >> 4) * kpitch + (col >> 5)) * 2048 +
                                  ((row & 15) + 16 * ((col & 31) >> 3)) * 16;
@@ -386,11 +408,11 @@ __global__ __launch_bounds__(256) void wavernn_cond_kernel(const estts_wavernn_c
     wavernn_cond_group(p, b, (int)(idx - (long)b * groups) + 1, step_now);
 }
 
-template <int MODE, int NT>
+template <int MODE, int NT, int MB = 2>
 int launch_layer(const estts_wavernn_layer_args& a, hipStream_t st) {
     const int per = 16 * (MODE ? 1 : NT);
-    const int grid = ((a.n_seq + 127) / 128) * ((a.n_units + per - 1) / per);
-    hipLaunchKernelGGL((wavernn_layer_kernel<MODE, NT>), dim3(grid), dim3(512), 0, st, a);
+    const int grid = ((a.n_seq + 64 * MB - 1) / (64 * MB)) * ((a.n_units + per - 1) / per);
+    hipLaunchKernelGGL((wavernn_layer_kernel<MODE, NT, MB>), dim3(grid), dim3(512), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_wavernn_layer");
     return 0;
 }
@@ -419,6 +441,9 @@ extern "C" int estts_wavernn_layer(const estts_wavernn_layer_args* args, void* s
     }
     ESTTS_CHECK_ARG(a.out_f32 || a.out_panel, "estts_wavernn_layer: no output");
     ESTTS_CHECK_ARG(a.act == ESTTS_ACT_NONE || a.act == ESTTS_ACT_RELU, "estts_wavernn_layer: activation must be none or relu");
+    ESTTS_CHECK_ARG(a.seq_tile == 0 || a.seq_tile == 128 || (a.seq_tile == 64 && a.unit_blocks == 2),
+                    "estts_wavernn_layer: seq_tile must be 0 / 128, or 64 with unit_blocks 2");
+    if (a.seq_tile == 64) return launch_layer<0, 2, 1>(a, st);
     switch (a.unit_blocks) {
         case 1: return launch_layer<0, 1>(a, st);
         case 2: return launch_layer<0, 2>(a, st);

@@ -303,7 +303,7 @@ class WaveRNN:
         self.gru2_b = f32([b_ih2[:R] + b_hh2[:R], b_ih2[R:2 * R] + b_hh2[R:2 * R], b_ih2[2 * R:], b_hh2[2 * R:]])
         self.n_in = n_in
         self.k_in_panel = 8 + self.feat_dims + self.aux_dims
-        self.fc_unit_blocks = 1
+        self.fc_unit_blocks, self.fc_seq_tile = 2, 64     # dense layers: 64 sequences x 32 units per workgroup
         self._pack_fc(w)
         # the two recurrent products depend only on the previous step's states: one batched launch (weights and biases of
         # rnn2 follow rnn1's in one packed buffer; 3R is a multiple of 64, so the second matrix starts on a block boundary)
@@ -560,6 +560,7 @@ class WaveRNN:
             a.x_res = x_res.data_ptr()
         a.W, a.bias = w.data_ptr(), b.data_ptr()
         a.n_seq, a.n_units, a.mode, a.act, a.unit_blocks = n_seq, n_units, mode, _lib.ACT[act], self.fc_unit_blocks
+        a.seq_tile = self.fc_seq_tile if mode == 0 and self.fc_unit_blocks == 2 else 0
         if out_f32 is not None:
             a.out_f32, a.ldo = out_f32.data_ptr(), (out_f32.stride(0) if out_f32.dim() == 2 else 0)
         if out_panel is not None:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 24
+#define ESTTS_ABI_VERSION 25
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -285,7 +285,8 @@ int estts_gru_gates(const float* gi, int32_t ldgi, const float* gh, int32_t ldgh
  *   mode 0 (dense: fc1, fc2, fc3):  y = act(W a0 + bias), a0 = panel of ks0 K-steps;
  *          written to out_f32 [n_seq, ldo] and / or to columns [0, n_units) of out_panel (either may be NULL).
  *          W: for each group of unit_blocks * 16 units, the fragment images (K-step, unit block, hi | lo); rows are padded
- *          with zeros to a whole group, bias likewise.
+ *          with zeros to a whole group, bias likewise.  A workgroup owns 128 sequences x one group, or with seq_tile 64
+ *          (unit_blocks 2 only) 64 sequences x 32 units: the same results, a third fewer operand bytes per workgroup.
  *   mode 1 (rnn1 with the input layer) / mode 2 (rnn2), torch's gate order (r, z, n), x = a0 row, h = a1 row (the previous
  *          state, ks1 = n_units / 32 K-steps):
  *            r = sigmoid(Wx_r x + Wh_r h + b_r);  z = sigmoid(Wx_z x + Wh_z h + b_z);  n = tanh(Wx_n x + b_in + r (Wh_n h + b_hn))
@@ -308,6 +309,7 @@ typedef struct estts_wavernn_layer_args {
     const uint16_t* W;
     const float* bias;
     int32_t n_seq, n_units, mode, act, unit_blocks;        /* unit_blocks (dense only): 1, 2 or 4 blocks of 16 units per workgroup */
+    int32_t seq_tile;                                      /* sequences per workgroup: 0 or 128; 64 (dense with unit_blocks 2 only) */
     const float* h_prev; int32_t ldh;
     const float* x_res; int32_t ldr;
     float* h_out; int32_t ldho;
