@@ -206,9 +206,12 @@ def test_gru_layer_vs_float64(n_seq, H, kx, mode):
     assert float(panel_unpack(out_p, n_seq, 32 * out_p.shape[1])[:, H:].abs().max()) == 0.0     # columns past n_units untouched
 
 
-@pytest.mark.parametrize('n_seq,N,K,nb,act', [(832, 512, 544, 1, 'relu'), (832, 512, 512, 4, None), (70, 30, 64, 1, None),
-                                              (300, 512, 544, 2, 'relu'), (17, 32, 96, 2, 'relu')])
-def test_dense_layer_vs_float64(n_seq, N, K, nb, act):
+@pytest.mark.parametrize('n_seq,N,K,nb,act,seq_tile', [
+    (832, 512, 544, 1, 'relu', 0), (832, 512, 512, 4, None, 128), (70, 30, 64, 1, None, 0), (300, 512, 544, 2, 'relu', 0),
+    (17, 32, 96, 2, 'relu', 0),
+    # 64 sequences x 32 units per workgroup: full size, a ragged last sequence block and unit group, fewer rows than one tile
+    (832, 512, 544, 2, 'relu', 64), (300, 500, 512, 2, None, 64), (70, 30, 64, 2, 'relu', 64), (17, 32, 96, 2, None, 64)])
+def test_dense_layer_vs_float64(n_seq, N, K, nb, act, seq_tile):
     from estts import _lib, ops
     from estts.wavernn import pack_dense_stream, panel_alloc, panel_pack, panel_unpack
     rng = np.random.default_rng(n_seq + N + K)
@@ -220,8 +223,8 @@ def test_dense_layer_vs_float64(n_seq, N, K, nb, act):
     b[:N] = rng.normal(size=N)
     out = torch.full((n_seq, N), float('nan'), device='cuda')
     out_p = panel_alloc(n_seq, (N + 31) // 32, 'cuda')
-    a = _layer_args(_lib, n_seq, N, 0, xp, xp.shape[1], stream.cuda(), d(b), act=_lib.ACT[act], unit_blocks=nb, out_f32=out, ldo=N,
-                    out_panel=out_p, out_kpitch=out_p.shape[1])
+    a = _layer_args(_lib, n_seq, N, 0, xp, xp.shape[1], stream.cuda(), d(b), act=_lib.ACT[act], unit_blocks=nb, seq_tile=seq_tile, out_f32=out,
+                    ldo=N, out_panel=out_p, out_kpitch=out_p.shape[1])
     _lib.check(_lib.load().estts_wavernn_layer(a, ops._stream()), 'estts_wavernn_layer')
     x64 = panel_unpack(xp, n_seq, K).cpu().numpy().astype(np.float64)
     y = x64 @ w.T.astype(np.float64) + b[:N]
@@ -229,6 +232,10 @@ def test_dense_layer_vs_float64(n_seq, N, K, nb, act):
         y = np.maximum(y, 0)
     assert np.abs(out.cpu().numpy() - y).max() < 5e-5
     assert np.abs(panel_unpack(out_p, n_seq, N).cpu().numpy() - y).max() < 1e-4
+    if seq_tile == 64:     # the small tile exists for two unit blocks only
+        a.unit_blocks = 1
+        with pytest.raises(_lib.EsttsError, match='seq_tile'):
+            _lib.check(_lib.load().estts_wavernn_layer(a, ops._stream()), 'estts_wavernn_layer')
 
 
 def test_panel_pack_round_trip():

@@ -9,5 +9,5 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_wv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_wv -- python3 $R/tools/bench_wavernn.py "$@" > $R/gpurun_out/prof_wv.log 2>&1
 grep "us per step" $R/gpurun_out/prof_wv.log
-f=$(find $R/gpurun_out/prof_wv -name "*kernel_stats.csv" | head -1)
-head -9 $f | cut -d, -f1-4 | cut -c1-150
+f=$(ls -t $(find $R/gpurun_out/prof_wv -name "*kernel_stats.csv") | head -1)
+head -9 $f | python3 -c "import csv,sys; [print(r[0][-60:], r[1], r[3][:8]) for r in csv.reader(sys.stdin)]"
