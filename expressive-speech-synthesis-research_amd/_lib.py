@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -118,7 +118,7 @@ class WavernnCondArgs(C.Structure):
 class WavernnSampleArgs(C.Structure):
     _fields_ = [('logits', _vp), ('ld_logits', _i32), ('n_classes', _i32), ('mode', _i32), ('u', _vp), ('u_mix', _vp),
                 ('forced', _vp), ('seed', C.c_uint32), ('wave', _vp), ('ld_wave', _i32), ('x_prev', _vp), ('step', _vp),
-                ('done', _vp), ('n_seq', _i32), ('with_cond', _i32), ('cond', WavernnCondArgs)]
+                ('done', _vp), ('step_next', _vp), ('n_seq', _i32), ('with_cond', _i32), ('cond', WavernnCondArgs)]
 
 
 

@@ -210,6 +210,11 @@ __global__ __launch_bounds__(512) void wavernn_sample_kernel(const estts_wavernn
             }
         }
     }
+    // two alternating counters: nobody reads the one this call writes
+    if (p.step_next) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.step_next[0] = step + 1;
+        return;
+    }
     // the last workgroup to finish has seen every workgroup read step[0]; it advances the counter
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -258,7 +263,8 @@ extern "C" int estts_gru_gates(const float* gi, int32_t ldgi, const float* gh, i
 extern "C" int estts_wavernn_sample(const estts_wavernn_sample_args* args, void* stream) {
     ESTTS_CHECK_ARG(args != nullptr, "estts_wavernn_sample: null args");
     const estts_wavernn_sample_args& a = *args;
-    ESTTS_CHECK_ARG(a.logits && a.wave && a.x_prev && a.step && a.done, "estts_wavernn_sample: null pointer");
+    ESTTS_CHECK_ARG(a.logits && a.wave && a.x_prev && a.step && (a.done || a.step_next), "estts_wavernn_sample: null pointer");
+    ESTTS_CHECK_ARG(a.step_next != a.step, "estts_wavernn_sample: step_next must be another counter than step");
     ESTTS_CHECK_ARG(a.n_seq > 0 && a.n_classes > 0 && a.ld_logits >= a.n_classes, "estts_wavernn_sample: bad sizes");
     ESTTS_CHECK_ARG(a.mode == 0 || (a.mode == 1 && a.n_classes % 3 == 0 && a.n_classes / 3 <= 64),
                     "estts_wavernn_sample: mode must be 0 (RAW) or 1 (MOL with <= 64 components)");

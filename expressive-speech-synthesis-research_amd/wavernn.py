@@ -303,6 +303,7 @@ class WaveRNN:
         self.gru2_b = f32([b_ih2[:R] + b_hh2[:R], b_ih2[R:2 * R] + b_hh2[R:2 * R], b_ih2[2 * R:], b_hh2[2 * R:]])
         self.n_in = n_in
         self.k_in_panel = 8 + self.feat_dims + self.aux_dims
+        self.alternate_step_counters = True
         self.fc_unit_blocks, self.fc_seq_tile = 2, 64     # dense layers: 64 sequences x 32 units per workgroup
         self._pack_fc(w)
         # the two recurrent products depend only on the previous step's states: one batched launch (weights and biases of
@@ -417,7 +418,7 @@ class WaveRNN:
                 'x2cat': torch.zeros(n_seq, R + d, **f32),
                 'f1cat': torch.zeros(n_seq, self.fc_dims + d, **f32), 'f2': torch.empty(n_seq, self.fc_dims, **f32),
                 'logits': torch.empty(n_seq, self.n_classes, **f32), 'x_prev': torch.zeros(n_seq, **f32),
-                'wave': torch.zeros(n_seq, L, **f32), 'step': torch.zeros(1, dtype=torch.int32, device=self.device),
+                'wave': torch.zeros(n_seq, L, **f32), 'step': torch.zeros(2, dtype=torch.int32, device=self.device),
                 'done': torch.zeros(1, dtype=torch.int32, device=self.device)}
 
     def _use_layers(self):
@@ -498,6 +499,9 @@ class WaveRNN:
             for args, nxt in ((a, 1), (b, 0)):
                 args.with_cond = 1
                 args.cond = _lib.WavernnCondArgs.from_buffer_copy(st['cond_args'][nxt])
+                # two step counters, like the panel sets: step t reads counter t & 1 and writes t + 1 into the other
+                if self.alternate_step_counters:
+                    args.step, args.step_next = st['step'][nxt ^ 1:].data_ptr(), st['step'][nxt:].data_ptr()
             a._keep = b._keep = (lg, u, u_mix, forced, st)
             return [a, b]
         return a

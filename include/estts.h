@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 25
+#define ESTTS_ABI_VERSION 26
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -355,6 +355,9 @@ int estts_wavernn_cond(const estts_wavernn_cond_args* args, void* stream);
  * counter-based generator keyed by (seed, step, b).  wave[b * ld_wave + step] receives the value;
  * x_prev[b] receives forced[step * n_seq + b] when forced != NULL, else the value.
  * `done` is one zero-initialised int32 used to find the last workgroup, which advances step[0].
+ * With step_next != NULL (a different int32 from step) the call writes step[0] + 1 there instead and leaves step and done
+ * alone: consecutive calls that alternate between two counters (each reading what the previous one wrote) need no
+ * workgroup to be the last -- the ~200 returning atomics on `done` otherwise end every call of a generation step.
  * Replaces: F.softmax + Categorical.sample (fatchord_version.py:210-216) and
  * sample_from_discretized_mix_logistic (utility/distribution.py:87-123). */
 typedef struct estts_wavernn_sample_args {
@@ -364,6 +367,7 @@ typedef struct estts_wavernn_sample_args {
     float* wave; int32_t ld_wave;
     float* x_prev;
     int32_t* step; int32_t* done;
+    int32_t* step_next;      /* NULL, or where step[0] + 1 goes (then step[0] and done are left alone) */
     int32_t n_seq;
     int32_t with_cond;       /* 1: also prepare the NEXT step's conditioning (step[0] + 1) into the panels of `cond`, exactly as
                                 estts_wavernn_cond would, plus the value fed back as bf16 hi | lo followed by seven zeros in the

@@ -26,6 +26,7 @@ ap.add_argument('--target', type=int, default=11000)
 ap.add_argument('--overlap', type=int, default=550)
 ap.add_argument('--steps-per-graph', type=int, default=50)
 ap.add_argument('--fc-tile', default=None, help='dense layer tile, sequences x units per workgroup: 128x16, 128x32, 128x64 or 64x32')
+ap.add_argument('--atomic-step', action='store_true', help='one step counter advanced by the last workgroup of the sampler')
 ap.add_argument('--unfused', action='store_true', help='separate products and gate launches for the GRU layers')
 args = ap.parse_args()
 hp = configs.wavernn_hparams_22k() if args.hop == 256 else configs.wavernn_hparams(voc_mode='RAW')
@@ -36,6 +37,8 @@ if args.fc_tile:
     seqs, units = (int(v) for v in args.fc_tile.split('x'))
     m.fc_unit_blocks, m.fc_seq_tile = units // 16, seqs
     m._pack_fc(m._sd)
+if args.atomic_step:
+    m.alternate_step_counters = False
 if args.unfused:
     m.fused = False
 rng = np.random.default_rng(1234)
