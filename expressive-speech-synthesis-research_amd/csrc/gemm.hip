@@ -30,31 +30,11 @@
 
 #include "common.h"
 #include "a_operand.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
 constexpr int BK = 64;
-
-__device__ __forceinline__ float epilogue_value(const estts_gemm_args& p, float acc, int row, int col, float s1,
-                                                float b1, float s2, float b2) {
-    float v = acc * s1 + b1;
-    v = apply_act(v, p.act);
-    if (p.drop_rate > 0.0f)
-        v = dropout_keep(p.drop_seed, p.drop_site, (uint32_t)(p.drop_row0 + row), (uint32_t)col, p.drop_rate) ? v / (1.0f - p.drop_rate) : 0.0f;
-    v *= p.alpha;
-    if (p.R) {
-        const int rr = p.r_mod > 0 ? row % p.r_mod : row;
-        v += p.R[(long)rr * p.ldr + col];
-    }
-    if (p.s2) v = v * s2 + b2;
-    return v;
-}
-
-
-// true when the activation panel (M rows) is the smaller operand: an L2 then holds all of it plus a strip of W columns
-__device__ __forceinline__ bool gemm_y_first(const estts_gemm_args& p) {
-    return (long)p.M * p.c_per_tap * 4 <= (long)p.N * p.K * (p.precision == 3 ? 4 : 2);
-}
 
 // split-K hand-off; returns true in the workgroup that must finish the tile (all threads must call)
 __device__ __forceinline__ bool splitk_last_arriver(const estts_gemm_args& p, int tile, int splitk, int* s_ticket) {
@@ -808,6 +788,23 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         // (with K <= 256 a workgroup's eight K-steps do not amortise the wider tile's prologue: 19200 x 768 x 256 runs 44 us
         // as 64 x 64 tiles, 49 us as 64 x 128)
         tile = (a.N >= 128 && n8 >= 384 && a.K > 256) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
+    }
+    if (tile == 9 || tile == 10) {   // explicit one-shot kernel: 16 x 16 / 32 x 32 tiles
+        const int r = estts_launch_gemm_oneshot(a, operand_kind(a), tile == 9, (a.tune >> 16) & 0xff, st);
+        ESTTS_CHECK_ARG(r != 1, "estts_gemm: shape outside the one-shot kernel (dense / 1-D convolution, K and c_per_tap multiples of 8, K <= 192 x waves)");
+        return r;
+    }
+    if (tile == 4 && (a.tune & 0xff) == 0 && splitk == 0) {
+        // launches of a few hundred small tiles: every load issued up front (gemm_oneshot.hip); 16 x 16 tiles while 32 x 32
+        // ones would leave half the chip idle
+        // (measured, tools/tune_gemm.py: 16 x 16 tiles win at every K they can hold -- 100 x 512 x 1536: 8.4 -> 6.0 us,
+        // 600 x 80 x 1280: 7.7 -> 5.3 us --; 32 x 32 tiles only up to 16 K-steps: beyond that a workgroup's 400 KB of operands
+        // are bound by its CU's L1 fill rate and the register ring of gemm_small_kernel, with its coalesced A loads, is faster)
+        const long t32 = (long)((a.M + 31) / 32) * ((a.N + 31) / 32);
+        if (t32 < 128 || a.K <= 512) {
+            const int r = estts_launch_gemm_oneshot(a, operand_kind(a), t32 < 128, 0, st);
+            if (r != 1) return r;
+        }
     }
     ESTTS_CHECK_ARG(a.batch <= 1 || (tile >= 5 && tile <= 8), "estts_gemm: batch > 1 needs an LDS-staged tile (tune 0 or 5..8)");
     ESTTS_CHECK_ARG(a.batch <= 65535, "estts_gemm: batch exceeds the grid limit");

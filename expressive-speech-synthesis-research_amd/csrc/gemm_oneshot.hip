@@ -1,0 +1,214 @@
+// estts_gemm for launches whose whole K extent fits in the registers of one workgroup: batch-1 synthesis, incremental
+// decoder steps, every dense layer / 1-D convolution with a few hundred output tiles and K <= 1536.
+//
+// Such launches are bound by dependent memory round trips, not by bandwidth or matrix work: a kernel that walks K in a
+// loop pays one round trip per iteration it cannot cover, then one more for its epilogue operands.  Here every wave issues
+// ALL its loads before it waits for any of them: first the epilogue operands of the outputs it will finish (scale, shift,
+// residual), then for each of its S <= 6 K-steps the A rows and the W fragments.  A workgroup owns a 16 T x 16 T tile of C
+// (T = 1 or 2); its NW waves take interleaved 32-wide K-steps.  Operands go from memory straight into the MFMA layout:
+// lane l = (i16, g) loads the 8 consecutive floats A[row i16][32 ks + 8 g .. + 7] (two float4; a wave touches 16 rows x
+// 128 B) and splits them into bf16 hi + lo in registers, and W is stored fragment-major (see gemm.hip), so no operand passes
+// through LDS.  The waves' partial tiles are summed through LDS once, and every wave finishes a share of the outputs.
+//
+// K index -> (tap, channel) needs c_per_tap % 8 == 0 (an 8-wide lane group never straddles a tap); K % 8 == 0.
+#include "common.h"
+#include "a_operand.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+__device__ __forceinline__ void split_bf16x8(const float4& x0, const float4& x1, bf16x8& hi, bf16x8& lo) {
+    bf16x4 h0, l0, h1, l1;
+    split_bf16x4(x0, h0, l0);
+    split_bf16x4(x1, h1, l1);
+    hi = (bf16x8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    lo = (bf16x8){l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+}
+
+template <int NSPLIT, int KIND, int T, int NW, int S>
+__global__ __launch_bounds__(NW * 64) void gemm_oneshot_kernel(const estts_gemm_args p) {
+    constexpr int NS = (NSPLIT > 1) ? 2 : 1;
+    constexpr int NF = 4 * T * T;                // accumulator registers per lane = 64-output groups of the tile
+    constexpr int OUTS = (NF + NW - 1) / NW;     // groups a wave finishes
+    __shared__ float red[NW * NF * 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15;
+    const int g = lane >> 4;
+    const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)));
+    const int m0 = tc.ty * 16 * T;
+    const int n0 = tc.tx * 16 * T;
+    const int KS = p.ldw >> 5;
+    const int nks = (p.K + 31) >> 5;
+
+    // ---- epilogue operands of the outputs this thread finishes: group f = (i T + j) 4 + r is element r of sub-tile (i, j)
+    float e_s1[OUTS], e_b1[OUTS], e_s2[OUTS], e_b2[OUTS], e_r[OUTS];
+    int e_row[OUTS], e_col[OUTS];
+    bool e_ok[OUTS];
+#pragma unroll
+    for (int o = 0; o < OUTS; ++o) {
+        const int f = wave + o * NW;
+        const int i = f / (4 * T), j = (f >> 2) % T, r = f & 3;
+        e_row[o] = m0 + i * 16 + g * 4 + r;
+        e_col[o] = n0 + j * 16 + i16;
+        e_ok[o] = f < NF && e_row[o] < p.M && e_col[o] < p.N;
+        const int col = e_ok[o] ? e_col[o] : 0;
+        const int row = e_ok[o] ? e_row[o] : 0;
+        e_s1[o] = p.s1 ? p.s1[col] : 1.0f;
+        e_b1[o] = p.b1 ? p.b1[col] : 0.0f;
+        e_s2[o] = p.s2 ? p.s2[col] : 1.0f;
+        e_b2[o] = p.s2 ? p.b2[col] : 0.0f;
+        e_r[o] = p.R ? p.R[(long)(p.r_mod > 0 ? row % p.r_mod : row) * p.ldr + col] : 0.0f;
+    }
+
+    // ---- all operand loads of this wave's K-steps
+    const float* a_ptr[T];
+    int a_pos[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int row = min(m0 + i * 16 + i16, p.M - 1);   // rows past M re-read the last one; their results are never stored
+        a_ptr[i] = p.A + (long)row * p.lda;
+        a_pos[i] = KIND == 2 ? row % p.conv_w : 0;
+    }
+    float4 av[S][T][2];
+    bool aok[S][T];
+    uint4 wh[S][T], wl[S][T];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int ks = wave + s * NW;
+        if (s < S - 1 || ks < nks) {                        // only a wave's last step can lie past K (uniform)
+            const int kk = ks * 32 + g * 8;
+            const bool kok = kk < p.K;
+            long off = kok ? kk : 0;                        // past K: re-read valid data of the row (W is zero there)
+            int dw = 0;
+            if (KIND == 2) {
+                const int tap = kk / p.c_per_tap;
+                dw = tap - p.conv_pl;
+                off = (long)dw * p.lda + (kk - tap * p.c_per_tap);
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                bool ok = true;
+                if (KIND == 2) ok = kok && (unsigned)(a_pos[i] + dw) < (unsigned)p.conv_w;
+                const float* src = a_ptr[i] + ((KIND == 2 && !ok) ? 0L : off);
+                av[s][i][0] = *reinterpret_cast<const float4*>(src);
+                av[s][i][1] = *reinterpret_cast<const float4*>(src + 4);
+                aok[s][i] = ok;
+            }
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const long woff = ((long)((n0 >> 4) + j) * KS + ks) * 512 + lane * 8;
+                wh[s][j] = *reinterpret_cast<const uint4*>(p.W_hi + woff);
+                if (NS == 2) wl[s][j] = *reinterpret_cast<const uint4*>(p.W_lo + woff);
+            }
+        }
+    }
+
+    // ---- matrix work, in the order the loads were issued
+    f32x4 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int ks = wave + s * NW;
+        if (s < S - 1 || ks < nks) {
+            bf16x8 ah[T], al[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                float4 x0 = av[s][i][0], x1 = av[s][i][1];
+                if (KIND == 2) { x0 = zero_unless(aok[s][i], x0); x1 = zero_unless(aok[s][i], x1); }
+                split_bf16x8(x0, x1, ah[i], al[i]);
+            }
+            // small terms first; consecutive MFMAs go to different accumulators
+            if (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], __builtin_bit_cast(bf16x8, wh[s][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], __builtin_bit_cast(bf16x8, wl[s][j]), acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], __builtin_bit_cast(bf16x8, wh[s][j]), acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- sum the waves' partial tiles; wave w finishes groups w, w + NW, ...
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * NF + (i * T + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < OUTS; ++o) {
+        const int f = wave + o * NW;
+        if (f < NF) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[(w * NF + f) * 64 + lane];
+            if (e_ok[o]) {
+                v = v * e_s1[o] + e_b1[o];
+                v = apply_act(v, p.act);
+                if (p.drop_rate > 0.0f)
+                    v = dropout_keep(p.drop_seed, p.drop_site, (uint32_t)(p.drop_row0 + e_row[o]), (uint32_t)e_col[o], p.drop_rate)
+                            ? v / (1.0f - p.drop_rate) : 0.0f;
+                v = v * p.alpha + e_r[o];
+                if (p.s2) v = v * e_s2[o] + e_b2[o];
+                p.C[(long)e_row[o] * p.ldc + e_col[o]] = v;
+            }
+        }
+    }
+}
+
+template <int NSPLIT, int KIND, int T, int NW>
+int launch_s(const estts_gemm_args& a, dim3 grid, int S, hipStream_t st) {
+#define ESTTS_ONESHOT_CASE(s_) \
+    case s_: hipLaunchKernelGGL((gemm_oneshot_kernel<NSPLIT, KIND, T, NW, s_>), grid, dim3(NW * 64), 0, st, a); break;
+    switch (S) {
+        ESTTS_ONESHOT_CASE(1) ESTTS_ONESHOT_CASE(2) ESTTS_ONESHOT_CASE(3)
+        ESTTS_ONESHOT_CASE(4) ESTTS_ONESHOT_CASE(5) ESTTS_ONESHOT_CASE(6)
+        default: return 1;
+    }
+#undef ESTTS_ONESHOT_CASE
+    ESTTS_CHECK_LAUNCH("estts_gemm");
+    return 0;
+}
+
+template <int KIND, int T, int NW>
+int launch_p(const estts_gemm_args& a, dim3 grid, int S, hipStream_t st) {
+    return a.precision == 3 ? launch_s<3, KIND, T, NW>(a, grid, S, st) : launch_s<1, KIND, T, NW>(a, grid, S, st);
+}
+
+template <int T, int NW>
+int launch_k(const estts_gemm_args& a, int kind, dim3 grid, int S, hipStream_t st) {
+    return kind == 1 ? launch_p<1, T, NW>(a, grid, S, st) : launch_p<2, T, NW>(a, grid, S, st);
+}
+
+}  // namespace
+
+int estts_launch_gemm_oneshot(const estts_gemm_args& a, int kind, int tile16, int waves, hipStream_t st) {
+    if ((kind != 1 && kind != 2) || (a.K & 7) || (a.c_per_tap & 7) || a.batch > 1) return 1;
+    const int nks = (a.K + 31) / 32;
+    if (waves == 0) waves = nks >= 8 ? 8 : 4;
+    if (waves != 4 && waves != 8) return 1;
+    const int S = (nks + waves - 1) / waves;
+    if (S > 6) return 1;
+    const int tm = tile16 ? 16 : 32;
+    dim3 grid((a.N + tm - 1) / tm, (a.M + tm - 1) / tm, 1);
+    if (grid.y > 65535) return 1;
+    if (tile16) return waves == 8 ? launch_k<1, 8>(a, kind, grid, S, st) : launch_k<1, 4>(a, kind, grid, S, st);
+    return waves == 8 ? launch_k<2, 8>(a, kind, grid, S, st) : launch_k<2, 4>(a, kind, grid, S, st);
+}

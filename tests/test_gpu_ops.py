@@ -86,7 +86,7 @@ def test_gemm_conv_epilogue(taps, lpad, cin, cout, T, B):
     assert (out_full[:, cout:] == 0).all()
 
 
-@pytest.mark.parametrize('tile', [1, 4, 5])
+@pytest.mark.parametrize('tile', [1, 4, 5, 9, 10, 9 | (4 << 16), 10 | (4 << 16)])
 def test_gemm_tile_layouts_identity_and_conv(tile):
     # identity input picks out W^T exactly (values exact in bf16): catches permuted fragment maps of each kernel
     K, N = 96, 160
@@ -109,6 +109,36 @@ def test_gemm_tile_layouts_identity_and_conv(tile):
     acc = sum(xp[:, j:j + T] @ kern[j].double() for j in range(taps)).reshape(B * T, cout)
     ref = (torch.tanh(acc * s1.double() + b1.double()) + res.double()) * s2.double() + b2.double()
     assert ((out.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
+
+
+@pytest.mark.parametrize('tile', [9, 10])
+@pytest.mark.parametrize('waves', [4, 8])
+@pytest.mark.parametrize('taps,cin,lpad', [(1, 32, 0), (1, 264, 0), (3, 96, 1), (5, 80, 2), (3, 256, 2), (1, 1536, 0)])
+def test_gemm_oneshot_kernel(tile, waves, taps, cin, lpad):
+    # the all-loads-up-front kernel at every K-step count a wave can hold (1..6), K tails inside a 32-wide step, rows past M,
+    # partial column tiles, several segments, both precisions; float64 reference
+    K = taps * cin
+    if (K + 31) // 32 > 6 * waves:
+        with pytest.raises(RuntimeError, match='one-shot'):
+            ops.gemm(torch.zeros(8, cin, device=DEV), PackedLinear(np.zeros((16, K), np.float32), device=DEV, taps=taps, lpad=lpad),
+                     torch.zeros(8, 16, device=DEV), tune=tile | (waves << 16))
+        return
+    B, T, N = 3, 23, 72
+    x = _rand(B * T, cin, seed=4)
+    kern = _rand(taps, cin, N, seed=5, scale=1 / math.sqrt(K))
+    s1, b1, s2, b2 = _rand(N, seed=6).abs() + 0.5, _rand(N, seed=7), _rand(N, seed=8).abs() + 0.5, _rand(N, seed=9)
+    res = _rand(T, N, seed=10)
+    lin = PackedLinear(kern.reshape(K, N).t().numpy(), bias=b1.numpy(), scale=s1.numpy(), device=DEV,
+                       taps=taps, lpad=lpad, act='relu', s2=s2.numpy(), b2=b2.numpy())
+    xp = torch.nn.functional.pad(x.double().view(B, T, cin), (0, 0, lpad, taps - 1 - lpad))
+    acc = sum(xp[:, j:j + T] @ kern[j].double() for j in range(taps)).reshape(B * T, N)
+    ref = (torch.relu(acc * s1.double() + b1.double()) * 0.5 + res.double().repeat(B, 1)) * s2.double() + b2.double()
+    for precision, tol in (('bf16x3', 3e-5), ('bf16', 2e-2)):
+        out = torch.full((B * T, N + 3), float('nan'), device=DEV)
+        ops.gemm(x.to(DEV), lin, out[:, :N], seg_len=T, residual=res.to(DEV), r_mod=T, alpha=0.5, precision=precision,
+                 tune=tile | (waves << 16))
+        assert ((out[:, :N].cpu().double() - ref).abs().max() / ref.abs().max()).item() < tol
+        assert torch.isnan(out[:, N:]).all()
 
 
 def test_gemm_posenc_residual_shared_rows():

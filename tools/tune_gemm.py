@@ -51,7 +51,7 @@ def main():
         ref = None
         res = []
         cands = [(t, sk, 0) for t, sk in itertools.product((1, 3), (1, 4))] + \
-                [(4, sk, wv) for sk, wv in itertools.product((1, 2, 3, 4, 6), (4, 8))] + [(6, 1, 0), (7, 1, 0), (8, 1, 0)]
+                [(4, sk, wv) for sk, wv in itertools.product((1, 2, 3, 4, 6), (4, 8))] + [(6, 1, 0), (7, 1, 0), (8, 1, 0)] + [(t, 1, wv) for t in (9, 10) for wv in (4, 8)]
         for tile, sk, wv in cands:
             tune = tile | (sk << 8) | (wv << 16)
             try:
