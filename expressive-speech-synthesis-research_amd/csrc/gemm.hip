@@ -794,6 +794,11 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         ESTTS_CHECK_ARG(r != 1, "estts_gemm: shape outside the one-shot kernel (dense / 1-D convolution, K and c_per_tap multiples of 8, K <= 192 x waves)");
         return r;
     }
+    if (tile == 11 || tile == 12) {  // explicit one-shot convolution kernel (source rows staged in LDS): 16 x 16 / 32 x 32 tiles
+        const int r = estts_launch_gemm_oneshot_conv(a, operand_kind(a), tile == 11, st);
+        ESTTS_CHECK_ARG(r != 1, "estts_gemm: shape outside the one-shot convolution kernel (1-D convolution, K and c_per_tap multiples of 8, K <= 1536, staged rows within 96 KiB)");
+        return r;
+    }
     if (tile == 4 && (a.tune & 0xff) == 0 && splitk == 0) {
         // launches of a few hundred small tiles: every load issued up front (gemm_oneshot.hip); 16 x 16 tiles while 32 x 32
         // ones would leave half the chip idle
@@ -803,6 +808,11 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         const long t32 = (long)((a.M + 31) / 32) * ((a.N + 31) / 32);
         if (t32 < 128 || a.K <= 512) {
             const int r = estts_launch_gemm_oneshot(a, operand_kind(a), t32 < 128, 0, st);
+            if (r != 1) return r;
+        } else if (a.taps > 1) {
+            // longer convolutions over 32 x 32 tiles: the tile's source rows once through LDS instead of once per tap
+            // (600 x 256 x 1536, three taps: 8.5 -> 7.3 us; 600 x 256 x 1280, five taps: 7.8 -> 6.7 us)
+            const int r = estts_launch_gemm_oneshot_conv(a, operand_kind(a), 0, st);
             if (r != 1) return r;
         }
     }

@@ -28,3 +28,5 @@ __device__ __forceinline__ bool gemm_y_first(const estts_gemm_args& p) {
 // envelope (the caller then takes another kernel), 0 after a launch, negative on a launch error.
 // tile16: 16 x 16 output tiles instead of 32 x 32; waves: 4 or 8 per workgroup, 0 = by K.
 int estts_launch_gemm_oneshot(const estts_gemm_args& a, int kind, int tile16, int waves, hipStream_t st);
+// The same for 1-D convolutions with the tile's source rows staged once in LDS (eight waves); same return values.
+int estts_launch_gemm_oneshot_conv(const estts_gemm_args& a, int kind, int tile16, hipStream_t st);

@@ -11,6 +11,8 @@
 // through LDS.  The waves' partial tiles are summed through LDS once, and every wave finishes a share of the outputs.
 //
 // K index -> (tap, channel) needs c_per_tap % 8 == 0 (an 8-wide lane group never straddles a tap); K % 8 == 0.
+#include <mutex>
+
 #include "common.h"
 #include "a_operand.h"
 #include "gemm_epilogue.h"
@@ -173,6 +175,195 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_kernel(const estts_gemm_
     }
 }
 
+// 1-D convolutions: the taps of a convolution re-read the same rows, shifted (three taps: every row three times).  This
+// variant fetches the 16 T + taps - 1 source rows of the tile ONCE (all waves, coalesced float4), splits them into bf16
+// hi + lo planes in LDS, and a wave reads the A fragment of (row block, tap, channel group) from there with one
+// ds_read_b128 per plane.  The W fragments are still requested first and land during the staging.  A staged row is raw
+// data; whether output row m may use source row m + tap - lpad (same sequence) is decided where the fragment is used.
+template <int NSPLIT, int T, int NW, int S>
+__global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_gemm_args p, const int rows_staged, const int lda_s) {
+    constexpr int NS = (NSPLIT > 1) ? 2 : 1;
+    constexpr int NF = 4 * T * T;
+    constexpr int OUTS = (NF + NW - 1) / NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];   // A planes, later the partial tiles
+    __bf16* a_hi = reinterpret_cast<__bf16*>(dyn_smem);
+    __bf16* a_lo = a_hi + rows_staged * lda_s;
+    float* red = reinterpret_cast<float*>(dyn_smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15;
+    const int g = lane >> 4;
+    const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)));
+    const int m0 = tc.ty * 16 * T;
+    const int n0 = tc.tx * 16 * T;
+    const int KS = p.ldw >> 5;
+    const int nks = (p.K + 31) >> 5;
+    const int C = p.c_per_tap;
+
+    // ---- W fragments of this wave's K-steps
+    uint4 wh[S][T], wl[S][T];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int ks = wave + s * NW;
+        if (s < S - 1 || ks < nks) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const long woff = ((long)((n0 >> 4) + j) * KS + ks) * 512 + lane * 8;
+                wh[s][j] = *reinterpret_cast<const uint4*>(p.W_hi + woff);
+                if (NS == 2) wl[s][j] = *reinterpret_cast<const uint4*>(p.W_lo + woff);
+            }
+        }
+    }
+
+    // ---- epilogue operands
+    float e_s1[OUTS], e_b1[OUTS], e_s2[OUTS], e_b2[OUTS], e_r[OUTS];
+    int e_row[OUTS], e_col[OUTS];
+    bool e_ok[OUTS];
+#pragma unroll
+    for (int o = 0; o < OUTS; ++o) {
+        const int f = wave + o * NW;
+        const int i = f / (4 * T), j = (f >> 2) % T, r = f & 3;
+        e_row[o] = m0 + i * 16 + g * 4 + r;
+        e_col[o] = n0 + j * 16 + i16;
+        e_ok[o] = f < NF && e_row[o] < p.M && e_col[o] < p.N;
+        const int col = e_ok[o] ? e_col[o] : 0;
+        const int row = e_ok[o] ? e_row[o] : 0;
+        e_s1[o] = p.s1 ? p.s1[col] : 1.0f;
+        e_b1[o] = p.b1 ? p.b1[col] : 0.0f;
+        e_s2[o] = p.s2 ? p.s2[col] : 1.0f;
+        e_b2[o] = p.s2 ? p.b2[col] : 0.0f;
+        e_r[o] = p.R ? p.R[(long)(p.r_mod > 0 ? row % p.r_mod : row) * p.ldr + col] : 0.0f;
+    }
+
+    // ---- stage source rows m0 - lpad .. + rows_staged - 1 (clamped into the buffer; validity is decided at use)
+    {
+        const int c4n = C >> 2;
+        const int total = rows_staged * c4n;
+        constexpr int MAXI = 10;      // float4 per thread the launcher guarantees to be enough
+        float4 x[MAXI];
+        int dst[MAXI];
+        // no load under a condition (it would become a branch that waits for its data): surplus slots repeat the last item
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int q = min(tid + it * (NW * 64), total - 1);
+            const int rr = q / c4n, c4 = q - rr * c4n;
+            const int src = min(max(m0 - p.conv_pl + rr, 0), p.M - 1);
+            x[it] = *reinterpret_cast<const float4*>(p.A + (long)src * p.lda + c4 * 4);
+            dst[it] = rr * lda_s + c4 * 4;
+        }
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            bf16x4 hi, lo;
+            split_bf16x4(x[it], hi, lo);
+            *reinterpret_cast<bf16x4*>(a_hi + dst[it]) = hi;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(a_lo + dst[it]) = lo;
+        }
+    }
+    __syncthreads();
+
+    int a_pos[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) a_pos[i] = min(m0 + i * 16 + i16, p.M - 1) % p.conv_w;
+
+    f32x4 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int ks = wave + s * NW;
+        if (s < S - 1 || ks < nks) {
+            const int kk = ks * 32 + g * 8;
+            const int tap = min(kk / C, p.taps - 1);
+            const int c0 = kk - tap * C;          // (past K: c0 >= C is never read because kok is false)
+            const bool kok = kk < p.K;
+            bf16x8 ah[T], al[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const bool ok = kok && (unsigned)(a_pos[i] + tap - p.conv_pl) < (unsigned)p.conv_w;
+                const int o = (i * 16 + i16 + tap) * lda_s + (kok ? c0 : 0);
+                // (masked word by word: a select between two 16-byte values is compiled into a table in scratch memory)
+                const unsigned keep = ok ? 0xffffffffu : 0u;
+                uint4 h = *reinterpret_cast<const uint4*>(a_hi + o);
+                h.x &= keep; h.y &= keep; h.z &= keep; h.w &= keep;
+                ah[i] = __builtin_bit_cast(bf16x8, h);
+                if (NS == 2) {
+                    uint4 l = *reinterpret_cast<const uint4*>(a_lo + o);
+                    l.x &= keep; l.y &= keep; l.z &= keep; l.w &= keep;
+                    al[i] = __builtin_bit_cast(bf16x8, l);
+                }
+            }
+            if (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], __builtin_bit_cast(bf16x8, wh[s][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+#pragma unroll
+                    for (int j = 0; j < T; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], __builtin_bit_cast(bf16x8, wl[s][j]), acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], __builtin_bit_cast(bf16x8, wh[s][j]), acc[i][j], 0, 0, 0);
+        }
+    }
+
+    __syncthreads();   // every wave is done with the A planes: the partial tiles take their place
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * NF + (i * T + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < OUTS; ++o) {
+        const int f = wave + o * NW;
+        if (f < NF) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[(w * NF + f) * 64 + lane];
+            if (e_ok[o]) {
+                v = v * e_s1[o] + e_b1[o];
+                v = apply_act(v, p.act);
+                if (p.drop_rate > 0.0f)
+                    v = dropout_keep(p.drop_seed, p.drop_site, (uint32_t)(p.drop_row0 + e_row[o]), (uint32_t)e_col[o], p.drop_rate)
+                            ? v / (1.0f - p.drop_rate) : 0.0f;
+                v = v * p.alpha + e_r[o];
+                if (p.s2) v = v * e_s2[o] + e_b2[o];
+                p.C[(long)e_row[o] * p.ldc + e_col[o]] = v;
+            }
+        }
+    }
+}
+
+template <int NSPLIT, int T>
+int launch_conv_s(const estts_gemm_args& a, dim3 grid, int S, int rows_staged, int lda_s, size_t smem, hipStream_t st) {
+#define ESTTS_ONESHOT_CASE(s_)                                                                                              \
+    case s_: {                                                                                                              \
+        auto kern = gemm_oneshot_conv_kernel<NSPLIT, T, 8, s_>;                                                            \
+        static std::once_flag once;                                                                                         \
+        std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); }); \
+        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, rows_staged, lda_s);                                         \
+    } break;
+    switch (S) {
+        ESTTS_ONESHOT_CASE(1) ESTTS_ONESHOT_CASE(2) ESTTS_ONESHOT_CASE(3)
+        ESTTS_ONESHOT_CASE(4) ESTTS_ONESHOT_CASE(5) ESTTS_ONESHOT_CASE(6)
+        default: return 1;
+    }
+#undef ESTTS_ONESHOT_CASE
+    ESTTS_CHECK_LAUNCH("estts_gemm");
+    return 0;
+}
+
 template <int NSPLIT, int KIND, int T, int NW>
 int launch_s(const estts_gemm_args& a, dim3 grid, int S, hipStream_t st) {
 #define ESTTS_ONESHOT_CASE(s_) \
@@ -198,6 +389,26 @@ int launch_k(const estts_gemm_args& a, int kind, dim3 grid, int S, hipStream_t s
 }
 
 }  // namespace
+
+int estts_launch_gemm_oneshot_conv(const estts_gemm_args& a, int kind, int tile16, hipStream_t st) {
+    if (kind != 2 || (a.K & 7) || (a.c_per_tap & 7) || a.batch > 1) return 1;
+    const int nks = (a.K + 31) / 32;
+    const int S = (nks + 7) / 8;
+    if (S > 6) return 1;
+    const int tm = tile16 ? 16 : 32;
+    const int rows_staged = tm + a.taps - 1;
+    const int lda_s = a.c_per_tap + 8;                                   // bf16 per staged row (+16 B: conflict-free b128 reads)
+    const size_t planes = (size_t)rows_staged * lda_s * 2 * (a.precision == 3 ? 2 : 1);
+    const size_t red = (size_t)8 * (tile16 ? 4 : 16) * 64 * 4;
+    const size_t smem = planes > red ? planes : red;
+    if (smem > 96 * 1024 || (long)rows_staged * (a.c_per_tap >> 2) > 10 * 512) return 1;
+    dim3 grid((a.N + tm - 1) / tm, (a.M + tm - 1) / tm, 1);
+    if (grid.y > 65535) return 1;
+    if (tile16) return a.precision == 3 ? launch_conv_s<3, 1>(a, grid, S, rows_staged, lda_s, smem, st)
+                                        : launch_conv_s<1, 1>(a, grid, S, rows_staged, lda_s, smem, st);
+    return a.precision == 3 ? launch_conv_s<3, 2>(a, grid, S, rows_staged, lda_s, smem, st)
+                            : launch_conv_s<1, 2>(a, grid, S, rows_staged, lda_s, smem, st);
+}
 
 int estts_launch_gemm_oneshot(const estts_gemm_args& a, int kind, int tile16, int waves, hipStream_t st) {
     if ((kind != 1 && kind != 2) || (a.K & 7) || (a.c_per_tap & 7) || a.batch > 1) return 1;

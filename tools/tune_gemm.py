@@ -51,12 +51,14 @@ def main():
         ref = None
         res = []
         cands = [(t, sk, 0) for t, sk in itertools.product((1, 3), (1, 4))] + \
-                [(4, sk, wv) for sk, wv in itertools.product((1, 2, 3, 4, 6), (4, 8))] + [(6, 1, 0), (7, 1, 0), (8, 1, 0)] + [(t, 1, wv) for t in (9, 10) for wv in (4, 8)]
+                [(4, sk, wv) for sk, wv in itertools.product((1, 2, 3, 4, 6), (4, 8))] + [(6, 1, 0), (7, 1, 0), (8, 1, 0)] + [(t, 1, wv) for t in (9, 10) for wv in (4, 8)] + [(11, 1, 0), (12, 1, 0)]
         for tile, sk, wv in cands:
             tune = tile | (sk << 8) | (wv << 16)
             try:
                 ops.gemm(x, lin, out, seg_len=M, precision=prec, tune=tune)
             except Exception as e:  # noqa
+                if os.environ.get('TUNE_VERBOSE'):
+                    print('   skipped', tile, sk, wv, str(e)[:100])
                 continue
             if ref is None:
                 ref = out.clone()
@@ -66,7 +68,7 @@ def main():
         ops.gemm(x, lin, out, seg_len=M, precision=prec)
         t_auto = timeit(lambda: ops.gemm(x, lin, out, seg_len=M, precision=prec))
         res.sort()
-        best = ' '.join(f'[t{tile} k{sk}: {t:5.1f}us e{err:.0e}]' for t, tile, sk, err in res[:6])
+        best = ' '.join(f'[t{tile} k{sk}: {t:5.1f}us e{err:.0e}]' for t, tile, sk, err in res[:(99 if os.environ.get('TUNE_VERBOSE') else 6)])
         print(f'M={M:4d} N={N:4d} K={K:4d} taps={taps} auto {t_auto:5.1f}us  {2e-6 * M * N * K / t_auto:6.1f} TF/s | best {best}', flush=True)
 
 
