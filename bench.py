@@ -586,6 +586,46 @@ def config1_cpu_seconds(args):
                          'sample': 'the whole workload: one utterance, float64 NumPy (oracle/audio_numpy.py)'}}))
 
 
+def in_flight_pass(w, cfg, tok_d, dur_d, T, want_attn, args, mel_ref):
+    """Serving shape of the batch-1 workload: k independent requests in flight, each a hipGraph of its own (own model
+    instance, own workspace) replayed on a HIP stream of its own.  A batch-1 forward is a chain of ~60 latency-bound launches
+    that leave most of the chip idle, so requests overlap.  Reported beside the headline value, which stays one request at
+    a time.  Every replica's mel must equal the one-at-a-time result bit for bit (same kernels, same inputs)."""
+    res = {'note': 'k independent batch-1 forwards in flight (one hipGraph and HIP stream each); the headline value is k = 1',
+           'points': []}
+    B = tok_d.shape[0]
+    replicas = []
+    for k in (2, 4):
+        while len(replicas) < k:
+            m = ForwardTransformer(w, cfg, precision=args.precision)
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                m.call(tok_d, target_durations=dur_d, max_frames=T, return_attention=want_attn)
+            torch.cuda.current_stream().wait_stream(st)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                o = m.call(tok_d, target_durations=dur_d, max_frames=T, return_attention=want_attn)
+            replicas.append((m, st, g, o))
+        torch.cuda.synchronize()
+        rounds = max(args.steps // k, 10)
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(rounds if timed else max(args.warmup // k, 3)):
+                for m, st, g, o in replicas[:k]:
+                    with torch.cuda.stream(st):
+                        g.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        same = all(bool(torch.equal(o['mel'], mel_ref)) for _, _, _, o in replicas[:k])
+        res['points'].append({'in_flight': k, 'value': k * rounds * B * T / dt, 'unit': 'mel-frames/s',
+                              'ms_per_forward': dt * 1e3 / (k * rounds), 'forwards_timed': k * rounds,
+                              'identical_to_one_at_a_time': same})
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -608,6 +648,8 @@ def main():
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
                          "AutoregressiveTransformer (config 3; use --batch 32); train: ForwardTransformer training step, "
                          "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
+    ap.add_argument('--no-in-flight', action='store_true',
+                    help='skip the block that runs several independent batch-1 forwards at once on HIP streams of their own')
     ap.add_argument('--no-wavernn', action='store_true',
                     help='skip the secondary passes of the default run: WaveRNN (config 4, reported under "wavernn") and the '
                          'child runs of configs 3 and 5 on one GPU ("config3", "config5_one_gpu")')
@@ -758,6 +800,8 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
+        if world == 1 and args.workload == 'forward' and graph is not None and not args.no_in_flight:
+            line['in_flight'] = in_flight_pass(w, cfg, tok_d, dur_d, T, want_attn, args, out['mel'])
         if world == 1 and not args.no_wavernn:
             line['wavernn'] = wavernn_pass(args.precision, cpu_leg=not args.no_cpu_baseline, kernel_table=args.kernel_table)
             if args.workload == 'forward' and B == 1:
