@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 27
+ABI_VERSION = 26
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -153,8 +153,6 @@ SIGNATURES = {
     'estts_bn_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'estts_dropout': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _u32, _u32, _vp]),
     'estts_axpby': (_i32, [_vp, _i32, _f32, _vp, _i32, _f32, _i32, _i32, _vp]),
-    'estts_posenc_scale': (_i32, [_vp, _vp, _vp, _i64, _vp]),
-    'estts_posenc_scalar_grad': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     'estts_head_scale': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     'estts_mine_divergence': (_i32, [_vp, _vp, _i32, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _f32, _vp]),
     'estts_mse': (_i32, [_vp, _vp, _i32, _vp, _vp, _f32, _vp]),

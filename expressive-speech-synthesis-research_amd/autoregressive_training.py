@@ -145,7 +145,6 @@ def _register_autoregressive_params(store, w, cfg, shapes):
             cnn(b + '.conv', 2)
 
     add('text_encoder_prenet.embeddings', w['text_encoder_prenet.embeddings'])
-    add('text_encoder.pos_encoding_scalar', w['text_encoder.pos_encoding_scalar'])     # tf.Variable(1.), layers.py:228: trainable
     for i in range(len(cfg['encoder_num_heads'])):
         b = f'text_encoder.block{i}'
         sarn(b + '.sarn')
@@ -176,7 +175,6 @@ def _register_autoregressive_params(store, w, cfg, shapes):
         add(p + '.gst_tokens', w[p + '.gst_tokens'])
     dense('decoder_prenet.d1')
     dense('decoder_prenet.d2')
-    add('decoder.pos_encoding_scalar', w['decoder.pos_encoding_scalar'])
     for i in range(len(cfg['decoder_num_heads'])):
         b = f'decoder.block{i}'
         sarn(b + '.sarn')
@@ -204,6 +202,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         self.r = self.max_r
         self.loss_weights = [1., 1., 1.]
         self.stop_scaling = float(cfg.get('stop_loss_scaling', 1.0))
+        self._pos_scalars = {k: float(np.asarray(weights[k + '.pos_encoding_scalar'])) for k in ('text_encoder', 'decoder')}
         self._orig_shapes = {}
         st = self.store = ParamStore(dev)
         _register_autoregressive_params(st, weights, cfg, self._orig_shapes)
@@ -214,11 +213,8 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         self.emb, self.demb = st.p['text_encoder_prenet.embeddings'], st.g['text_encoder_prenet.embeddings']
         if self.emb.shape[1] != de:
             raise ValueError('encoder_prenet_dimension must equal encoder_model_dimension')
-        self.pe_enc_raw = ops.positional_encoding_table(cfg['encoder_max_position_encoding'], de, dev)
-        self.pe_dec_raw = ops.positional_encoding_table(cfg['decoder_max_position_encoding'], dd, dev)
-        self.pe_enc, self.pe_dec = torch.empty_like(self.pe_enc_raw), torch.empty_like(self.pe_dec_raw)
-        self.pos_enc, self.dpos_enc = st.p['text_encoder.pos_encoding_scalar'], st.g['text_encoder.pos_encoding_scalar']
-        self.pos_dec, self.dpos_dec = st.p['decoder.pos_encoding_scalar'], st.g['decoder.pos_encoding_scalar']
+        self.pe_enc = ops.positional_encoding_table(cfg['encoder_max_position_encoding'], de, dev) * self._pos_scalars['text_encoder']
+        self.pe_dec = ops.positional_encoding_table(cfg['decoder_max_position_encoding'], dd, dev) * self._pos_scalars['decoder']
         self.enc_blocks = self._make_stack('text_encoder', de, cfg['encoder_num_heads'], cfg['encoder_dense_blocks'],
                                            cfg['encoder_attention_conv_kernel'])
         self.enc_names = self._attn_names('TextEncoder', cfg['encoder_num_heads'], cfg['encoder_dense_blocks'])
@@ -294,7 +290,10 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
 
     def weights(self):
         """Current variables as a dict name -> ndarray in the layouts of weights.py."""
-        return self._named(self.store.numpy())
+        out = self._named(self.store.numpy())
+        for k, s in self._pos_scalars.items():
+            out[k + '.pos_encoding_scalar'] = np.array(s, np.float32)
+        return out
 
     def gradients(self):
         """The gradients of the last step under the same names and layouts as weights() (tests, logging)."""
@@ -530,14 +529,12 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         key_mask = self._empty(B, N)
         cat0 = self._empty(Me, 2 * de)
         x0 = cat0[:, :de]
-        T.posenc_scale(self.pe_enc_raw, self.pos_enc, self.pe_enc)
         ops.embed_posenc(tokens, self.emb, self.pe_enc, None, x0, key_mask, math.sqrt(np.float32(de)))
         site0, rate0 = self._next_site(), self.dropout_rate
         T.dropout(x0, x0, rate0, self._seed_now, site0, M=Me, D=de)
 
         def embed_backward(dx):
             T.dropout(dx, dx, rate0, self._seed_now, site0, M=Me, D=de)
-            T.posenc_scalar_grad(dx, self.pe_enc_raw, N, self.dpos_enc, M=Me, D=de)
             T.embed_bwd(tokens, dx, self.demb, math.sqrt(np.float32(de)))
             return None
 
@@ -605,8 +602,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         self._lin_fwd(p1, self.prenet2, p2, Md, dropout=(rp, self._seed_now, 1001, 0))
         if self.gate_log is not None:
             self.gate_log += [p1 > 0, p2 > 0]
-        pe_raw = self.pe_dec_raw[0:Tt:r].contiguous()
-        pe = T.posenc_scale(pe_raw, self.pos_dec, torch.empty_like(pe_raw))
+        pe = self.pe_dec[0:Tt:r].contiguous()
         cat = self._empty(Md, 2 * dd)
         y0 = cat[:, :dd]
         T.affine_act(p2, y0, self.dec_scale, self.dec_shift, None, residual=pe, r_mod=Tq, M=Md, C=dd)
@@ -616,7 +612,6 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
 
         def prenet_backward(dy0):
             T.dropout(dy0, dy0, rate1, self._seed_now, site1, M=Md, D=dd)
-            T.posenc_scalar_grad(dy0, pe_raw, Tq, self.dpos_dec, M=Md, D=dd)
             T.axpby(dy0, dy0, alpha=math.sqrt(np.float32(dd)) * inv_keep, beta=0.0, M=Md, D=dd)
             T.colreduce(1, self.prenet2.db, g=dy0, a=p2, act='relu', dy_out=dy0, M=Md, C=dd)
             T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.backward_precision)

@@ -671,56 +671,6 @@ extern "C" int estts_axpby(const float* x, int32_t ldx, float alpha, float* out,
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Trainable scale of the positional encoding (SelfAttentionBlocks.pos_encoding_scalar, a tf.Variable that the optimizer
-// updates with every other variable): the table scaled by the scalar's current value for the forward pass, and the
-// scalar's gradient <dx, pe> summed over every (row, channel) -- row m of dx takes table row m % r_mod.
-// ------------------------------------------------------------------------------------------------------
-__global__ void posenc_scale_kernel(const float* __restrict__ pe, const float* __restrict__ scalar, float* __restrict__ out, long n4) {
-    const float s = scalar[0];
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        float4 v = reinterpret_cast<const float4*>(pe)[i];
-        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-        reinterpret_cast<float4*>(out)[i] = v;
-    }
-}
-
-__global__ __launch_bounds__(256) void posenc_scalar_grad_kernel(const float* __restrict__ dx, int ldx, const float* __restrict__ pe,
-                                                                 int r_mod, int M, int D, float* __restrict__ dscalar) {
-    __shared__ float part[4];
-    float acc = 0.0f;
-    const int d4 = D >> 2;
-    for (int m = blockIdx.x; m < M; m += gridDim.x) {
-        const float4* g = reinterpret_cast<const float4*>(dx + (long)m * ldx);
-        const float4* t = reinterpret_cast<const float4*>(pe + (long)(m % r_mod) * D);
-        for (int c = threadIdx.x; c < d4; c += blockDim.x) {
-            const float4 a = g[c], b = t[c];
-            acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-        }
-    }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f32(dscalar, part[0] + part[1] + part[2] + part[3]);
-}
-
-extern "C" int estts_posenc_scale(const float* pe, const float* scalar, float* out, int64_t n, void* stream) {
-    ESTTS_CHECK_ARG(pe && scalar && out && n > 0 && (n & 3) == 0, "estts_posenc_scale: bad arguments");
-    hipLaunchKernelGGL(posenc_scale_kernel, dim3(ew_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, pe, scalar, out, (long)(n >> 2));
-    ESTTS_CHECK_LAUNCH("estts_posenc_scale");
-    return 0;
-}
-
-extern "C" int estts_posenc_scalar_grad(const float* dx, int32_t ldx, const float* pe, int32_t r_mod, int32_t M, int32_t D,
-                                        float* dscalar, void* stream) {
-    ESTTS_CHECK_ARG(dx && pe && dscalar && M > 0 && D > 0 && r_mod > 0 && (D & 3) == 0 && (ldx & 3) == 0,
-                    "estts_posenc_scalar_grad: bad arguments");
-    hipLaunchKernelGGL(posenc_scalar_grad_kernel, dim3(M < 512 ? M : 512), dim3(256), 0, (hipStream_t)stream, dx, ldx, pe, r_mod, M, D,
-                       dscalar);
-    ESTTS_CHECK_LAUNCH("estts_posenc_scalar_grad");
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------------
 // Patches of a 2-D convolution over NHWC images (training of the GST reference encoder: the weight gradient and the data
 // gradient of Conv2D become a dense wgrad / GEMM over these rows).  One thread per patch value / per input value.
 // ------------------------------------------------------------------------------------------------------

@@ -35,8 +35,7 @@ class ParamStore:
         self._train, self._state = [], []
 
     def add(self, name, array, trainable=True):
-        a = np.asarray(array, dtype=np.float32)
-        a = np.ascontiguousarray(a).reshape(a.shape)       # (ascontiguousarray alone turns a scalar into a vector of one)
+        a = np.ascontiguousarray(np.asarray(array, dtype=np.float32))
         (self._train if trainable else self._state).append((name, a))
 
     def build(self):
@@ -203,16 +202,12 @@ def _register_forward_params(store, w, cfg):
                 cnn(b + '.conv', 2, True)
 
     store.add('encoder_prenet.embeddings', w['encoder_prenet.embeddings'])
-    # (pos_encoding_scalar is a tf.Variable of SelfAttentionBlocks, layers.py:228, hence trainable; each sits where the
-    # backward pass produces its gradient: beside the embedding / behind the decoder prenet)
-    store.add('encoder.pos_encoding_scalar', w['encoder.pos_encoding_scalar'])
     stack('encoder', cfg['encoder_num_heads'], cfg['encoder_dense_blocks'])
     cnn('dur_pred.conv_blocks', 2, False)
     store.add('dur_pred.linear.kernel', np.asarray(w['dur_pred.linear.kernel'])[:, 0])
     store.add('dur_pred.linear.bias', w['dur_pred.linear.bias'])
     dense('decoder_prenet.d1')
     dense('decoder_prenet.d2')
-    store.add('decoder.pos_encoding_scalar', w['decoder.pos_encoding_scalar'])
     stack('decoder', cfg['decoder_num_heads'], cfg['decoder_dense_blocks'])
     dense('out')
     cnn('decoder_postnet', cfg['postnet_conv_layers'], True)
@@ -258,6 +253,7 @@ class ForwardTransformerTrainer:
         self._init_common(config, device, precision, seed, process_group, bucket_mb)
         cfg = self.config
         self.loss_weights = [3., 1.]
+        self._pos_scalars = {k: float(np.asarray(weights[k + '.pos_encoding_scalar'])) for k in ('encoder', 'decoder')}
         dev = self.device
         st = self.store = ParamStore(dev)
         _register_forward_params(st, weights, cfg)
@@ -265,12 +261,8 @@ class ForwardTransformerTrainer:
         de, dd = cfg['encoder_model_dimension'], cfg['decoder_model_dimension']
         self.de, self.dd = de, dd
         self.emb, self.demb = st.p['encoder_prenet.embeddings'], st.g['encoder_prenet.embeddings']
-        # unscaled tables, and the tables under the trainable scalars' current values (refreshed at the start of a step)
-        self.pe_enc_raw = ops.positional_encoding_table(cfg['encoder_max_position_encoding'], de, dev)
-        self.pe_dec_raw = ops.positional_encoding_table(cfg['decoder_max_position_encoding'], dd, dev)
-        self.pe_enc, self.pe_dec = torch.empty_like(self.pe_enc_raw), torch.empty_like(self.pe_dec_raw)
-        self.pos_enc, self.dpos_enc = st.p['encoder.pos_encoding_scalar'], st.g['encoder.pos_encoding_scalar']
-        self.pos_dec, self.dpos_dec = st.p['decoder.pos_encoding_scalar'], st.g['decoder.pos_encoding_scalar']
+        self.pe_enc = ops.positional_encoding_table(cfg['encoder_max_position_encoding'], de, dev) * self._pos_scalars['encoder']
+        self.pe_dec = ops.positional_encoding_table(cfg['decoder_max_position_encoding'], dd, dev) * self._pos_scalars['decoder']
         self.enc_blocks = self._make_stack('encoder', de, cfg['encoder_num_heads'], cfg['encoder_dense_blocks'],
                                            cfg['encoder_attention_conv_kernel'])
         self.dec_blocks = self._make_stack('decoder', dd, cfg['decoder_num_heads'], cfg['decoder_dense_blocks'],
@@ -572,6 +564,8 @@ class ForwardTransformerTrainer:
                 out[k] = v.reshape(kk, v.shape[0] // kk, v.shape[1])
             else:
                 out[k] = v
+        for k, s in self._pos_scalars.items():
+            out[k + '.pos_encoding_scalar'] = np.array(s, np.float32)
         return out
 
     def _prepare_batch(self, input_sequence, target_sequence, target_durations):
@@ -619,8 +613,6 @@ class ForwardTransformerTrainer:
         Me, Md = B * N, B * Tm
         tape, enc_attn, dec_attn = [], {}, {}
         st.clear_gradients()
-        T.posenc_scale(self.pe_enc_raw, self.pos_enc, self.pe_enc)
-        T.posenc_scale(self.pe_dec_raw, self.pos_dec, self.pe_dec)
 
         # ---- encoder
         key_mask = self._empty(B, N)
@@ -632,7 +624,6 @@ class ForwardTransformerTrainer:
 
         def embed_backward(dx):
             T.dropout(dx, dx, self.dropout_rate, self._seed_now, site0, M=Me, D=de)
-            T.posenc_scalar_grad(dx, self.pe_enc_raw, N, self.dpos_enc, M=Me, D=de)
             T.embed_bwd(tokens, dx, self.demb, math.sqrt(np.float32(de)))
             return None
 
@@ -685,7 +676,6 @@ class ForwardTransformerTrainer:
 
         def prenet_backward(dy0):
             T.dropout(dy0, dy0, self.dropout_rate, self._seed_now, site1, M=Md, D=dd)
-            T.posenc_scalar_grad(dy0, self.pe_dec_raw, Tm, self.dpos_dec, M=Md, D=dd)
             T.axpby(dy0, dy0, alpha=math.sqrt(np.float32(dd)) * inv_keep, beta=0.0, M=Md, D=dd)
             T.colreduce(1, self.prenet2.db, g=dy0, a=p2, act='relu', dy_out=dy0, M=Md, C=dd)
             T.wgrad(p1, dy0, self.prenet2.dk, M=Md, precision=self.backward_precision)

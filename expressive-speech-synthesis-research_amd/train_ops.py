@@ -212,22 +212,6 @@ def axpby(x, out, alpha=1.0, beta=1.0, M=None, D=None):
     return out
 
 
-def posenc_scale(pe, scalar, out):
-    """out = scalar[0] * pe (the positional table under the trainable pos_encoding_scalar's current value)."""
-    check(_lib.load().estts_posenc_scale(pe.data_ptr(), scalar.data_ptr(), out.data_ptr(), pe.numel(), _stream()), 'estts_posenc_scale')
-    return out
-
-
-def posenc_scalar_grad(dx, pe, r_mod, dscalar, M=None, D=None):
-    """dscalar[0] += <dx, pe[m % r_mod]> over the M x D block of dx (pe: the unscaled table)."""
-    M = dx.shape[0] if M is None else M
-    D = dx.shape[1] if D is None else D
-    if pe.shape[1] != D or r_mod > pe.shape[0] or not pe.is_contiguous():
-        raise ValueError('posenc_scalar_grad: table must be contiguous [>= r_mod, D]')
-    check(_lib.load().estts_posenc_scalar_grad(dx.data_ptr(), dx.stride(0), pe.data_ptr(), r_mod, M, D, dscalar.data_ptr(), _stream()),
-          'estts_posenc_scalar_grad')
-
-
 def head_scale(x, scale, B, L, H, depth):
     check(_lib.load().estts_head_scale(x.data_ptr(), x.stride(0), scale.data_ptr(), B, L, H, depth, _stream()), 'estts_head_scale')
     return x

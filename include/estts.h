@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 27
+#define ESTTS_ABI_VERSION 26
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -521,16 +521,6 @@ int estts_dropout(const float* x, int32_t ldx, float* out, int32_t ldo, int32_t 
 /* out[m, c] = beta * out[m, c] + alpha * x[m, c]   (gradient accumulation on residual paths) */
 int estts_axpby(const float* x, int32_t ldx, float alpha, float* out, int32_t ldo, float beta, int32_t M, int32_t D,
                 void* stream);
-
-/* Trainable positional-encoding scale (SelfAttentionBlocks.pos_encoding_scalar = tf.Variable(1.), TransformerTTS/model/
- * layers.py:228, used at :245 as x += pos_encoding_scalar * pos_encoding[:, :seq_len]; it is one of model.trainable_variables,
- * so the optimizer step at pretrained_models/for_text_encoder/models.py:402-403 updates it).
- * estts_posenc_scale: out[i] = scalar[0] * pe[i] for n floats (n a multiple of 4): the table the forward pass adds.
- * estts_posenc_scalar_grad: dscalar[0] += sum_{m < M, c < D} dx[m, c] * pe[m % r_mod, c] (float atomics; pe is the UNSCALED
- * table, D floats per row). */
-int estts_posenc_scale(const float* pe, const float* scalar, float* out, int64_t n, void* stream);
-int estts_posenc_scalar_grad(const float* dx, int32_t ldx, const float* pe, int32_t r_mod, int32_t M, int32_t D,
-                             float* dscalar, void* stream);
 
 /* Patches of a 2-D convolution over an NHWC image x [B, H, W, C] (TensorFlow 'SAME' geometry: pad_t / pad_l on the low
  * side): out[(b, ho, wo), (kh_i * kw + kw_i) * C + c] = x[b, ho * stride + kh_i - pad_t, wo * stride + kw_i - pad_l, c], zero

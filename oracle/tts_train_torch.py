@@ -146,7 +146,7 @@ def forward_train_step(w, cfg, tokens, mel, durations, masks=None, head_keep=Non
     wt = {}
     for k, v in w.items():
         t = torch.as_tensor(np.asarray(v)).to(dt)
-        trainable = not (k.endswith('moving_mean') or k.endswith('moving_variance'))   # pos_encoding_scalar is a tf.Variable: trained
+        trainable = not (k.endswith('moving_mean') or k.endswith('moving_variance') or k.endswith('pos_encoding_scalar'))
         wt[k] = t.clone().requires_grad_(trainable)
     signs = None
     if gates is not None:
@@ -269,7 +269,7 @@ def autoregressive_train_step(w, cfg, tokens, tar_mel, tar_real, tar_stop, spk_e
     wt = {}
     for k, v in w.items():
         t = torch.as_tensor(np.asarray(v)).to(dt)
-        trainable = not (k.endswith('moving_mean') or k.endswith('moving_variance'))   # pos_encoding_scalar is a tf.Variable: trained
+        trainable = not (k.endswith('moving_mean') or k.endswith('moving_variance') or k.endswith('pos_encoding_scalar'))
         wt[k] = t.clone().requires_grad_(trainable)
     signs = None
     if gates is not None:

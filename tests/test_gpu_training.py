@@ -270,9 +270,8 @@ def test_global_lengths_rescale_losses_and_gradients():
     oa = a.train_step(tokens, mel, durs)
     ob = b.train_step(tokens, mel, durs, global_lengths=(Tm + 9, N + 5))
     fm, fd = Tm / (Tm + 9), N / (N + 5)
-    # (the loss sums are float atomics: two runs of the same step differ in the last bits)
-    assert abs(float(ob['losses']['mel']) - fm * float(oa['losses']['mel'])) < 3e-6 * max(1.0, float(oa['losses']['mel']))
-    assert abs(float(ob['losses']['duration']) - fd * float(oa['losses']['duration'])) < 3e-6 * max(1.0, float(oa['losses']['duration']))
+    assert abs(float(ob['losses']['mel']) - fm * float(oa['losses']['mel'])) < 1e-6
+    assert abs(float(ob['losses']['duration']) - fd * float(oa['losses']['duration'])) < 1e-6
     ga, gb = grads_by_name(a), grads_by_name(b)
     last_beta = f"decoder_postnet.norm{cfg['postnet_conv_layers']}.beta"
     assert np.abs(ga[last_beta]).max() > 1e-4
@@ -318,9 +317,7 @@ def test_checkpoint_resume_equals_uninterrupted_training(tmp_path):
     err = np.abs(resumed.store.flat.cpu().numpy() - ref)
     err_cold = np.abs(cold.store.flat.cpu().numpy() - ref)
     print(f'resume: mean |dw| {err.mean():.2e} (with the moments) vs {err_cold.mean():.2e} (without), lr {lr}')
-    # (measured: 5e-5 .. 1e-4 with the moments against 8e-4 without; the two positional scalars are single numbers whose
-    # gradients cancel to ~1e-2 of their terms, so run-to-run noise can turn their +-lr steps and with them every activation)
-    assert err.mean() < 0.15 * lr and err_cold.mean() > 5 * err.mean()
+    assert err.mean() < 0.1 * lr and err_cold.mean() > 10 * err.mean()
 
 
 def tight_compare(model, ref, tol=1e-3):
@@ -333,12 +330,6 @@ def tight_compare(model, ref, tol=1e-3):
         scale = np.abs(r).max()
         if scale < 1e-7:
             assert np.abs(a).max() < 1e-5, k
-            continue
-        if k.endswith('.pos_encoding_scalar'):
-            # one number: the sum of a stack's whole input gradient times the table, whose sine / cosine columns cancel to
-            # ~1e-2 of the terms, so the ~1e-5 rounding of the terms shows as up to 5e-3 of the sum (measured 2e-6 .. 6e-5
-            # absolute on gradients of 1e-3 .. 3e-1, beside tensors of the same stage that agree to 6e-4)
-            assert abs(float(a) - float(r)) < 1e-2 * scale + 1e-6, (k, float(a), float(r))
             continue
         errs.append((float(np.abs(a - r).max() / scale), k))
     errs.sort(reverse=True)
