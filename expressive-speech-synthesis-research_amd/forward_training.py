@@ -35,7 +35,8 @@ class ParamStore:
         self._train, self._state = [], []
 
     def add(self, name, array, trainable=True):
-        a = np.ascontiguousarray(np.asarray(array, dtype=np.float32))
+        a = np.asarray(array, dtype=np.float32)
+        a = np.ascontiguousarray(a).reshape(a.shape)       # (ascontiguousarray alone turns a scalar into a vector of one)
         (self._train if trainable else self._state).append((name, a))
 
     def build(self):

@@ -270,8 +270,9 @@ def test_global_lengths_rescale_losses_and_gradients():
     oa = a.train_step(tokens, mel, durs)
     ob = b.train_step(tokens, mel, durs, global_lengths=(Tm + 9, N + 5))
     fm, fd = Tm / (Tm + 9), N / (N + 5)
-    assert abs(float(ob['losses']['mel']) - fm * float(oa['losses']['mel'])) < 1e-6
-    assert abs(float(ob['losses']['duration']) - fd * float(oa['losses']['duration'])) < 1e-6
+    # (the loss sums are float atomics: two runs of the same step differ in the last bits)
+    assert abs(float(ob['losses']['mel']) - fm * float(oa['losses']['mel'])) < 3e-6 * max(1.0, float(oa['losses']['mel']))
+    assert abs(float(ob['losses']['duration']) - fd * float(oa['losses']['duration'])) < 3e-6 * max(1.0, float(oa['losses']['duration']))
     ga, gb = grads_by_name(a), grads_by_name(b)
     last_beta = f"decoder_postnet.norm{cfg['postnet_conv_layers']}.beta"
     assert np.abs(ga[last_beta]).max() > 1e-4
