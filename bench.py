@@ -218,6 +218,19 @@ def wavernn_pass(precision, cpu_leg=True, kernel_table=False):
 NO_ROOFLINE = False
 
 
+def csrc_hash():
+    """SHA-1 over the kernel sources (the same digest tools/update_pmc_traffic.py stores beside the PMC figures)."""
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'expressive-speech-synthesis-research_amd', 'csrc')
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.h')):
+            h.update(name.encode())
+            with open(os.path.join(csrc, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def roofline_from_trace(trace, kernel_table, rank):
     """Groups the traced launches by kernel and shape, times one representative of every group in isolation and prices
     the dominant group against its roofline."""
@@ -255,7 +268,12 @@ def roofline_from_trace(trace, kernel_table, rank):
     roofline['traffic'] = None
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as f:
-            pmc = json.load(f).get(roofline['kernel'])
+            table = json.load(f)
+        pmc = table.get(roofline['kernel'])
+        if pmc and table.get('csrc_sha1') != csrc_hash():
+            # the kernels changed after the counter passes: an old measurement must not pass for the new code
+            roofline['traffic_source'] = 'stale: kernel sources changed since the PMC passes (tools/update_pmc_traffic.py)'
+            pmc = None
         if pmc:
             roofline['traffic'] = pmc['hbm_bytes']
             roofline['traffic_source'] = pmc['source']

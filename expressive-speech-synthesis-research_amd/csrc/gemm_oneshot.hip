@@ -345,13 +345,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
     }
 }
 
+// Dynamic LDS beyond 64 KiB has to be allowed per kernel and device before the first launch.
+std::mutex g_attr_mutex;
+bool allow_large_lds(const void* kern, bool (&raised)[64]) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        estts_set_error("estts_gemm: hipGetDevice failed or device index %d out of range", dev);
+        return false;
+    }
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    if (!raised[dev]) {
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) {
+            estts_set_error("estts_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+            return false;
+        }
+        raised[dev] = true;
+    }
+    return true;
+}
+
 template <int NSPLIT, int T>
 int launch_conv_s(const estts_gemm_args& a, dim3 grid, int S, int rows_staged, int lda_s, size_t smem, hipStream_t st) {
 #define ESTTS_ONESHOT_CASE(s_)                                                                                              \
     case s_: {                                                                                                              \
         auto kern = gemm_oneshot_conv_kernel<NSPLIT, T, 8, s_>;                                                            \
-        static std::once_flag once;                                                                                         \
-        std::call_once(once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); }); \
+        static bool raised[64] = {};       /* per GPU: the attribute belongs to the device's copy of the kernel */         \
+        if (!allow_large_lds(reinterpret_cast<const void*>(kern), raised)) return -2;                                      \
         hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, rows_staged, lda_s);                                         \
     } break;
     switch (S) {

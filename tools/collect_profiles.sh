@@ -20,7 +20,7 @@ prof() {   # name, bench arguments...
   grep '^{' $O/tmp_$name.log | tail -n 1 > $O/${P}_bench_${name}_under_rocprof.json
   rm -rf $O/tmp_$name $O/tmp_$name.log
 }
-prof forward_b1 --steps 200 --warmup 20 --no-wavernn --no-cpu-baseline
+prof forward_b1 --steps 200 --warmup 20 --no-wavernn --no-cpu-baseline --no-in-flight
 prof gst_b32 --workload gst --batch 32 --steps 20 --warmup 3 --no-cpu-baseline --no-wavernn
 prof train_b32 --workload train --batch 32 --steps 10 --warmup 3 --no-cpu-baseline
 prof train_b32_steps_only --workload train --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline
@@ -40,10 +40,12 @@ table train_ar --workload train_ar --batch 8 --steps 10 --warmup 3
 
 for c in FETCH_SIZE WRITE_SIZE; do
   say pmc $c
-  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/tmp_pmc -o p -- python3 bench.py --steps 20 --warmup 2 --no-wavernn --no-cpu-baseline --no-roofline > $O/tmp_pmc.log 2>&1
+  timeout -s KILL 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/tmp_pmc -o p -- python3 bench.py --steps 20 --warmup 2 --no-wavernn --no-cpu-baseline --no-roofline --no-in-flight > $O/tmp_pmc.log 2>&1
   cp $O/tmp_pmc/p_counter_collection.csv $O/${P}_pmc_forward_b1_$c.csv
   rm -rf $O/tmp_pmc $O/tmp_pmc.log
 done
+say pmc table '(copy into profiles/ together with the two CSV files)'
+python3 tools/update_pmc_traffic.py $O/${P}_pmc_forward_b1_FETCH_SIZE.csv $O/${P}_pmc_forward_b1_WRITE_SIZE.csv > /dev/null && cp profiles/pmc_traffic.json $O/pmc_traffic.json
 say precision sweep
 timeout -k 10 400 python3 -u tests/precision_sweep.py --out $O/${P}_precision_sweep.json > $O/${P}_precision_sweep.txt 2>&1
 say config 1

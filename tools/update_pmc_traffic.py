@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Rebuild profiles/pmc_traffic.json (HBM bytes per launch of the kernels bench.py quotes a roofline for) from a pair of
+rocprofv3 --pmc passes, and stamp it with a hash of the kernel sources it was measured on: bench.py reports `traffic` only
+while that hash matches the tree, so a changed kernel cannot inherit an old measurement.
+
+usage: update_pmc_traffic.py FETCH_SIZE.csv WRITE_SIZE.csv"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'expressive-speech-synthesis-research_amd', 'csrc')
+
+# bench.py roofline key -> (substring of the kernel name, note appended to the source line)
+KERNELS = {
+    'gemm {"M": 100, "N": 512, "K": 1536, "taps": 3}': (
+        'gemm_oneshot_kernel<3, 2, 1, 8, 6>',
+        ' (the eight M = 100, N = 512, K = 3 x 512 convolution launches of each forward; 224 workgroups of 16 x 16 outputs)'),
+    'attention {"B": 1, "H": 4, "Lq": 600, "Lk": 600, "depth": 64, "weights": true}': ('attention_kernel<64, 2, 3, 8>', ''),
+}
+
+
+def csrc_hash():
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith(('.hip', '.h')):
+            h.update(name.encode())
+            with open(os.path.join(CSRC, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def main():
+    fetch, write = sys.argv[1], sys.argv[2]
+    rows = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), fetch, write]))
+    out = {'csrc_sha1': csrc_hash()}
+    for key, (pat, note) in KERNELS.items():
+        hit = [r for r in rows if pat in r['kernel']]
+        if not hit:
+            print(f'no dispatch of {pat} in the passes', file=sys.stderr)
+            continue
+        r = max(hit, key=lambda x: x['dispatches'])
+        out[key] = {
+            'hbm_bytes': round(r['hbm_bytes']), 'read_bytes': round(r['read_bytes']), 'write_bytes': round(r['write_bytes']),
+            'source': f"profiles/{os.path.basename(fetch)} + {os.path.basename(write)} (rocprofv3 --pmc, separate passes; read = 2 x "
+                      f"FETCH_SIZE KiB per the gfx950 correction, write = WRITE_SIZE KiB), mean of {r['dispatches']} dispatches of "
+                      f"{pat} with {r['grid']} threads{note}, summarised by tools/pmc_summary.py"}
+    with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
