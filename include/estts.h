@@ -71,8 +71,12 @@ const char* estts_last_error(void);
  * output tile through float32 slabs in ws (ws_bytes >= splitk * tiles * tile_elems * 4) and one
  * int32 ticket per tile in counters (n_counters of them, zero before the first launch; the kernel
  * leaves them zero).  Calls that may overlap on the GPU must not share ws / counters.
- * tune: 0 = choose tile and split automatically; else (tile id 1..5) | (splitk << 8) | (waves << 16,
- * tile 4 only: 4, 8 or 16 waves per workgroup, 0 = by K).  Tile 5 (128 x 128) does not split K.
+ * tune: 0 = choose tile and split automatically; else (tile id) | (splitk << 8) | (waves << 16).  Tile ids: 1..3 LDS-staged
+ * 64 x 64 / 32 x 64 / 32 x 32 with split-K; 4 register-ring 32 x 32 (waves: 4, 8 or 16 per workgroup, 0 = by K; split-K);
+ * 5..8 LDS-staged 128 x 128 / 64 x 64 / 128 x 64 / 64 x 128 for thousands of rows (no split-K); 9 / 10 one-shot 16 x 16 /
+ * 32 x 32 (every load issued up front: dense layers and 1-D convolutions with K <= 192 x waves, K and c_per_tap multiples
+ * of 8; waves 4 or 8); 11 / 12 the same for convolutions with the tile's source rows staged once in LDS.  An explicit id
+ * outside its kernel's envelope is an error; tune = 0 never fails on shape.
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_gemm_args {
     const float* A;

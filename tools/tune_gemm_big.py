@@ -31,13 +31,16 @@ def main():
         out = torch.empty(M, N, device='cuda')
         res = []
         ref = None
-        for tile in (4, 5, 6, 7, 8):
-            ops.gemm(x, lin, out, seg_len=M, precision=prec, tune=tile | (1 << 8))
+        for tile in (4, 5, 6, 7, 8, 10 | (4 << 16), 10 | (8 << 16), 12):
+            try:
+                ops.gemm(x, lin, out, seg_len=M, precision=prec, tune=tile | (1 << 8))
+            except RuntimeError:
+                continue
             if ref is None:
                 ref = out.clone()
             err = (out - ref).abs().max().item()
             t = timeit(lambda: ops.gemm(x, lin, out, seg_len=M, precision=prec, tune=tile | (1 << 8)), reps=10, rounds=3)
-            res.append(f'tile{tile} {t:8.1f} us {2.0 * M * N * K / t / 1e6:7.1f} TF/s (d {err:.1e})')
+            res.append(f'tile{tile & 0xff}{"w%d" % (tile >> 16) if tile >> 16 else ""} {t:8.1f} us {2.0 * M * N * K / t / 1e6:7.1f} TF/s (d {err:.1e})')
         print(f'M={M:6d} N={N:5d} K={K:5d} taps={taps} | ' + ' | '.join(res), flush=True)
 
 
