@@ -13,6 +13,7 @@ from estts import ops
 from estts.ops import PackedLinear
 
 SHAPES = [  # (M, N, K, taps)
+    (32, 512, 1536, 1), (32, 1536, 512, 1), (1, 512, 1536, 1), (1, 1536, 512, 1),
     (100, 1536, 512, 1), (100, 512, 1024, 1), (100, 512, 512, 1), (100, 512, 1536, 3),
     (600, 1024, 512, 1), (600, 256, 1024, 1), (600, 768, 256, 1), (600, 256, 512, 1), (600, 512, 768, 3),
     (600, 256, 1536, 3), (600, 80, 256, 1), (600, 256, 400, 5), (600, 256, 1280, 5), (600, 80, 1280, 5),
