@@ -144,6 +144,53 @@ def test_gemm_oneshot_kernel(tile, waves, taps, cin, lpad):
         assert torch.isnan(out[:, N:]).all()
 
 
+def test_gemm_oneshot_kernels_agree_with_the_ring_kernel_on_random_shapes():
+    # 120 random dense / convolution shapes (row counts from 1, column counts that leave partial tiles, K tails inside a 32-wide
+    # step, 1..4 sequences so that tiles straddle sequence boundaries, causal and 'same' padding, padded row strides on input,
+    # output and residual, r_mod): every one-shot kernel that accepts the shape against the register-ring kernel (tile 4),
+    # which the float64 tests above pin.  Same products in a different summation order: 2e-5 of the output range.
+    rng = np.random.default_rng(7)
+    checked = 0
+    for case in range(120):
+        taps = int(rng.choice([1, 1, 3, 5]))
+        cin = 8 * int(rng.integers(1, 40 if taps == 1 else 24))
+        K = taps * cin
+        if K > 1536:
+            continue
+        B, T = int(rng.integers(1, 5)), int(rng.integers(1, 70))
+        N = int(rng.integers(1, 150))
+        lpad = int(rng.integers(0, taps))
+        M = B * T
+        pa, pc, pr = (4 * int(rng.integers(0, 3)) for _ in range(3))
+        x = _rand(M, cin + pa, seed=1000 + case)
+        w = _rand(N, K, seed=2000 + case, scale=1 / math.sqrt(K))
+        b1, s1 = _rand(N, seed=3000 + case), _rand(N, seed=4000 + case).abs() + 0.5
+        use_rmod = bool(rng.integers(0, 2)) and T > 1
+        res = _rand(T if use_rmod else M, N + pr, seed=5000 + case)
+        lin = PackedLinear(w.numpy(), bias=b1.numpy(), scale=s1.numpy(), device=DEV, taps=taps, lpad=lpad, act='tanh')
+        xd, rd = x.to(DEV), res.to(DEV)
+
+        def run(tune):
+            out = torch.full((M, N + pc), float('nan'), device=DEV)
+            ops.gemm(xd[:, :cin], lin, out[:, :N], seg_len=T, residual=rd[:, :N], r_mod=T if use_rmod else 0, alpha=0.7,
+                     precision='bf16x3', tune=tune)
+            assert torch.isnan(out[:, N:]).all()
+            return out[:, :N].clone()
+
+        ref = run(4)
+        assert torch.isfinite(ref).all()
+        for tune in (9 | (4 << 16), 9 | (8 << 16), 10 | (4 << 16), 10 | (8 << 16), 11, 12, 0):
+            try:
+                got = run(tune)
+            except RuntimeError as e:
+                assert 'one-shot' in str(e), e          # outside that kernel's envelope (K-steps per wave, taps == 1)
+                continue
+            err = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-3)).item()
+            assert err < 2e-5, (case, tune, M, N, K, taps, lpad, T, err)
+            checked += 1
+    assert checked > 400
+
+
 def test_gemm_posenc_residual_shared_rows():
     B, T, K, N = 3, 17, 64, 32
     x, w, pe = _rand(B * T, K, seed=1), _rand(N, K, seed=2, scale=0.1), _rand(40, N, seed=3)
