@@ -75,6 +75,29 @@ def test_small_model_predicted_durations_and_speed():
         assert np.abs(out['duration'].cpu().numpy() - ref['duration']).max() < 1e-4
 
 
+def test_graph_call_replays_the_eager_call():
+    """graph_call (one hipGraph per shape) gives what call gives, bit for bit, for every new input of that shape: target
+    durations, predicted durations with a fixed frame count, a second batch through the same graph, a second shape."""
+    cfg = small_cfg()
+    w = weights.init_forward_transformer(cfg, seed=11)
+    model = ForwardTransformer(w, cfg, precision='bf16x3')
+    eager = ForwardTransformer(w, cfg, precision='bf16x3')       # workspaces of its own: graph buffers stay untouched
+    for B, N, seed in ((3, 21, 5), (3, 21, 6), (1, 17, 7)):
+        tokens, durs = _inputs(cfg, B, N, seed=seed)
+        T = 4 * N + 6                                             # fixed per shape: past the longest possible utterance
+        ref = eager.call(tokens, target_durations=durs, max_frames=T)
+        out = model.graph_call(tokens, target_durations=durs, max_frames=T)
+        assert torch.equal(out['mel'], ref['mel']) and torch.equal(out['expanded_mask'], ref['expanded_mask'])
+        for k, v in ref['decoder_attention'].items():
+            assert torch.equal(out['decoder_attention'][k], v)
+        ref = eager.call(tokens, max_frames=T, durations_scalar=1.3)
+        out = model.graph_call(tokens, max_frames=T, durations_scalar=1.3)
+        assert torch.equal(out['mel'], ref['mel']) and torch.equal(out['duration'], ref['duration'])
+    assert len(model._graphs) == 4                                # (3, 21) twice through the same two graphs
+    with pytest.raises(ValueError, match='max_frames'):
+        model.graph_call(tokens)
+
+
 def test_bf16_mode_error_is_bounded():
     cfg = small_cfg()
     w = weights.init_forward_transformer(cfg, seed=11)
