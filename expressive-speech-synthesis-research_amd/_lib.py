@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -28,7 +28,9 @@ class GemmArgs(C.Structure):
                 ('conv_stride', _i32), ('conv_pt', _i32), ('conv_pl', _i32),
                 ('drop_rate', _f32), ('drop_seed', _u32), ('drop_site', _u32), ('drop_row0', _i32),
                 ('batch', _i32), ('batch_stride_a', _i64), ('batch_stride_w', _i64), ('batch_stride_c', _i64),
-                ('batch_stride_v', _i64)]
+                ('batch_stride_v', _i64),
+                ('ln_y', _vp), ('ln_x', _vp), ('ln_ga', _vp), ('ln_ba', _vp), ('ln_gb', _vp), ('ln_bb', _vp), ('ln_out', _vp),
+                ('ln_ldy', _i32), ('ln_ldx', _i32), ('ln_ldo', _i32), ('ln_act', _i32), ('ln_eps', _f32)]
 
 
 class AttentionArgs(C.Structure):

@@ -66,13 +66,17 @@ class SelfAttentionLayer:
         self.last_ln = pack_ln(w, p + '.last_ln', device)
         self.d, self.heads = d, heads
 
-    def run(self, xc, qkv, y, x1, B, L, key_mask, causal, attn, precision):
+    def run(self, xc, qkv, y, x1, B, L, key_mask, causal, attn, precision, defer_norm=False):
+        """defer_norm: leave LN(LN(y) + x) to the convolution that consumes it (ops.gemm(ln=...)); returns its description."""
         d = self.d
         ops.gemm(xc[:, :d], self.qkv, qkv, precision=precision, site='qkv')
         ops.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], xc[:, d:], B, self.heads, L, L, d // self.heads,
                       key_mask=key_mask, causal=causal, attn=attn, precision=precision)
         ops.gemm(xc, self.out, y, precision=precision, site='attn_out')
+        if defer_norm:
+            return dict(y=y, x=xc[:, :d], ln_a=self.ln, ln_b=self.last_ln, out=x1)
         ops.rownorm(y, x1, ln_a=self.ln, residual=xc[:, :d], ln_b=self.last_ln)
+        return None
 
 
 class FFNLayer:
@@ -119,13 +123,19 @@ class ConvBNLayer:
     def hidden(self):
         return max([l.N for l in self.layers[:-1]] + [0])
 
-    def run(self, x, h_a, h_b, out, seg_len, precision, site='conv'):
-        """x: block input view; h_a/h_b: two scratch buffers wide enough for the hidden size; out: output view."""
+    def can_take_norm(self, M, precision, site='conv'):
+        """True when the block's first convolution can compute its input as a deferred LayerNorm combination (it must not be
+        the layer that adds the block input back: that one reads rows other workgroups are still writing)."""
+        return len(self.layers) >= 2 and ops.can_fuse_ln(self.layers[0], M, precision=precision, site=site)
+
+    def run(self, x, h_a, h_b, out, seg_len, precision, site='conv', ln=None):
+        """x: block input view; h_a/h_b: two scratch buffers wide enough for the hidden size; out: output view.
+        ln: the block input is still to be computed (SelfAttentionLayer.run(defer_norm=True)): the first convolution does it."""
         src = x
         bufs = (h_a, h_b)
         for i, lin in enumerate(self.layers[:-1]):
             dst = bufs[i & 1][:, :lin.N]
-            ops.gemm(src, lin, dst, seg_len=seg_len, precision=precision, site=site)
+            ops.gemm(src, lin, dst, seg_len=seg_len, precision=precision, site=site, ln=ln if i == 0 else None)
             src = dst
         ops.gemm(src, self.layers[-1], out, seg_len=seg_len, residual=x, precision=precision, site=site)
 
@@ -149,6 +159,7 @@ class SelfAttentionStack:
                 self.names.append(f'{name}_ConvBlock{i - dense_blocks + 1}_SelfAttention')
             self.blocks.append((sa, ff))
         self.hidden = max(ff.hidden() for _, ff in self.blocks)
+        self.fuse_norm = True        # the attention block's LN(LN(y) + x) inside the next convolution where that launch can
 
     def alloc(self, rows, device):
         d = self.d
@@ -167,11 +178,12 @@ class SelfAttentionStack:
             if return_attention:
                 attn = torch.empty(B, sa.heads, L, L, dtype=torch.float32, device=xc.device)
                 attn_out[name] = attn
-            sa.run(xc, ws['qkv'], ws['y'], ws['x1'], B, L, key_mask, causal, attn, precision)
+            defer = isinstance(ff, ConvBNLayer) and self.fuse_norm and ff.can_take_norm(B * L, precision)
+            ln = sa.run(xc, ws['qkv'], ws['y'], ws['x1'], B, L, key_mask, causal, attn, precision, defer_norm=defer)
             if isinstance(ff, FFNLayer):
                 ff.run(ws['x1'], ws['h'], ws['y'], xc[:, :d], precision)
             else:
-                ff.run(ws['x1'], ws['h'], ws['h'], xc[:, :d], L, precision)
+                ff.run(ws['x1'], ws['h'], ws['h'], xc[:, :d], L, precision, ln=ln)
         return attn_out
 
 

@@ -33,17 +33,34 @@ void estts_set_error(const char* fmt, ...);
         }                                                                        \
     } while (0)
 
+// Wave-wide reductions on the data-parallel-primitive path of the vector ALU (DPP operand modifiers: no LDS crossbar, no
+// waits): quad swaps, half-row and row mirrors give every lane the result of its row of 16; row_bcast15 / row_bcast31 carry
+// the rows' results up so that lane 63 holds the wave's, which v_readlane hands to every lane as a scalar.  The butterfly
+// of ds_bpermute steps (__shfl_xor) costs a round trip through the LDS unit per step, ~0.3 us per reduction.
+#define ESTTS_DPP(v, ctrl, row_mask) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    const float ident = 0.0f;
+    v += ESTTS_DPP(v, 0xB1, 0xf);    // quad_perm [1, 0, 3, 2]
+    v += ESTTS_DPP(v, 0x4E, 0xf);    // quad_perm [2, 3, 0, 1]
+    v += ESTTS_DPP(v, 0x141, 0xf);   // row_half_mirror
+    v += ESTTS_DPP(v, 0x140, 0xf);   // row_mirror: every lane holds the sum of its row
+    v += ESTTS_DPP(v, 0x142, 0xa);   // row_bcast15 into rows 1 and 3
+    v += ESTTS_DPP(v, 0x143, 0xc);   // row_bcast31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    const float ident = -INFINITY;
+    v = fmaxf(v, ESTTS_DPP(v, 0xB1, 0xf));
+    v = fmaxf(v, ESTTS_DPP(v, 0x4E, 0xf));
+    v = fmaxf(v, ESTTS_DPP(v, 0x141, 0xf));
+    v = fmaxf(v, ESTTS_DPP(v, 0x140, 0xf));
+    v = fmaxf(v, ESTTS_DPP(v, 0x142, 0xa));
+    v = fmaxf(v, ESTTS_DPP(v, 0x143, 0xc));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#undef ESTTS_DPP
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ESTTS_ACT_RELU) return fmaxf(v, 0.0f);

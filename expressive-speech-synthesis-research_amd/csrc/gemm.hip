@@ -759,7 +759,7 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
                         a.taps % a.conv_kw == 0 && a.M % a.conv_howo == 0 && a.conv_howo % a.conv_wo == 0,
                         "estts_gemm: inconsistent 2-D convolution geometry");
     }
-    ESTTS_CHECK_ARG(a.A && a.W_hi && a.C, "estts_gemm: null A/W/C");
+    ESTTS_CHECK_ARG((a.A || a.ln_y) && a.W_hi && a.C, "estts_gemm: null A/W/C");
     ESTTS_CHECK_ARG(a.M > 0 && a.N > 0 && a.K > 0, "estts_gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     ESTTS_CHECK_ARG(a.precision == 1 || a.precision == 3, "estts_gemm: precision must be 1 or 3");
     ESTTS_CHECK_ARG(a.precision == 1 || a.W_lo, "estts_gemm: precision 3 needs W_lo");
@@ -788,6 +788,22 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         // (with K <= 256 a workgroup's eight K-steps do not amortise the wider tile's prologue: 19200 x 768 x 256 runs 44 us
         // as 64 x 64 tiles, 49 us as 64 x 128)
         tile = (a.N >= 128 && n8 >= 384 && a.K > 256) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
+    }
+    if (a.ln_y) {   // LayerNorm prologue: only the kernel that stages a tile's source rows can compute them on the way in
+        ESTTS_CHECK_ARG(a.ln_ga && a.ln_ba && a.ln_out && (!a.ln_gb == !a.ln_bb), "estts_gemm: LayerNorm prologue needs ln_ga, ln_ba, ln_out (and ln_gb with ln_bb)");
+        ESTTS_CHECK_ARG(a.ln_out != a.ln_y && a.ln_out != a.ln_x, "estts_gemm: ln_out must not alias ln_y / ln_x (other workgroups still read those rows)");
+        ESTTS_CHECK_ARG(a.C != a.ln_y && a.C != a.ln_x && a.C != a.ln_out && a.R != a.ln_out,
+                        "estts_gemm: C must not alias an operand of the LayerNorm prologue, and R must not be ln_out (written by this launch)");
+        ESTTS_CHECK_ARG(((uintptr_t)a.ln_y & 15) == 0 && ((uintptr_t)a.ln_x & 15) == 0 && ((uintptr_t)a.ln_out & 15) == 0 &&
+                        ((uintptr_t)a.ln_ga & 15) == 0 && ((uintptr_t)a.ln_ba & 15) == 0 && ((uintptr_t)a.ln_gb & 15) == 0 &&
+                        ((uintptr_t)a.ln_bb & 15) == 0 && (a.ln_ldy & 3) == 0 && (a.ln_ldx & 3) == 0 && (a.ln_ldo & 3) == 0 &&
+                        a.ln_ldy >= a.c_per_tap && a.ln_ldo >= a.c_per_tap && (!a.ln_x || a.ln_ldx >= a.c_per_tap),
+                        "estts_gemm: LayerNorm prologue operands must be 16-byte aligned with row strides >= c_per_tap, multiples of 4");
+        const long t32 = (long)((a.M + 31) / 32) * ((a.N + 31) / 32);
+        const int r = estts_launch_gemm_oneshot_conv(a, operand_kind(a), tile == 11 || (tile != 12 && t32 < 128), st);
+        ESTTS_CHECK_ARG(r != 1, "estts_gemm: this launch cannot take a LayerNorm prologue (1-D convolution with 2..8 taps, c_per_tap <= 512 and a "
+                                "multiple of 8, K <= 1536, precision 3): run estts_rownorm first");
+        return r;
     }
     if (tile == 9 || tile == 10) {   // explicit one-shot kernel: 16 x 16 / 32 x 32 tiles
         const int r = estts_launch_gemm_oneshot(a, operand_kind(a), tile == 9, (a.tune >> 16) & 0xff, st);

@@ -180,7 +180,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_kernel(const estts_gemm_
 // hi + lo planes in LDS, and a wave reads the A fragment of (row block, tap, channel group) from there with one
 // ds_read_b128 per plane.  The W fragments are still requested first and land during the staging.  A staged row is raw
 // data; whether output row m may use source row m + tap - lpad (same sequence) is decided where the fragment is used.
-template <int NSPLIT, int T, int NW, int S>
+// LNCH > 0: the staged rows are not read from A but computed as LNb(act(LNa(ln_y)) + ln_x) (see estts_gemm_args.ln_y): one
+// wave per source row, LNCH float4 per lane (c_per_tap <= 256 LNCH), every operand of the wave's rows requested before the
+// first reduction; the workgroups of column tile 0 also write their own rows (not the halo) to ln_out.
+template <int NSPLIT, int T, int NW, int S, int LNCH>
 __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_gemm_args p, const int rows_staged, const int lda_s) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
     constexpr int NF = 4 * T * T;
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
     }
 
     // ---- stage source rows m0 - lpad .. + rows_staged - 1 (clamped into the buffer; validity is decided at use)
-    {
+    if constexpr (LNCH == 0) {
         const int c4n = C >> 2;
         const int total = rows_staged * c4n;
         constexpr int MAXI = 10;      // float4 per thread the launcher guarantees to be enough
@@ -259,6 +262,110 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
             split_bf16x4(x[it], hi, lo);
             *reinterpret_cast<bf16x4*>(a_hi + dst[it]) = hi;
             if (NS == 2) *reinterpret_cast<bf16x4*>(a_lo + dst[it]) = lo;
+        }
+    }
+    if constexpr (LNCH > 0) {
+        constexpr int RPW = T == 1 ? 3 : 5;              // rows per wave: 16 T + taps - 1 <= 8 RPW (taps <= 8)
+        float4 ga[LNCH], ba[LNCH], gb[LNCH], bb[LNCH], y[RPW][LNCH], x[RPW][LNCH];
+        int cc[LNCH];
+        float live[LNCH];                                 // 0 for the lanes past the row's end
+#pragma unroll
+        for (int i = 0; i < LNCH; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            live[i] = c < C ? 1.0f : 0.0f;
+            cc[i] = min(c, C - 4);
+            // (no load under a condition -- it would become a branch with a wait of its own, one round trip each: an absent
+            // operand is read from a present one and ignored)
+            ga[i] = *reinterpret_cast<const float4*>(p.ln_ga + cc[i]);
+            ba[i] = *reinterpret_cast<const float4*>(p.ln_ba + cc[i]);
+            gb[i] = *reinterpret_cast<const float4*>((p.ln_gb ? p.ln_gb : p.ln_ga) + cc[i]);
+            bb[i] = *reinterpret_cast<const float4*>((p.ln_bb ? p.ln_bb : p.ln_ba) + cc[i]);
+        }
+        const float* xsrc = p.ln_x ? p.ln_x : p.ln_y;
+        const int xld = p.ln_x ? p.ln_ldx : p.ln_ldy;
+        const float xk = p.ln_x ? 1.0f : 0.0f;
+        int src[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int rr = min(wave + NW * r, rows_staged - 1);   // surplus slots repeat the last row (same values, same place)
+            src[r] = min(max(m0 - p.conv_pl + rr, 0), p.M - 1);
+#pragma unroll
+            for (int i = 0; i < LNCH; ++i) {
+                y[r][i] = *reinterpret_cast<const float4*>(p.ln_y + (long)src[r] * p.ln_ldy + cc[i]);
+                x[r][i] = *reinterpret_cast<const float4*>(xsrc + (long)src[r] * xld + cc[i]);
+            }
+        }
+        // every request above is issued before anything below is scheduled: left alone, the compiler sinks the rows' loads to
+        // their uses to save registers, and the wave then pays one memory round trip per row instead of one in all
+        __builtin_amdgcn_sched_barrier(0);
+        const float inv_c = 1.0f / (float)C;
+        const float floor_v = p.ln_act == ESTTS_ACT_RELU ? 0.0f : -INFINITY;
+        // the rows of a wave are independent: each phase runs over all of them so that their reductions interleave
+        auto layer_norm = [&](const float4 (&g)[LNCH], const float4 (&b)[LNCH]) {
+            float mean[RPW], inv[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < LNCH; ++i) t += (y[r][i].x + y[r][i].y + y[r][i].z + y[r][i].w) * live[i];
+                mean[r] = t;
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) mean[r] = wave_sum(mean[r]) * inv_c;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < LNCH; ++i) {
+                    const float a = y[r][i].x - mean[r], b2 = y[r][i].y - mean[r], c = y[r][i].z - mean[r], d = y[r][i].w - mean[r];
+                    q += (a * a + b2 * b2 + c * c + d * d) * live[i];
+                }
+                inv[r] = q;
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) inv[r] = rsqrtf(wave_sum(inv[r]) * inv_c + p.ln_eps);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int i = 0; i < LNCH; ++i) {
+                    y[r][i].x = (y[r][i].x - mean[r]) * inv[r] * g[i].x + b[i].x;
+                    y[r][i].y = (y[r][i].y - mean[r]) * inv[r] * g[i].y + b[i].y;
+                    y[r][i].z = (y[r][i].z - mean[r]) * inv[r] * g[i].z + b[i].z;
+                    y[r][i].w = (y[r][i].w - mean[r]) * inv[r] * g[i].w + b[i].w;
+                }
+        };
+        layer_norm(ga, ba);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < LNCH; ++i) {
+                // (none or ReLU only, as a select: the library tanh is a branchy routine, and its blocks between the rows' loads and
+                // their use kept the compiler from issuing the loads together)
+                y[r][i].x = fmaxf(y[r][i].x, floor_v);
+                y[r][i].y = fmaxf(y[r][i].y, floor_v);
+                y[r][i].z = fmaxf(y[r][i].z, floor_v);
+                y[r][i].w = fmaxf(y[r][i].w, floor_v);
+                y[r][i].x += xk * x[r][i].x;
+                y[r][i].y += xk * x[r][i].y;
+                y[r][i].z += xk * x[r][i].z;
+                y[r][i].w += xk * x[r][i].w;
+            }
+        if (p.ln_gb) layer_norm(gb, bb);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int rr = min(wave + NW * r, rows_staged - 1);
+            const int own = m0 - p.conv_pl + rr;          // unclamped source row
+            const bool write_out = tc.tx == 0 && wave + NW * r < rows_staged && rr >= p.conv_pl && rr < p.conv_pl + 16 * T && own < p.M;
+#pragma unroll
+            for (int i = 0; i < LNCH; ++i) {
+                if ((lane + 64 * i) * 4 < C) {
+                    bf16x4 hi, lo;
+                    split_bf16x4(y[r][i], hi, lo);
+                    *reinterpret_cast<bf16x4*>(a_hi + rr * lda_s + cc[i]) = hi;
+                    if (NS == 2) *reinterpret_cast<bf16x4*>(a_lo + rr * lda_s + cc[i]) = lo;
+                    if (write_out) *reinterpret_cast<float4*>(p.ln_out + (long)own * p.ln_ldo + cc[i]) = y[r][i];
+                }
+            }
         }
     }
     __syncthreads();
@@ -365,11 +472,11 @@ bool allow_large_lds(const void* kern, bool (&raised)[64]) {
     return true;
 }
 
-template <int NSPLIT, int T>
+template <int NSPLIT, int T, int LNCH>
 int launch_conv_s(const estts_gemm_args& a, dim3 grid, int S, int rows_staged, int lda_s, size_t smem, hipStream_t st) {
 #define ESTTS_ONESHOT_CASE(s_)                                                                                              \
     case s_: {                                                                                                              \
-        auto kern = gemm_oneshot_conv_kernel<NSPLIT, T, 8, s_>;                                                            \
+        auto kern = gemm_oneshot_conv_kernel<NSPLIT, T, 8, s_, LNCH>;                                                      \
         static bool raised[64] = {};       /* per GPU: the attribute belongs to the device's copy of the kernel */         \
         if (!allow_large_lds(reinterpret_cast<const void*>(kern), raised)) return -2;                                      \
         hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, rows_staged, lda_s);                                         \
@@ -424,10 +531,16 @@ int estts_launch_gemm_oneshot_conv(const estts_gemm_args& a, int kind, int tile1
     if (smem > 96 * 1024 || (long)rows_staged * (a.c_per_tap >> 2) > 10 * 512) return 1;
     dim3 grid((a.N + tm - 1) / tm, (a.M + tm - 1) / tm, 1);
     if (grid.y > 65535) return 1;
-    if (tile16) return a.precision == 3 ? launch_conv_s<3, 1>(a, grid, S, rows_staged, lda_s, smem, st)
-                                        : launch_conv_s<1, 1>(a, grid, S, rows_staged, lda_s, smem, st);
-    return a.precision == 3 ? launch_conv_s<3, 2>(a, grid, S, rows_staged, lda_s, smem, st)
-                            : launch_conv_s<1, 2>(a, grid, S, rows_staged, lda_s, smem, st);
+    const int lnch = a.ln_y ? (a.c_per_tap <= 256 ? 1 : 2) : 0;
+    if (lnch && (a.c_per_tap > 512 || a.taps > 8 || a.precision != 3 || (!tile16 && lnch == 2 && S > 3) ||
+                 (a.ln_act != ESTTS_ACT_NONE && a.ln_act != ESTTS_ACT_RELU))) return 1;   // (the last: 256 registers and spills)
+#define ESTTS_CONV_GO(t_)                                                                                               \
+    (lnch == 0 ? (a.precision == 3 ? launch_conv_s<3, t_, 0>(a, grid, S, rows_staged, lda_s, smem, st)                  \
+                                   : launch_conv_s<1, t_, 0>(a, grid, S, rows_staged, lda_s, smem, st))                 \
+     : lnch == 1 ? launch_conv_s<3, t_, 1>(a, grid, S, rows_staged, lda_s, smem, st)                                   \
+                 : launch_conv_s<3, t_, 2>(a, grid, S, rows_staged, lda_s, smem, st))
+    return tile16 ? ESTTS_CONV_GO(1) : ESTTS_CONV_GO(2);
+#undef ESTTS_CONV_GO
 }
 
 int estts_launch_gemm_oneshot(const estts_gemm_args& a, int kind, int tile16, int waves, hipStream_t st) {

@@ -73,7 +73,8 @@ class ForwardTransformer:
             Me, Md = B * N, B * T
             ws = {'enc': self.encoder.alloc(Me, dev), 'dec': self.decoder.alloc(Md, dev),
                   'key_mask': torch.empty(B, N, **f32), 'dp_a': torch.empty(Me, self.de, **f32),
-                  'dp_b': torch.empty(Me, self.de, **f32), 'dur': torch.empty(B, N, **f32),
+                  'dp_b': torch.empty(Me, self.de, **f32), 'dp_c': torch.empty(Me, self.de, **f32),
+                  'dur': torch.empty(B, N, **f32),
                   'cum': torch.empty(B, N, dtype=torch.int32, device=dev),
                   'totals': torch.empty(B, dtype=torch.int32, device=dev),
                   'mels_in': torch.empty(Md, self.de, **f32), 'frame_mask': torch.empty(B, T, **f32),
@@ -93,9 +94,14 @@ class ForwardTransformer:
         attn = self.encoder.run(e, B, N, ws['key_mask'], self.precision, return_attention)
         x = e['xc'][:, :de]
         ops.gemm(x, self.dp_conv0, ws['dp_a'], seg_len=N, precision=self.precision, site='dur_pred')
-        ops.rownorm(ws['dp_a'], ws['dp_b'], ln_a=self.dp_ln[0], act='relu')
-        ops.gemm(ws['dp_b'], self.dp_conv1, ws['dp_a'], seg_len=N, precision=self.precision, site='dur_pred')
-        ops.rownorm(ws['dp_a'], None, ln_a=self.dp_ln[1], act='relu', residual=x, ln_b=self.dp_ln[2],
+        if ops.can_fuse_ln(self.dp_conv1, B * N, precision=self.precision, site='dur_pred'):
+            # relu(LN(conv0)) computed by the second convolution on its way in (one launch fewer)
+            ops.gemm(ws['dp_b'], self.dp_conv1, ws['dp_c'], seg_len=N, precision=self.precision, site='dur_pred',
+                     ln=dict(y=ws['dp_a'], ln_a=self.dp_ln[0], act='relu', out=ws['dp_b']))
+        else:
+            ops.rownorm(ws['dp_a'], ws['dp_b'], ln_a=self.dp_ln[0], act='relu')
+            ops.gemm(ws['dp_b'], self.dp_conv1, ws['dp_c'], seg_len=N, precision=self.precision, site='dur_pred')
+        ops.rownorm(ws['dp_c'], None, ln_a=self.dp_ln[1], act='relu', residual=x, ln_b=self.dp_ln[2],
                     dot_w=self.dp_w, dot_b=self.dp_b, dot_scale=float(durations_scalar),
                     dot_mask=ws['key_mask'].view(-1), dot_out=ws['dur'].view(-1))
         return attn

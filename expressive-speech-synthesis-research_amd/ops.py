@@ -226,15 +226,34 @@ def new_gemm_workspace(device, nbytes=4 << 20):
     return (torch.empty(nbytes // 4, dtype=torch.float32, device=device), torch.zeros(_N_COUNTERS, dtype=torch.int32, device=device))
 
 
+def can_fuse_ln(lin, M, N_out=None, precision='bf16x3', site=None, act=None):
+    """True when gemm(..., ln=...) can compute its input rows as a LayerNorm combination on the way in (estts_gemm_args.ln_y):
+    a 1-D convolution of 2..8 taps over at most 1024 rows, c_per_tap <= 512, K <= 1536, split-bf16 operands, no activation or
+    ReLU between the two norms, and not while a step program is being recorded.  Callers fall back to rownorm() + gemm()."""
+    if _program is not None or precision_at(precision, site) != 'bf16x3' or act not in (None, 'relu'):
+        return False
+    C = lin.c_per_tap
+    if not (2 <= lin.taps <= 8 and C % 8 == 0 and C <= 512 and lin.K % 8 == 0 and lin.K <= 1536 and M <= 1024):
+        return False
+    t32 = ((M + 31) // 32) * (((lin.N if N_out is None else N_out) + 31) // 32)
+    tm = 16 if t32 < 128 else 32
+    if (tm + lin.taps - 1) * (C + 8) * 4 > 96 * 1024:
+        return False
+    return not (tm == 32 and C > 256 and lin.K > 768)      # (that variant would not fit its registers)
+
+
 def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
-         split=True, conv2d=None, dropout=None, batch=None, workspace=None, site=None):
+         split=True, conv2d=None, dropout=None, batch=None, workspace=None, site=None, ln=None):
     """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary).
     dropout = (rate, seed, site, row0): keep/scale after the activation, generator row = row0 + output row.
     batch = (count, stride_a, stride_w, stride_c, stride_v): that many products of this shape in one launch; x / lin / out
     describe product 0 and the strides (elements) lead to the others (see estts_gemm_args.batch).
     workspace = (float32 scratch, zeroed int32 tickets): split-K scratch of its own for launches on a second stream that may
     run beside launches using the shared one (new_gemm_workspace()).
-    precision: 'bf16' / 'bf16x3', or a PrecisionPolicy resolved at `site`."""
+    precision: 'bf16' / 'bf16x3', or a PrecisionPolicy resolved at `site`.
+    ln = dict(y=, x= or None, ln_a=(gamma, beta), ln_b=(gamma, beta) or None, act= or None, out=, eps=1e-6): the input rows
+    are LNb(act(LNa(y)) + x), computed inside the launch and also written to `out`, which is what `x` must be (see
+    can_fuse_ln; rownorm() fused into the convolution that consumes it)."""
     precision = precision_at(precision, site)
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
@@ -263,6 +282,21 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
         a.drop_rate, a.drop_seed, a.drop_site, a.drop_row0 = dropout
     if batch is not None:
         a.batch, a.batch_stride_a, a.batch_stride_w, a.batch_stride_c, a.batch_stride_v = batch
+    if ln is not None:
+        y, xr, lo = ln['y'], ln.get('x'), ln['out']
+        _check_f32(y, 'ln.y'); _check_f32(lo, 'ln.out')
+        if x.data_ptr() != lo.data_ptr():
+            raise ValueError('gemm: with ln= the input must be the buffer the normalised rows are written to (ln[\'out\'])')
+        if out.data_ptr() in (y.data_ptr(), lo.data_ptr()) or (xr is not None and out.data_ptr() == xr.data_ptr()):
+            raise ValueError('gemm: the output must not alias an operand of the LayerNorm prologue')
+        a.ln_y, a.ln_ldy, a.ln_out, a.ln_ldo = y.data_ptr(), y.stride(0), lo.data_ptr(), lo.stride(0)
+        if xr is not None:
+            _check_f32(xr, 'ln.x')
+            a.ln_x, a.ln_ldx = xr.data_ptr(), xr.stride(0)
+        a.ln_ga, a.ln_ba = ln['ln_a'][0].data_ptr(), ln['ln_a'][1].data_ptr()
+        if ln.get('ln_b') is not None:
+            a.ln_gb, a.ln_bb = ln['ln_b'][0].data_ptr(), ln['ln_b'][1].data_ptr()
+        a.ln_act, a.ln_eps = ACT[ln.get('act')], ln.get('eps', 1e-6)
     if split:
         ws, cnt = gemm_workspace(x.device) if workspace is None else workspace
         a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
@@ -277,7 +311,7 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     nsplit = 2 if precision == 'bf16x3' else 1
     _record('gemm', {'M': M, 'N': lin.N, 'K': lin.K, 'taps': lin.taps, 'flops': 2.0 * M * lin.N * lin.K,
                      'bytes': 4.0 * M * lin.K / lin.taps + 2.0 * nsplit * lin.N * lin.K + 4.0 * M * lin.N},
-            _lib.load().estts_gemm, a, keep=(x, out, residual, lin))
+            _lib.load().estts_gemm, a, keep=(x, out, residual, lin, ln))
     return out
 
 

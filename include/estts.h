@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 26
+#define ESTTS_ABI_VERSION 27
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -118,6 +118,18 @@ typedef struct estts_gemm_args {
      * z * batch_stride_c, and s1 / b1 / s2 / b2 + z * batch_stride_v (floats).  LDS-staged tiles only (tune 0 or 5..8). */
     int32_t batch;
     int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_v;
+    /* LayerNorm prologue (ln_y != NULL): the A operand is not read from A but computed per source row, over c_per_tap
+     * columns, as  a = LNb( act_ln( LNa(ln_y[row]) ) + ln_x[row] )  -- LNa = (ln_ga, ln_ba), LNb = (ln_gb, ln_bb) or none,
+     * ln_x or none, act_ln one of ESTTS_ACT_* -- i.e. estts_rownorm fused into the convolution that consumes it
+     * (SelfAttentionResNorm's LN(LN(y) + x) in front of CNNResNorm's first Conv1D, TransformerTTS/model/layers.py:163-168 and
+     * :35-40).  Every row is also written once to ln_out (float32, ln_ldo floats per row), which must not alias ln_y / ln_x.
+     * Only 1-D convolutions (taps 2..8) over few rows with c_per_tap <= 512 can take it (the kernel that stages a tile's
+     * source rows in LDS): estts_gemm fails with an error otherwise and the caller runs estts_rownorm itself. */
+    const float* ln_y; const float* ln_x;
+    const float* ln_ga; const float* ln_ba; const float* ln_gb; const float* ln_bb;
+    float* ln_out;
+    int32_t ln_ldy, ln_ldx, ln_ldo, ln_act;
+    float ln_eps;
 } estts_gemm_args;
 
 int estts_gemm(const estts_gemm_args* args, void* stream);

@@ -191,6 +191,45 @@ def test_gemm_oneshot_kernels_agree_with_the_ring_kernel_on_random_shapes():
     assert checked > 400
 
 
+@pytest.mark.parametrize('B,T,cin,taps,lpad,N', [(1, 100, 512, 3, 1, 512), (1, 600, 256, 3, 1, 512), (3, 23, 96, 5, 2, 72),
+                                                (2, 37, 264, 2, 1, 40), (4, 150, 256, 3, 2, 256)])
+@pytest.mark.parametrize('form', ['double', 'single_relu', 'residual_only_a'])
+def test_gemm_layernorm_prologue(B, T, cin, taps, lpad, N, form):
+    # the convolution that computes its input rows as LNb(act(LNa(y)) + x) on the way in (and writes them out once) against
+    # estts_rownorm followed by the same convolution: same kernels downstream of the rows, so 2e-5 of the output range;
+    # several sequences (halo rows across sequence boundaries are masked at use), 16 x 16 and 32 x 32 tiles, both row widths
+    M, K = B * T, taps * cin
+    y, x = _rand(M, cin + 4, seed=21), _rand(M, cin, seed=22)
+    ga, ba = _rand(cin, seed=23).abs() + 0.5, _rand(cin, seed=24)
+    gb, bb = _rand(cin, seed=25).abs() + 0.5, _rand(cin, seed=26)
+    w = _rand(N, K, seed=27, scale=1 / math.sqrt(K))
+    lin = PackedLinear(w.numpy(), bias=_rand(N, seed=28).numpy(), device=DEV, taps=taps, lpad=lpad, act='relu')
+    yd, xd = y.to(DEV)[:, :cin], x.to(DEV)
+    ln_a, ln_b = (ga.to(DEV), ba.to(DEV)), (gb.to(DEV), bb.to(DEV))
+    kw = {'double': dict(ln_a=ln_a, ln_b=ln_b, residual=xd, act=None),
+          'single_relu': dict(ln_a=ln_a, ln_b=None, residual=None, act='relu'),
+          'residual_only_a': dict(ln_a=ln_a, ln_b=None, residual=xd, act='relu')}[form]
+    assert ops.can_fuse_ln(lin, M)
+    rows_ref = torch.empty(M, cin, device=DEV)
+    ops.rownorm(yd, rows_ref, ln_a=kw['ln_a'], act=kw['act'], residual=kw['residual'], ln_b=kw['ln_b'])
+    out_ref = torch.empty(M, N, device=DEV)
+    ops.gemm(rows_ref, lin, out_ref, seg_len=T, precision='bf16x3', tune=4)
+    rows = torch.full((M, cin + 8), float('nan'), device=DEV)
+    out = torch.full((M, N + 4), float('nan'), device=DEV)
+    ops.gemm(rows[:, :cin], lin, out[:, :N], seg_len=T, precision='bf16x3',
+             ln=dict(y=yd, x=kw['residual'], ln_a=kw['ln_a'], ln_b=kw['ln_b'], act=kw['act'], out=rows[:, :cin]))
+    assert torch.isnan(rows[:, cin:]).all() and torch.isnan(out[:, N:]).all()
+    assert (rows[:, :cin] - rows_ref).abs().max().item() < 2e-5 * max(1.0, rows_ref.abs().max().item())
+    assert ((out[:, :N] - out_ref).abs().max() / out_ref.abs().max()).item() < 2e-5
+    # what cannot take the prologue says so (dense layer), and aliasing is refused
+    dense = PackedLinear(_rand(N, cin, seed=29).numpy(), device=DEV)
+    assert not ops.can_fuse_ln(dense, M)
+    with pytest.raises(RuntimeError, match='LayerNorm prologue'):
+        ops.gemm(rows[:, :cin], dense, out[:, :N], ln=dict(y=yd, ln_a=ln_a, out=rows[:, :cin]))
+    with pytest.raises(ValueError, match='alias'):
+        ops.gemm(rows[:, :cin], lin, yd, seg_len=T, ln=dict(y=yd, ln_a=ln_a, out=rows[:, :cin]))
+
+
 def test_gemm_posenc_residual_shared_rows():
     B, T, K, N = 3, 17, 64, 32
     x, w, pe = _rand(B * T, K, seed=1), _rand(N, K, seed=2, scale=0.1), _rand(40, N, seed=3)
