@@ -309,8 +309,12 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
         return out
     check(_lib.load().estts_gemm(a, _stream()), 'estts_gemm')
     nsplit = 2 if precision == 'bf16x3' else 1
-    _record('gemm', {'M': M, 'N': lin.N, 'K': lin.K, 'taps': lin.taps, 'flops': 2.0 * M * lin.N * lin.K,
-                     'bytes': 4.0 * M * lin.K / lin.taps + 2.0 * nsplit * lin.N * lin.K + 4.0 * M * lin.N},
+    info = {'M': M, 'N': lin.N, 'K': lin.K, 'taps': lin.taps, 'flops': 2.0 * M * lin.N * lin.K,
+            'bytes': 4.0 * M * lin.K / lin.taps + 2.0 * nsplit * lin.N * lin.K + 4.0 * M * lin.N}
+    if ln is not None:       # another kernel (rows normalised on the way in, read twice, written once): its own line in a kernel table
+        info['ln_prologue'] = True
+        info['bytes'] += 4.0 * M * lin.c_per_tap * (2 if ln.get('x') is not None else 1)
+    _record('gemm', info,
             _lib.load().estts_gemm, a, keep=(x, out, residual, lin, ln))
     return out
 

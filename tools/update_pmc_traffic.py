@@ -17,10 +17,15 @@ CSRC = os.path.join(ROOT, 'expressive-speech-synthesis-research_amd', 'csrc')
 KERNELS = {
     'gemm {"M": 100, "N": 512, "K": 1536, "taps": 3}': (
         'gemm_oneshot_kernel<3, 2, 1, 8, 6>',
-        ' (the eight M = 100, N = 512, K = 3 x 512 convolution launches of each forward; 224 workgroups of 16 x 16 outputs)'),
+        ' (the second convolution of each encoder block: M = 100, N = 512, K = 3 x 512; 224 workgroups of 16 x 16 outputs)'),
+    'gemm {"M": 100, "N": 512, "K": 1536, "taps": 3, "ln_prologue": true}': (
+        'gemm_oneshot_conv_kernel<3, 1, 8, 6, 2>',
+        ' (the first convolution of each encoder block with the attention block\'s LN(LN(y) + x) computed on the way in)'),
+    'gemm {"M": 600, "N": 512, "K": 768, "taps": 3, "ln_prologue": true}': (
+        'gemm_oneshot_conv_kernel<3, 2, 8, 3, 1>',
+        ' (the first convolution of each decoder block with the attention block\'s LN(LN(y) + x) computed on the way in)'),
     'attention {"B": 1, "H": 4, "Lq": 600, "Lk": 600, "depth": 64, "weights": true}': ('attention_kernel<64, 2, 3, 8>', ''),
 }
-
 
 def csrc_hash():
     h = hashlib.sha1()
