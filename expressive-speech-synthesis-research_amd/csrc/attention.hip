@@ -194,8 +194,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int j = 0; j < 4; ++j) tmax = fmaxf(tmax, s[sub][j]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, lane_xor16(tmax));
+        tmax = fmaxf(tmax, lane_xor32(tmax));
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = exp_neg(m_run - m_new);  // exp(-inf) = 0 on the first tile
         float pv[8], psum = 0.0f;
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
                 pv[sub * 4 + j] = e;
                 psum += e;
             }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
+        psum += lane_xor16(psum);
+        psum += lane_xor32(psum);
         l_run = l_run * alpha + psum;
         m_run = m_new;
         const Frag<NS> pf = make_frag<NS>(pv);
@@ -512,8 +512,8 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
         float tmax = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 8; ++e) tmax = fmaxf(tmax, s[e]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, lane_xor16(tmax));
+        tmax = fmaxf(tmax, lane_xor32(tmax));
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = exp_neg(m_run - m_new);  // exp(-inf) = 0 on the first tile
         float pv[8], psum = 0.0f;
@@ -522,8 +522,8 @@ __global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attenti
             pv[e] = exp_neg(s[e] - m_new);
             psum += pv[e];
         }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
+        psum += lane_xor16(psum);
+        psum += lane_xor32(psum);
         l_run = l_run * alpha + psum;
         m_run = m_new;
         if (with_v) {

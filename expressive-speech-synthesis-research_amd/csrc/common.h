@@ -62,6 +62,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 #undef ESTTS_DPP
 
+// The value held by lane ^ 16 / lane ^ 32, through the row-swap instructions of gfx950 (v_permlane16_swap exchanges the odd
+// rows of its first operand with the even rows of its second, v_permlane32_swap the upper half with the lower half; given the
+// same register twice, one of the two results holds the partner's value, depending on which side the lane is on).  Vector
+// ALU work, where __shfl_xor takes a round trip through the LDS unit (ds_bpermute).
+__device__ __forceinline__ float lane_xor16(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ESTTS_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == ESTTS_ACT_TANH) return tanhf(v);
