@@ -361,47 +361,63 @@ class WaveRNN:
         return n
 
     # ------------------------------------------------------------------ conditioning network
-    def _aux_frames(self, mel_padded):
-        """mel_padded: [T + 2 pad, feat] float32 device tensor -> MelResNet output [T, res_out] (fatchord_version.py:39-45)."""
+    def _aux_frames(self, mel_padded, seg_len=None):
+        """mel_padded: [n (T + 2 pad), feat] float32 device tensor, n utterances of seg_len = T + 2 pad padded frames each
+        -> MelResNet output [n (T + 2 pad), res_out] (fatchord_version.py:39-45); the first T rows of every utterance count."""
         Tp = mel_padded.shape[0]
-        T = Tp - 2 * self.pad
+        seg_len = Tp if seg_len is None else seg_len
         f32 = dict(dtype=torch.float32, device=self.device)
         x = torch.empty(Tp, self.compute_dims, **f32)
         h = torch.empty(Tp, self.compute_dims, **f32)
         y = torch.empty(Tp, self.compute_dims, **f32)
-        ops.gemm(mel_padded, self.conv_in, x, seg_len=Tp, precision=self.precision)   # rows >= T are partial sums, unused
+        ops.gemm(mel_padded, self.conv_in, x, seg_len=seg_len, precision=self.precision)   # rows >= T are partial sums, unused
         for c1, c2 in self.res:
             ops.gemm(x, c1, h, precision=self.precision)
             ops.gemm(h, c2, y, residual=x, precision=self.precision)
             x, y = y, x
         out = torch.empty(Tp, self.res_out_dims, **f32)
         ops.gemm(x, self.conv_out, out, precision=self.precision)
-        return out[:T]
+        return out
+
+    def _pack_conditioning(self, padded):
+        """padded: list of [T + 2 pad, feat] float32 host tensors.  Runs the residual network once per group of utterances of
+        equal length (all rows of a group in one launch per layer: 22 launches for the whole batch instead of 22 per
+        utterance) and returns the packed padded mel frames, aux frames and per-utterance offsets on the device."""
+        frames = [int(mp.shape[0]) - 2 * self.pad for mp in padded]
+        mel_all = torch.cat(padded).contiguous().to(self.device)
+        mel_off = np.concatenate([[0], np.cumsum([t + 2 * self.pad for t in frames])[:-1]]).astype(np.int64)
+        aux_off = np.concatenate([[0], np.cumsum(frames)[:-1]]).astype(np.int64)
+        aux_all = torch.empty(int(sum(frames)), self.res_out_dims, dtype=torch.float32, device=self.device)
+        groups = {}
+        for i, t in enumerate(frames):
+            groups.setdefault(t, []).append(i)
+        for T, idx in groups.items():
+            Tp = T + 2 * self.pad
+            if len(idx) == len(frames):
+                stacked = mel_all                                   # one group: the packed frames are the stacked batch
+            else:
+                stacked = torch.cat([mel_all[mel_off[i]:mel_off[i] + Tp] for i in idx])
+            out = self._aux_frames(stacked, seg_len=Tp).view(len(idx), Tp, self.res_out_dims)
+            for j, i in enumerate(idx):
+                aux_all[aux_off[i]:aux_off[i] + T].copy_(out[j, :T])
+        i32 = dict(dtype=torch.int32, device=self.device)
+        return {'mel': mel_all, 'aux': aux_all,
+                'mel_off': torch.tensor(mel_off, **i32), 'aux_off': torch.tensor(aux_off, **i32), 'frames': frames,
+                'utt_samples': torch.tensor([t * self.hop_length for t in frames], **i32)}
 
     def _prepare(self, mel_list):
-        """mel_list: list of [feat, T] arrays/tensors (values as the reference expects).  Returns the packed padded mel
-        frames, aux frames and per-utterance offsets on the device."""
-        mels_p, auxs, mel_off, aux_off, frames = [], [], [], [], []
-        mo = ao = 0
+        """mel_list: list of [feat, T] arrays/tensors (values as the reference expects): zero-padded by `pad` frames on both
+        sides (fatchord_version.py:153-156), then _pack_conditioning."""
+        padded = []
         for m in mel_list:
             m = torch.as_tensor(m, dtype=torch.float32)
             if m.dim() != 2 or m.shape[0] != self.feat_dims:
                 raise ValueError(f'each mel must be [feat={self.feat_dims}, T], got {tuple(m.shape)}')
             T = m.shape[1]
             mp = torch.zeros(T + 2 * self.pad, self.feat_dims, dtype=torch.float32)
-            mp[self.pad:self.pad + T] = m.t()
-            mp = mp.to(self.device)
-            mels_p.append(mp)
-            auxs.append(self._aux_frames(mp))
-            mel_off.append(mo)
-            aux_off.append(ao)
-            frames.append(T)
-            mo += T + 2 * self.pad
-            ao += T
-        i32 = dict(dtype=torch.int32, device=self.device)
-        return {'mel': torch.cat(mels_p).contiguous(), 'aux': torch.cat(auxs).contiguous(),
-                'mel_off': torch.tensor(mel_off, **i32), 'aux_off': torch.tensor(aux_off, **i32), 'frames': frames,
-                'utt_samples': torch.tensor([t * self.hop_length for t in frames], **i32)}
+            mp[self.pad:self.pad + T] = m.t().cpu()
+            padded.append(mp)
+        return self._pack_conditioning(padded)
 
     # ------------------------------------------------------------------ step machinery
     def _alloc_state(self, n_seq, L):
@@ -705,22 +721,7 @@ class WaveRNN:
 
     def _prepare_padded(self, mels):
         """mels [B, feat, T + 2 pad] whose edge frames are real context (training windows), not zero padding."""
-        mels_p, auxs, mel_off, aux_off, frames = [], [], [], [], []
-        mo = ao = 0
-        for m in mels:
-            mp = m.t().contiguous().to(self.device)
-            T = mp.shape[0] - 2 * self.pad
-            mels_p.append(mp)
-            auxs.append(self._aux_frames(mp))
-            mel_off.append(mo)
-            aux_off.append(ao)
-            frames.append(T)
-            mo += T + 2 * self.pad
-            ao += T
-        i32 = dict(dtype=torch.int32, device=self.device)
-        return {'mel': torch.cat(mels_p).contiguous(), 'aux': torch.cat(auxs).contiguous(),
-                'mel_off': torch.tensor(mel_off, **i32), 'aux_off': torch.tensor(aux_off, **i32), 'frames': frames,
-                'utt_samples': torch.tensor([t * self.hop_length for t in frames], **i32)}
+        return self._pack_conditioning([torch.as_tensor(m, dtype=torch.float32).t().contiguous().cpu() for m in mels])
 
     def upsample(self, mels):
         """UpsampleNetwork.forward (fatchord_version.py:79-86), materialised: mels [B, feat, T + 2 pad] ->
