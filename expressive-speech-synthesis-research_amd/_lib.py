@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -117,6 +117,12 @@ class WavernnCondArgs(C.Structure):
                 ('aux_ks', _i32), ('aux_kpitch', _i32), ('n_seq', _i32), ('feat', _i32), ('d', _i32), ('hop', _i32)]
 
 
+class WavernnUnfoldArgs(C.Structure):
+    _fields_ = [('wave', _vp), ('ld_wave', _i32), ('seq_off', _vp), ('n_folds', _vp), ('out_len', _vp), ('out_off', _vp),
+                ('out', _vp), ('n_utt', _i32), ('target', _i32), ('overlap', _i32), ('max_len', _i32), ('mu', _i32),
+                ('fade_tail', _i32), ('step_in', C.c_double), ('step_tail', C.c_double)]
+
+
 class WavernnSampleArgs(C.Structure):
     _fields_ = [('logits', _vp), ('ld_logits', _i32), ('n_classes', _i32), ('mode', _i32), ('u', _vp), ('u_mix', _vp),
                 ('forced', _vp), ('seed', C.c_uint32), ('wave', _vp), ('ld_wave', _i32), ('x_prev', _vp), ('step', _vp),
@@ -143,6 +149,7 @@ SIGNATURES = {
     'estts_wavernn_prep': (_i32, [C.POINTER(WavernnPrepArgs), _vp]),
     'estts_gru_gates': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_wavernn_sample': (_i32, [C.POINTER(WavernnSampleArgs), _vp]),
+    'estts_wavernn_unfold': (_i32, [C.POINTER(WavernnUnfoldArgs), _vp]),
     'estts_wavernn_layer': (_i32, [C.POINTER(WavernnLayerArgs), _vp]),
     'estts_wavernn_cond': (_i32, [C.POINTER(WavernnCondArgs), _vp]),
     'estts_pack_weight': (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

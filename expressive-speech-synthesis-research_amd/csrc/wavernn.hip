@@ -282,3 +282,66 @@ extern "C" int estts_wavernn_sample(const estts_wavernn_sample_args* args, void*
     ESTTS_CHECK_LAUNCH("estts_wavernn_sample");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// Cross-fade of the folds, mu-law expansion and closing fade in float64 (see estts_wavernn_unfold in include/estts.h): one
+// thread per output sample.  The window values follow NumPy's linspace (k * step + start, the last element the end point
+// itself), multiply and add kept separate so that they round as on the host.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+#pragma clang fp contract(off)
+__device__ __forceinline__ double lin_t(int k, int n, double step) {      // linspace(-1, 1, n)[k]
+    const double prod = (double)k * step;
+    return k == n - 1 ? 1.0 : prod + -1.0;
+}
+
+__global__ __launch_bounds__(256) void wavernn_unfold_kernel(const estts_wavernn_unfold_args p) {
+#pragma clang fp contract(off)
+    const int u = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.out_len[u]) return;
+    const int stride = p.target + p.overlap;
+    const int F = p.n_folds[u];
+    const int silence = p.overlap / 2;
+    const int fade_len = p.overlap - silence;
+    const float* base = p.wave + (long)p.seq_off[u] * p.ld_wave;
+    const int f1 = i / stride;
+    const int j1 = i - f1 * stride;
+    double v = 0.0;
+    if (f1 >= 1 && j1 < p.overlap) {          // tail of the previous fold: fade_out[j1] = sqrt(0.5 (1 - t[j1])), then silence
+        const double y = (double)base[(long)(f1 - 1) * p.ld_wave + j1 + stride];
+        const double w = j1 < fade_len ? sqrt(0.5 * (1.0 - lin_t(j1, fade_len, p.step_in))) : 0.0;
+        v = 0.0 + y * w;
+    }
+    if (f1 < F) {                              // this fold: silence, fade_in, then plain
+        const double y = (double)base[(long)f1 * p.ld_wave + j1];
+        double w = 1.0;
+        if (j1 < silence) w = 0.0;
+        else if (j1 < p.overlap) w = sqrt(0.5 * (1.0 + lin_t(j1 - silence, fade_len, p.step_in)));
+        v = v + y * w;
+    }
+    if (p.mu > 0) {
+        const double m = (double)(p.mu - 1);
+        const double sgn = v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 0.0);
+        v = sgn / m * (pow(1.0 + m, fabs(v)) - 1.0);
+    }
+    const int k = i - (p.out_len[u] - p.fade_tail);
+    if (p.fade_tail > 0 && k >= 0) {
+        const double prod = (double)k * p.step_tail;
+        v *= (k == p.fade_tail - 1) ? 0.0 : prod + 1.0;
+    }
+    p.out[p.out_off[u] + i] = v;
+}
+}  // namespace
+
+extern "C" int estts_wavernn_unfold(const estts_wavernn_unfold_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_wavernn_unfold: null args");
+    const estts_wavernn_unfold_args a = *args;
+    ESTTS_CHECK_ARG(a.wave && a.seq_off && a.n_folds && a.out_len && a.out_off && a.out, "estts_wavernn_unfold: null pointer");
+    ESTTS_CHECK_ARG(a.n_utt > 0 && a.n_utt <= 65535 && a.target > 0 && a.overlap >= 4 && a.max_len > 0 && a.mu >= 0 && a.fade_tail >= 0 &&
+                    a.ld_wave >= a.target + 2 * a.overlap, "estts_wavernn_unfold: bad sizes (utterances %d, target %d, overlap %d, row %d)",
+                    a.n_utt, a.target, a.overlap, a.ld_wave);
+    hipLaunchKernelGGL(wavernn_unfold_kernel, dim3((a.max_len + 255) / 256, a.n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_CHECK_LAUNCH("estts_wavernn_unfold");
+    return 0;
+}

@@ -663,6 +663,8 @@ class WaveRNN:
             st['cond_args'] = self._cond_args(cond, st, seq_utt_d, seq_start_d, n_seq)
         sample_args = self._sample_args(st, n_seq, seed, u, u_mix, forced_d)
         self._run_steps(st, prep_args, sample_args, L, use_graph)
+        if batched and overlap >= 4 and not return_trace:
+            return self._unfold_on_device(st['wave'], cond['frames'], folds, target, overlap, mu_law)
         raw = st['wave'].cpu().numpy().astype(np.float64)
         outs, o = [], 0
         for ui, T in enumerate(cond['frames']):
@@ -678,6 +680,33 @@ class WaveRNN:
         if return_trace:
             return outs, raw
         return outs
+
+    def _unfold_on_device(self, wave, frames, folds, target, overlap, mu_law):
+        """The tail of WaveRNN.generate (fatchord_version.py:222-241) for every utterance of the batch in one float64 launch
+        (estts_wavernn_unfold): cross-fade of the folds, mu-law expansion, cut to (T - 1) hop samples, closing fade over the
+        last 20 hops; one device-to-host copy of the finished waveforms.  The host forms (xfade_and_unfold, decode_mu_law)
+        remain for the unbatched path and as the reference the tests compare this with."""
+        hop = self.hop_length
+        lens = [(T - 1) * hop for T in frames]
+        out_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        seq_off = np.concatenate([[0], np.cumsum(folds)[:-1]]).astype(np.int32)
+        dev = self.device
+        out = torch.empty(int(sum(lens)), dtype=torch.float64, device=dev)
+        t = {k: torch.tensor(np.asarray(v), dtype=dt, device=dev) for k, v, dt in (
+            ('seq_off', seq_off, torch.int32), ('n_folds', folds, torch.int32), ('out_len', lens, torch.int32),
+            ('out_off', out_off, torch.int64))}
+        a = _lib.WavernnUnfoldArgs()
+        a.wave, a.ld_wave = wave.data_ptr(), wave.stride(0)
+        a.seq_off, a.n_folds, a.out_len, a.out_off = (t[k].data_ptr() for k in ('seq_off', 'n_folds', 'out_len', 'out_off'))
+        a.out, a.n_utt, a.target, a.overlap, a.max_len = out.data_ptr(), len(frames), target, overlap, max(lens)
+        a.mu = self.n_classes if mu_law else 0
+        a.fade_tail = 20 * hop
+        fade_len = overlap - overlap // 2
+        a.step_in = 2.0 / (fade_len - 1)                 # numpy.linspace(-1, 1, fade_len): step = (stop - start) / (n - 1)
+        a.step_tail = -1.0 / (20 * hop - 1)              # numpy.linspace(1, 0, 20 hop)
+        check(_lib.load().estts_wavernn_unfold(a, ops._stream()), 'estts_wavernn_unfold')
+        host = out.cpu().numpy()
+        return [host[o:o + n] for o, n in zip(out_off, lens)]
 
     def generate(self, mels, batched, target, overlap, mu_law, **kw):
         """fatchord_version.py:150.  mels: [1, feat, T]."""

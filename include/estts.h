@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 27
+#define ESTTS_ABI_VERSION 28
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -392,6 +392,31 @@ typedef struct estts_wavernn_sample_args {
 } estts_wavernn_sample_args;
 
 int estts_wavernn_sample(const estts_wavernn_sample_args* args, void* stream);
+
+/* What WaveRNN.generate does to the generated folds on the host (WaveRNN/models/fatchord_version.py:222-241 and
+ * xfade_and_unfold, :321-383; utility/dsp.py:100-105), as one float64 pass on the device: for utterance u and output sample i
+ *   v = sum over the (at most two) folds that cover i of wave[seq_off[u] + fold, i - fold (target + overlap)] * fade
+ *       (fade: 0 over the first overlap / 2 samples of a fold's head, then sqrt(0.5 (1 + t)), t = linspace(-1, 1, n) -- passed
+ *        as step_in = 2 / (n - 1) --; the mirror image over the fold's tail; 1 in between);
+ *   v = sign(v) / (mu - 1) * (mu ^ |v| - 1)                      when mu > 0 (decode_mu_law(., n_classes, False));
+ *   v *= 1 + k step_tail over the last fade_tail samples (k = 0 .. fade_tail - 1; the closing linspace(1, 0, 20 hop));
+ *   out[out_off[u] + i] = v,  0 <= i < out_len[u].
+ * wave holds float32 sample values, one row of ld_wave steps per fold.  Sums, windows and the expansion are computed in
+ * float64 as NumPy does on the host (the windows bit for bit; pow() of the device library may differ in the last bit). */
+typedef struct estts_wavernn_unfold_args {
+    const float* wave; int32_t ld_wave;
+    const int32_t* seq_off;      /* [n_utt] row of every utterance's first fold */
+    const int32_t* n_folds;      /* [n_utt] */
+    const int32_t* out_len;      /* [n_utt] samples kept */
+    const int64_t* out_off;      /* [n_utt] start of every utterance in out */
+    double* out;
+    int32_t n_utt, target, overlap, max_len;
+    int32_t mu;                  /* 0 = no expansion, else the number of classes */
+    int32_t fade_tail;           /* 0 = none */
+    double step_in, step_tail;
+} estts_wavernn_unfold_args;
+
+int estts_wavernn_unfold(const estts_wavernn_unfold_args* args, void* stream);
 
 
 

@@ -113,6 +113,38 @@ def test_batch_of_utterances_matches_single_runs():
         assert np.array_equal(got, alone)
 
 
+@pytest.mark.parametrize('mu_law', [True, False])
+def test_unfold_on_device_matches_the_host_functions(mu_law):
+    """estts_wavernn_unfold (cross-fade of the folds, mu-law expansion, cut, closing fade; float64 on the device) against the
+    host path it replaces in batched generation -- xfade_and_unfold, decode_mu_law and the linspace fade of WaveRNN.generate --
+    on random fold contents for utterances of different lengths: windows and sums are the same float64 operations, only pow()
+    may round differently (2e-15 absolute on values in [-1, 1])."""
+    from estts.wavernn import WaveRNN, decode_mu_law, fold_starts, xfade_and_unfold
+    hp = configs.wavernn_hparams(voc_mode='RAW')
+    hp.update(voc_rnn_dims=32, voc_fc_dims=32, voc_compute_dims=16, voc_res_out_dims=16, voc_res_blocks=1)
+    m = WaveRNN.from_hparams(hp)
+    hop, target, overlap = m.hop_length, 700, 90
+    rng = np.random.default_rng(3)
+    frames = [31, 47, 25, 60]
+    folds = [len(fold_starts(T * hop, target, overlap)) for T in frames]
+    L = target + 2 * overlap
+    raw = rng.integers(0, m.n_classes, size=(sum(folds), L)).astype(np.float32) * (2.0 / (m.n_classes - 1)) - 1.0
+    wave = torch.from_numpy(raw.astype(np.float32)).cuda()
+    got = m._unfold_on_device(wave, frames, folds, target, overlap, mu_law)
+    o = 0
+    for T, F, g in zip(frames, folds, got):
+        y = xfade_and_unfold(raw[o:o + F].astype(np.float64), target, overlap)
+        o += F
+        if mu_law:
+            y = decode_mu_law(y, m.n_classes, False)
+        y = y[:(T - 1) * hop]
+        y[-20 * hop:] *= np.linspace(1, 0, 20 * hop)
+        assert g.dtype == np.float64 and g.shape == y.shape
+        assert np.abs(g - y).max() < 2e-15
+        if not mu_law:
+            assert np.array_equal(g, y)           # without pow(): bit for bit
+
+
 def test_builtin_generator_is_deterministic_and_uniform():
     hp = small_hp('RAW')
     m, w = _model(hp, 9)

@@ -42,7 +42,7 @@ def test_struct_sizes_match_header_layout(tmp_path):
     import subprocess
     pairs = {'estts_gemm_args': _lib.GemmArgs, 'estts_attention_args': _lib.AttentionArgs,
              'estts_rownorm_args': _lib.RownormArgs, 'estts_wavernn_prep_args': _lib.WavernnPrepArgs,
-             'estts_wavernn_sample_args': _lib.WavernnSampleArgs, 'estts_wavernn_layer_args': _lib.WavernnLayerArgs, 'estts_wavernn_cond_args': _lib.WavernnCondArgs, 'estts_wgrad_args': _lib.WgradArgs,
+             'estts_wavernn_sample_args': _lib.WavernnSampleArgs, 'estts_wavernn_unfold_args': _lib.WavernnUnfoldArgs, 'estts_wavernn_layer_args': _lib.WavernnLayerArgs, 'estts_wavernn_cond_args': _lib.WavernnCondArgs, 'estts_wgrad_args': _lib.WgradArgs,
              'estts_attention_bwd_args': _lib.AttentionBwdArgs, 'estts_rownorm_bwd_args': _lib.RownormBwdArgs,
              'estts_colreduce_args': _lib.ColreduceArgs, 'estts_wavernn_prep_bwd_args': _lib.WavernnPrepBwdArgs, 'estts_rowmask_args': _lib.RowmaskArgs,
              'estts_prog_op': _lib.ProgOp, 'estts_pack_job': _lib.PackJob}
