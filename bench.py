@@ -134,8 +134,8 @@ def wavernn_pass(precision, cpu_leg=True, kernel_table=False):
     res = {'workload': 'WaveRNN RAW 9-bit mu-law, 64 utterances x 560 frames, hop 256 / 22050 Hz (BASELINE config 4)',
            'rtf': dt / audio, 'wall_s': dt, 'audio_s': audio, 'samples_per_s': samples / dt, 'us_per_step': dt / steps * 1e6,
            'sequences': n_seq, 'precision': precision,
-           'includes': 'conditioning network, 12100 sampling steps (50 per hipGraph replay), device-to-host copy, '
-                       'host cross-fade / mu-law expansion'}
+           'includes': 'conditioning network, 12100 sampling steps (50 per hipGraph replay), cross-fade / mu-law expansion / '
+                       'closing fade in float64 on the device, device-to-host copy of the waveforms'}
 
     # one step's launches, traced and timed in isolation: the dominant layer against the matrix-core peak, the step against
     # the launch-chain floor and the weight stream
