@@ -299,6 +299,8 @@ def train_bench(args, rank, world, dist):
     model = ForwardTransformerTrainer(w, cfg, precision=args.precision, seed=1234)
     if args.backward_precision:
         model.backward_precision = args.backward_precision
+    if os.environ.get('ESTTS_BENCH_FOLD_SUMS') == '0':      # same-box comparison with the two-launch BatchNorm sums
+        model.fold_sums = False
     model.set_constants(learning_rate=1e-4, decoder_prenet_dropout=0.0, drop_n_heads=0)
     tok_d = torch.from_numpy(tokens).cuda()
     mel_d = torch.from_numpy(mel).cuda()

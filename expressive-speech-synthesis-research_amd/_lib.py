@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -30,7 +30,8 @@ class GemmArgs(C.Structure):
                 ('batch', _i32), ('batch_stride_a', _i64), ('batch_stride_w', _i64), ('batch_stride_c', _i64),
                 ('batch_stride_v', _i64),
                 ('ln_y', _vp), ('ln_x', _vp), ('ln_ga', _vp), ('ln_ba', _vp), ('ln_gb', _vp), ('ln_bb', _vp), ('ln_out', _vp),
-                ('ln_ldy', _i32), ('ln_ldx', _i32), ('ln_ldo', _i32), ('ln_act', _i32), ('ln_eps', _f32)]
+                ('ln_ldy', _i32), ('ln_ldx', _i32), ('ln_ldo', _i32), ('ln_act', _i32), ('ln_eps', _f32),
+                ('stat_slots', _vp), ('stat_shift', _vp)]
 
 
 class AttentionArgs(C.Structure):
@@ -93,7 +94,8 @@ class PackJob(C.Structure):
 class ColreduceArgs(C.Structure):
     _fields_ = [('z', _vp), ('ldz', _i32), ('g', _vp), ('ldg', _i32), ('a', _vp), ('lda', _i32), ('act', _i32),
                 ('mean', _vp), ('rstd', _vp), ('out0', _vp), ('out1', _vp), ('dy_out', _vp), ('lddy', _i32),
-                ('M', _i32), ('C', _i32), ('mode', _i32), ('scale', _vp), ('shift', _vp), ('ws', _vp), ('ws_bytes', _i64)]
+                ('M', _i32), ('C', _i32), ('mode', _i32), ('scale', _vp), ('shift', _vp), ('ws', _vp), ('ws_bytes', _i64),
+                ('defer', _i32), ('clear', _vp), ('clear_floats', _i64)]
 
 
 class WavernnPrepArgs(C.Structure):
@@ -160,6 +162,8 @@ SIGNATURES = {
     'estts_bn_finalize': (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'estts_affine_act': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_bn_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'estts_bn_finalize_slots': (_i32, [_vp, _i64, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'estts_bn_bwd_slots': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'estts_dropout': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _u32, _u32, _vp]),
     'estts_axpby': (_i32, [_vp, _i32, _f32, _vp, _i32, _f32, _i32, _i32, _vp]),
     'estts_head_scale': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),

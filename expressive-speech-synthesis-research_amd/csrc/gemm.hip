@@ -639,6 +639,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
         }
     }
 
+    // column moments of the output (stat_slots): a lane sums its 16 TM rows of the column, the two half-waves are added with
+    // one lane swap, and each wave adds its 32 TN columns to copy (row tile % 16) of the sums
+    const bool stats = p.stat_slots != nullptr;
+    const long stat_cp = (long)((p.N + 255) / 256) * 256;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * 32 * TN + j * 32 + r;
@@ -647,12 +651,29 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
         const float b1 = p.b1 ? p.b1[col] : 0.0f;
         const float s2 = p.s2 ? p.s2[col] : 1.0f;
         const float b2 = p.s2 ? p.b2[col] : 0.0f;
+        const float k0 = (stats && p.stat_shift) ? p.stat_shift[col] : 0.0f;
+        float q0 = 0.0f, q1 = 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value(p, acc[i][j][e], row, col, s1, b1, s2, b2);
+                if (row < p.M) {
+                    const float v = epilogue_value(p, acc[i][j][e], row, col, s1, b1, s2, b2);
+                    p.C[(long)row * p.ldc + col] = v;
+                    const float d = v - k0;
+                    q0 += d;
+                    q1 += d * d;
+                }
+            }
+        }
+        if (stats) {
+            q0 += lane_xor32(q0);
+            q1 += lane_xor32(q1);
+            if (h == 0) {
+                float* dst = p.stat_slots + (long)(tc.ty % 16) * 2 * stat_cp + col;
+                atomic_add_f32(dst, q0);
+                atomic_add_f32(dst + stat_cp, q1);
             }
         }
     }
@@ -788,6 +809,21 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         // (with K <= 256 a workgroup's eight K-steps do not amortise the wider tile's prologue: 19200 x 768 x 256 runs 44 us
         // as 64 x 64 tiles, 49 us as 64 x 128)
         tile = (a.N >= 128 && n8 >= 384 && a.K > 256) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
+    }
+    if (a.stat_slots) {
+        ESTTS_CHECK_ARG(a.batch <= 1 && !a.ln_y, "estts_gemm: stat_slots not with batch > 1 or a LayerNorm prologue");
+        if (tile < 5 || tile > 8) {   // a kernel without the summing epilogue: the product, then a pass over C
+            ESTTS_CHECK_ARG((a.N & 3) == 0 && (a.ldc & 3) == 0, "estts_gemm: stat_slots needs N and ldc multiples of 4 at this size");
+            estts_gemm_args b = *args;
+            b.stat_slots = nullptr;
+            b.stat_shift = nullptr;
+            const int r = estts_gemm(&b, stream);
+            if (r != 0) return r;
+            estts_colreduce_args c = {};
+            c.z = a.C; c.ldz = a.ldc; c.M = a.M; c.C = a.N; c.mode = 0; c.defer = 1; c.shift = a.stat_shift;
+            c.ws = a.stat_slots; c.ws_bytes = (int64_t)16 * 2 * ((a.N + 255) / 256) * 256 * 4;
+            return estts_colreduce(&c, stream);
+        }
     }
     if (a.ln_y) {   // LayerNorm prologue: only the kernel that stages a tile's source rows can compute them on the way in
         ESTTS_CHECK_ARG(a.ln_ga && a.ln_ba && a.ln_out && (!a.ln_gb == !a.ln_bb), "estts_gemm: LayerNorm prologue needs ln_ga, ln_ba, ln_out (and ln_gb with ln_bb)");

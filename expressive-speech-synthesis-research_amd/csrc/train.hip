@@ -112,6 +112,59 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* dy, int lddy, 
     });
 }
 
+// the same with dbeta / dgamma still spread over COLREDUCE_SLOTS copies (estts_colreduce with defer): a thread keeps its
+// four columns, adds the copies up once and walks rows blockIdx.y * 4 + (its row lane), + 4 gridDim.y, ...; the first row
+// split also adds the totals to the parameter gradients
+__global__ __launch_bounds__(256) void bn_bwd_slots_kernel(const float* dy, int lddy, const float* z, int ldz, const float* mean,
+                                                           const float* rstd, const float* gamma, const float* slots,
+                                                           long cp, float* dgamma, float* dbeta, float* dz, int lddz, int M,
+                                                           int C) {
+    const int chunk = threadIdx.x & 63;
+    const int rl = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + chunk) * 4;
+    if (c >= C) return;
+    float4 db = make_float4(0.f, 0.f, 0.f, 0.f), dg = db;
+    {
+        float4 v0[16], v1[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            v0[k] = ld4(slots + (long)k * 2 * cp + c);
+            v1[k] = ld4(slots + (long)k * 2 * cp + cp + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            db.x += v0[k].x; db.y += v0[k].y; db.z += v0[k].z; db.w += v0[k].w;
+            dg.x += v1[k].x; dg.y += v1[k].y; dg.z += v1[k].z; dg.w += v1[k].w;
+        }
+    }
+    if (blockIdx.y == 0 && rl == 0) {
+        float4 a = ld4(dbeta + c), b = ld4(dgamma + c);
+        a.x += db.x; a.y += db.y; a.z += db.z; a.w += db.w;
+        b.x += dg.x; b.y += dg.y; b.z += dg.z; b.w += dg.w;
+        st4(dbeta + c, a);
+        st4(dgamma + c, b);
+    }
+    const float inv_m = 1.0f / (float)M;
+    const float4 mu = ld4(mean + c), rs = ld4(rstd + c), ga = ld4(gamma + c);
+    auto one = [&](const float4& g, const float4& x) {
+        float4 r;
+        r.x = ga.x * rs.x * (g.x - db.x * inv_m - (x.x - mu.x) * rs.x * dg.x * inv_m);
+        r.y = ga.y * rs.y * (g.y - db.y * inv_m - (x.y - mu.y) * rs.y * dg.y * inv_m);
+        r.z = ga.z * rs.z * (g.z - db.z * inv_m - (x.z - mu.z) * rs.z * dg.z * inv_m);
+        r.w = ga.w * rs.w * (g.w - db.w * inv_m - (x.w - mu.w) * rs.w * dg.w * inv_m);
+        return r;
+    };
+    const int stride = gridDim.y * 4;
+    int row = blockIdx.y * 4 + rl;
+    for (; row + stride < M; row += 2 * stride) {   // two rows in flight (dz may alias dy: loads first)
+        const float4 g0 = ld4(dy + (long)row * lddy + c), x0 = ld4(z + (long)row * ldz + c);
+        const float4 g1 = ld4(dy + (long)(row + stride) * lddy + c), x1 = ld4(z + (long)(row + stride) * ldz + c);
+        st4(dz + (long)row * lddz + c, one(g0, x0));
+        st4(dz + (long)(row + stride) * lddz + c, one(g1, x1));
+    }
+    if (row < M) st4(dz + (long)row * lddz + c, one(ld4(dy + (long)row * lddy + c), ld4(z + (long)row * ldz + c)));
+}
+
 __global__ __launch_bounds__(256) void dropout_kernel(const float* x, int ldx, float* out, int ldo, int M, int D, float rate,
                                                       uint32_t seed, uint32_t site) {
     const float keep = 1.0f / (1.0f - rate);
@@ -228,9 +281,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const estts_colreduce_ar
     const int c = (blockIdx.x * 64 + chunk) * 4;
     const bool live = c < p.C;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (p.clear) {   // zero the other region
+        const long step = (long)gridDim.x * gridDim.y * 256;
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < p.clear_floats; i += step) p.clear[i] = 0.0f;
+    }
     if (live) {
         float4 k0 = s0, mu = s0, rs = s0, sc = s0, sh = s0;
-        if (p.mode == 0) k0 = ld4(p.z + c);
+        if (p.mode == 0 && !p.defer) k0 = ld4(p.z + c);
+        if (p.mode == 0 && p.defer && p.shift) k0 = ld4(p.shift + c);
         if (p.mode == 2) { mu = ld4(p.mean + c); rs = ld4(p.rstd + c); }
         const bool recompute = p.mode != 0 && !p.a && p.scale && p.act != ESTTS_ACT_NONE;
         if (recompute) { sc = ld4(p.scale + c); sh = ld4(p.shift + c); }
@@ -340,12 +398,29 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* s0, const
                                                           float eps, float momentum, float mv_scale, const float* gamma,
                                                           const float* beta,
                                                           float* moving_mean, float* moving_var, float* mean, float* rstd,
-                                                          float* scale, float* shift) {
+                                                          float* scale, float* shift, float* slots, long slot_stride) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const float a = s0[c] / (float)M;
+    float t0 = s0[c], t1 = s1[c];
+    if (slots) {   // 16 copies of both sums, one thread per column: add up, then clear
+        float v0[COLREDUCE_SLOTS], v1[COLREDUCE_SLOTS];
+#pragma unroll
+        for (int k = 0; k < COLREDUCE_SLOTS; ++k) {
+            v0[k] = slots[(long)k * 2 * slot_stride + c];
+            v1[k] = slots[(long)k * 2 * slot_stride + slot_stride + c];
+        }
+        t0 = t1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < COLREDUCE_SLOTS; ++k) {
+            t0 += v0[k];
+            t1 += v1[k];
+            slots[(long)k * 2 * slot_stride + c] = 0.0f;
+            slots[(long)k * 2 * slot_stride + slot_stride + c] = 0.0f;
+        }
+    }
+    const float a = t0 / (float)M;
     const float mu = z0[c] + a;
-    const float var = fmaxf(s1[c] / (float)M - a * a, 0.0f);
+    const float var = fmaxf(t1 / (float)M - a * a, 0.0f);
     const float rs = rsqrtf(var + eps);
     mean[c] = mu;
     rstd[c] = rs;
@@ -648,6 +723,23 @@ extern "C" int estts_bn_bwd(const float* dy, int32_t lddy, const float* z, int32
     hipLaunchKernelGGL(bn_bwd_kernel, dim3(ew_grid((long)M * (C >> 2))), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz,
                        mean, rstd, gamma, dgamma, dbeta, dz, lddz, M, C);
     ESTTS_CHECK_LAUNCH("estts_bn_bwd");
+    return 0;
+}
+
+extern "C" int estts_bn_bwd_slots(const float* dy, int32_t lddy, const float* z, int32_t ldz, const float* mean, const float* rstd,
+                                  const float* gamma, const float* slots, int64_t slot_stride, float* dgamma, float* dbeta,
+                                  float* dz, int32_t lddz, int32_t M, int32_t C, void* stream) {
+    ESTTS_CHECK_ARG(dy && z && mean && rstd && gamma && slots && dgamma && dbeta && dz && M > 0 && C > 0 && (C & 3) == 0 &&
+                        (lddy & 3) == 0 && (ldz & 3) == 0 && (lddz & 3) == 0,
+                    "estts_bn_bwd_slots: bad arguments");
+    ESTTS_CHECK_ARG(slot_stride == ((int64_t)(C + 255) / 256) * 256, "estts_bn_bwd_slots: slot_stride must be C rounded up to 256");
+    const int gx = (C + 255) / 256;
+    int ysplit = (M + 15) / 16;          // at least 16 rows per workgroup, about 1024 workgroups
+    const int cap = (1024 + gx - 1) / gx;
+    if (ysplit > cap) ysplit = cap;
+    hipLaunchKernelGGL(bn_bwd_slots_kernel, dim3(gx, ysplit), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma,
+                       slots, (long)slot_stride, dgamma, dbeta, dz, lddz, M, C);
+    ESTTS_CHECK_LAUNCH("estts_bn_bwd_slots");
     return 0;
 }
 
@@ -961,7 +1053,7 @@ extern "C" int estts_colreduce(const estts_colreduce_args* args, void* stream) {
     ESTTS_CHECK_ARG(args != nullptr, "estts_colreduce: null args");
     const estts_colreduce_args& a = *args;
     ESTTS_CHECK_ARG(a.M > 0 && a.C > 0 && (a.C & 3) == 0 && a.mode >= 0 && a.mode <= 2, "estts_colreduce: bad shape / mode");
-    ESTTS_CHECK_ARG(a.out0 && (a.mode == 1 || a.out1), "estts_colreduce: null output");
+    ESTTS_CHECK_ARG(a.defer || (a.out0 && (a.mode == 1 || a.out1)), "estts_colreduce: null output");
     if (a.mode == 0) {
         ESTTS_CHECK_ARG(a.z && (a.ldz & 3) == 0, "estts_colreduce: mode 0 needs z");
     } else {
@@ -978,6 +1070,20 @@ extern "C" int estts_colreduce(const estts_colreduce_args* args, void* stream) {
     const int gx = (a.C + 255) / 256;
     const long cp = (long)gx * 256;
     estts_colreduce_args k = a;
+    if (a.defer) {
+        ESTTS_CHECK_ARG(a.mode != 1, "estts_colreduce: defer is for modes 0 and 2");
+        ESTTS_CHECK_ARG(a.ws && a.ws_bytes >= (int64_t)COLREDUCE_SLOTS * 2 * cp * 4,
+                        "estts_colreduce: defer needs ws of %ld bytes", (long)COLREDUCE_SLOTS * 2 * cp * 4);
+        ESTTS_CHECK_ARG(!a.clear || (a.clear_floats >= 0 && (a.clear + a.clear_floats <= a.ws || a.clear >= a.ws + (long)COLREDUCE_SLOTS * 2 * cp)),
+                        "estts_colreduce: clear must not overlap the sums at ws");
+        int ys = (a.M + 15) / 16;
+        const int cap_d = (target + gx - 1) / gx;
+        if (ys > cap_d) ys = cap_d;
+        hipLaunchKernelGGL(colreduce_kernel, dim3(gx, ys), dim3(256), 0, (hipStream_t)stream, k);
+        ESTTS_CHECK_LAUNCH("estts_colreduce");
+        return 0;
+    }
+    k.clear = nullptr;
     if (k.ws && k.ws_bytes < (int64_t)COLREDUCE_SLOTS * 2 * cp * 4) k.ws = nullptr;
     int ysplit = (a.M + 15) / 16;
     const int cap = k.ws ? (target + gx - 1) / gx : 128;
@@ -1001,8 +1107,22 @@ extern "C" int estts_bn_finalize(const float* s0, const float* s1, const float* 
     ESTTS_CHECK_ARG(s0 && s1 && z0 && gamma && beta && mean && rstd && scale && shift && M > 0 && C > 0, "estts_bn_finalize: bad arguments");
     ESTTS_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "estts_bn_finalize: moving statistics go together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s0, s1, z0, M, C, eps, momentum,
-                       moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift);
+                       moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, (float*)nullptr, 0L);
     ESTTS_CHECK_LAUNCH("estts_bn_finalize");
+    return 0;
+}
+
+extern "C" int estts_bn_finalize_slots(float* slots, int64_t slot_stride, const float* z0, int32_t M, int32_t C, float eps,
+                                       float momentum, float moving_var_scale, const float* gamma, const float* beta,
+                                       float* moving_mean, float* moving_var, float* mean, float* rstd, float* scale,
+                                       float* shift, void* stream) {
+    ESTTS_CHECK_ARG(slots && z0 && gamma && beta && mean && rstd && scale && shift && M > 0 && C > 0, "estts_bn_finalize_slots: bad arguments");
+    ESTTS_CHECK_ARG(slot_stride == ((int64_t)(C + 255) / 256) * 256, "estts_bn_finalize_slots: slot_stride must be C rounded up to 256");
+    ESTTS_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "estts_bn_finalize_slots: moving statistics go together");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, slots, slots, z0, M, C, eps,
+                       momentum, moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, slots,
+                       (long)slot_stride);
+    ESTTS_CHECK_LAUNCH("estts_bn_finalize_slots");
     return 0;
 }
 

@@ -248,6 +248,10 @@ class ForwardTransformerTrainer:
         # piecewise-linear function the device did
         self.gate_log = None
         self._bn_batch = True      # BatchNormalization on batch statistics (training=True); False: on its moving statistics
+        # BatchNormalization sums (moments forward, dbeta / dgamma backward) go from the launch that builds them -- the
+        # layer's own product where that can sum its output -- straight to the launch that uses them; False: every sum is a
+        # reduction pass plus a launch that adds its 16 copies up (for comparisons)
+        self.fold_sums = True
         self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
 
     def __init__(self, weights, config, device='cuda', precision='bf16x3', seed=0, process_group=None, bucket_mb=25):
@@ -404,13 +408,32 @@ class ForwardTransformerTrainer:
 
         tape.append(backward)
 
-    def _bn_train(self, z, norm, M, C):
-        """Batch statistics of z [M, C] -> (mean, rstd, scale, shift); updates the moving statistics (momentum 0.99)."""
-        sums = self.store.zeros(2, C)
-        T.colreduce(0, sums[0], sums[1], z=z, M=M, C=C)
+    def _bn_train(self, z, norm, M, C, summed=None):
+        """Batch statistics of z [M, C] -> (mean, rstd, scale, shift); updates the moving statistics (momentum 0.99).
+        summed: the (pointer, stride) the layer's own launch already left the moments in, taken about the moving mean
+        (_stat_request); otherwise a reduction pass over z builds them.  Either way the sums stay spread over their 16 copies
+        until estts_bn_finalize_slots adds them up."""
         st = self._empty(4, C)
-        T.bn_finalize(sums[0], sums[1], z, M, C, norm.gamma, norm.beta, norm.mm, norm.mv, st[0], st[1], st[2], st[3])
+        if summed is None and not (self.fold_sums and C <= T.SumSlots.MAX_C):
+            sums = self.store.zeros(2, C)
+            T.colreduce(0, sums[0], sums[1], z=z, M=M, C=C)
+            T.bn_finalize(sums[0], sums[1], z, M, C, norm.gamma, norm.beta, norm.mm, norm.mv, st[0], st[1], st[2], st[3])
+            return st
+        if summed is None:
+            summed, about = T.colreduce(0, z=z, M=M, C=C, shift=z[0], defer=True), z
+        else:
+            about = norm.mm
+        T.bn_finalize(None, None, about, M, C, norm.gamma, norm.beta, norm.mm, norm.mv, st[0], st[1], st[2], st[3], slots=summed)
         return st
+
+    def _stat_request(self, z, norm, C):
+        """(gemm keyword arguments, slots) that make the layer's own launch sum the moments of its output z for `norm`: about
+        the moving mean, an estimate of the batch mean that is known before the launch (the shift only conditions the
+        variance's subtraction; any value is exact in exact arithmetic)."""
+        if not (self._bn_batch and self.fold_sums) or C > T.SumSlots.MAX_C:
+            return {}, None
+        ptr, stride = T.SumSlots.on(z.device).forward_region(C)
+        return {'stats': (ptr, norm.mm)}, (ptr, stride)
 
     def _bn_eval(self, norm, C):
         """(mean, rstd, scale, shift) of a BatchNormalization layer in inference mode: its moving statistics, left untouched
@@ -419,14 +442,15 @@ class ForwardTransformerTrainer:
         T.bn_finalize(self.store.zeros(C), norm.mv, norm.mm, 1, C, norm.gamma, norm.beta, None, None, st[0], st[1], st[2], st[3])
         return st
 
-    def _bn_stats(self, z, norm, M, C):
-        return self._bn_train(z, norm, M, C) if self._bn_batch else self._bn_eval(norm, C)
+    def _bn_stats(self, z, norm, M, C, summed=None):
+        return self._bn_train(z, norm, M, C, summed) if self._bn_batch else self._bn_eval(norm, C)
 
-    def _bn_input_grad(self, batch, dy, z, st, norm, sums, dz, M, C):
-        """Gradient with respect to the normalised tensor given sum(dy) and sum(dy * xhat) in `sums` (beta, gamma order):
-        the batch-statistics form, or dy * scale when the layer ran on its moving statistics."""
+    def _bn_input_grad(self, batch, dy, z, st, norm, sums, dz, M, C, slots=None):
+        """Gradient with respect to the normalised tensor given sum(dy) and sum(dy * xhat) in `sums` (beta, gamma order), or
+        still spread over the copies at `slots` (then also added to `sums`, the parameter gradients): the batch-statistics
+        form, or dy * scale when the layer ran on its moving statistics."""
         if batch:
-            T.bn_bwd(dy, z, st[0], st[1], norm.gamma, sums[1], sums[0], dz, M=M, C=C)
+            T.bn_bwd(dy, z, st[0], st[1], norm.gamma, sums[1], sums[0], dz, M=M, C=C, slots=slots)
         else:
             T.affine_act(dy, dz, st[2], self.store.zeros(C), None, M=M, C=C)
 
@@ -436,8 +460,9 @@ class ForwardTransformerTrainer:
         saved, h, s = [], x, None
         for i, (conv, norm, act) in enumerate(zip(Cb.convs, Cb.norms[:n], Cb.acts)):
             z = self._empty(M, conv.N)
-            self._lin_fwd(h, conv, z, M, seg)
-            st = self._bn_stats(z, norm, M, conv.N)
+            kw, summed = self._stat_request(z, norm, conv.N)
+            self._lin_fwd(h, conv, z, M, seg, **kw)
+            st = self._bn_stats(z, norm, M, conv.N, summed)
             nxt = self._empty(M, conv.N)
             T.affine_act(z, nxt, st[2], st[3], act, residual=x if i == n - 1 else None, M=M, C=conv.N)
             if self.gate_log is not None and act == 'relu':
@@ -457,16 +482,17 @@ class ForwardTransformerTrainer:
 
         def backward(dout):
             ds = self._empty(M, C)
-            T.colreduce(2, last.dbeta, last.dgamma, z=s, g=dout, mean=st_last[0], rstd=st_last[1], M=M, C=C)
-            self._bn_input_grad(batch, dout, s, st_last, last, (last.dbeta, last.dgamma), ds, M, C)
+            defer = batch and self.fold_sums and C <= T.SumSlots.MAX_C      # the sums go straight to the launch that uses them
+            sl = T.colreduce(2, last.dbeta, last.dgamma, z=s, g=dout, mean=st_last[0], rstd=st_last[1], M=M, C=C, defer=defer)
+            self._bn_input_grad(batch, dout, s, st_last, last, (last.dbeta, last.dgamma), ds, M, C, slots=sl)
             g, dx = ds, None
             for i in reversed(range(n)):
                 conv, norm, act = Cb.convs[i], Cb.norms[i], Cb.acts[i]
                 hin, z, st = saved[i]
                 dz = self._empty(M, conv.N)
-                T.colreduce(2, norm.dbeta, norm.dgamma, z=z, g=g, act=act, mean=st[0], rstd=st[1], dy_out=dz, M=M, C=conv.N,
-                            scale=st[2], shift=st[3])
-                self._bn_input_grad(batch, dz, z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N)
+                sl = T.colreduce(2, norm.dbeta, norm.dgamma, z=z, g=g, act=act, mean=st[0], rstd=st[1], dy_out=dz, M=M, C=conv.N,
+                                 scale=st[2], shift=st[3], defer=batch and self.fold_sums and conv.N <= T.SumSlots.MAX_C)
+                self._bn_input_grad(batch, dz, z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N, slots=sl)
                 if i > 0:
                     g = self._empty(M, conv.lin.cin)
                     self._lin_bwd(hin, conv, dz, M, seg, dx=g)

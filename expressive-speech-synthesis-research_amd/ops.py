@@ -243,7 +243,7 @@ def can_fuse_ln(lin, M, N_out=None, precision='bf16x3', site=None, act=None):
 
 
 def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
-         split=True, conv2d=None, dropout=None, batch=None, workspace=None, site=None, ln=None):
+         split=True, conv2d=None, dropout=None, batch=None, workspace=None, site=None, ln=None, stats=None):
     """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary).
     dropout = (rate, seed, site, row0): keep/scale after the activation, generator row = row0 + output row.
     batch = (count, stride_a, stride_w, stride_c, stride_v): that many products of this shape in one launch; x / lin / out
@@ -253,7 +253,9 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     precision: 'bf16' / 'bf16x3', or a PrecisionPolicy resolved at `site`.
     ln = dict(y=, x= or None, ln_a=(gamma, beta), ln_b=(gamma, beta) or None, act= or None, out=, eps=1e-6): the input rows
     are LNb(act(LNa(y)) + x), computed inside the launch and also written to `out`, which is what `x` must be (see
-    can_fuse_ln; rownorm() fused into the convolution that consumes it)."""
+    can_fuse_ln; rownorm() fused into the convolution that consumes it).
+    stats = (slots pointer, shift [N] tensor or None): also add the column moments of the output about `shift` to the 16
+    copies at the pointer (train_ops.SumSlots.forward_region; estts_gemm_args.stat_slots), for bn_finalize(slots=...)."""
     precision = precision_at(precision, site)
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
@@ -297,6 +299,8 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
         if ln.get('ln_b') is not None:
             a.ln_gb, a.ln_bb = ln['ln_b'][0].data_ptr(), ln['ln_b'][1].data_ptr()
         a.ln_act, a.ln_eps = ACT[ln.get('act')], ln.get('eps', 1e-6)
+    if stats is not None:
+        a.stat_slots, a.stat_shift = stats[0], _ptr(stats[1])
     if split:
         ws, cnt = gemm_workspace(x.device) if workspace is None else workspace
         a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()

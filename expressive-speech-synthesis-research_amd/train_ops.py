@@ -143,12 +143,58 @@ def colreduce_workspace(device):
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     ws = _colreduce_ws.get(key)
     if ws is None:
-        ws = _colreduce_ws[key] = torch.zeros(16 * 2 * 8192, dtype=torch.float32, device=torch.device('cuda', key))
+        ws = _colreduce_ws[key] = torch.zeros(16 * 2 * 8192 + 64, dtype=torch.float32, device=torch.device('cuda', key))
     return ws
 
 
-def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None, rstd=None, dy_out=None, M=None, C=None,
-              scale=None, shift=None):
+class SumSlots:
+    """Column sums that stay spread over 16 copies between the launch that builds them and the launch that consumes them
+    (estts_colreduce with defer, estts_gemm with stat_slots -> estts_bn_finalize_slots / estts_bn_bwd_slots), one set of
+    regions per device; every launch involved must run on one stream.
+    Region 2 holds forward moments: estts_bn_finalize_slots clears what it reads.  Regions 0 and 1 take turns for the
+    BatchNorm backward sums: estts_bn_bwd_slots reads a region from many workgroups and cannot clear it, so the next
+    deferred reduction, which writes the other region, clears it on the side."""
+    MAX_C = 4096
+    _per_device = {}
+
+    def __init__(self, device):
+        self.buf = torch.zeros(3, 16 * 2 * self.MAX_C, dtype=torch.float32, device=device)
+        self.used = [0, 0]       # floats of regions 0 / 1 that may be non-zero
+        self.turn = 0
+
+    @classmethod
+    def on(cls, device):
+        dev = torch.device(device)
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in cls._per_device:
+            cls._per_device[key] = cls(torch.device('cuda', key))
+        return cls._per_device[key]
+
+    @staticmethod
+    def stride(C):
+        return (C + 255) // 256 * 256
+
+    def forward_region(self, C):
+        """(pointer, stride) of the zeroed region a producer of forward moments for C columns writes."""
+        if C > self.MAX_C:
+            raise ValueError(f'SumSlots: at most {self.MAX_C} columns')
+        return self.buf[2].data_ptr(), self.stride(C)
+
+    def backward_region(self, C):
+        """(pointer, stride, clear pointer, clear floats) for the next deferred mode-2 reduction over C columns."""
+        if C > self.MAX_C:
+            raise ValueError(f'SumSlots: at most {self.MAX_C} columns')
+        i, o = self.turn, 1 - self.turn
+        out = (self.buf[i].data_ptr(), self.stride(C), self.buf[o].data_ptr() if self.used[o] else None, self.used[o])
+        self.used[i], self.used[o], self.turn = 16 * 2 * self.stride(C), 0, o
+        return out
+
+
+def colreduce(mode, out0=None, out1=None, z=None, g=None, a=None, act=None, mean=None, rstd=None, dy_out=None, M=None, C=None,
+              scale=None, shift=None, defer=False):
+    """defer=True (modes 0 / 2): the sums stay spread over 16 copies (SumSlots) and the call returns (pointer, stride) for
+    bn_finalize(slots=...) / bn_bwd(slots=...); out0 / out1 are not used.  In mode 0 `shift` [C] is then what the moments
+    are taken about (zero when None; z[0] is the usual choice)."""
     r = ColreduceArgs()
     ref = z if z is not None else g
     r.M = ref.shape[0] if M is None else M
@@ -161,18 +207,38 @@ def colreduce(mode, out0, out1=None, z=None, g=None, a=None, act=None, mean=None
         r.a, r.lda = a.data_ptr(), a.stride(0)
     r.act = ACT[act]
     r.mean, r.rstd = _ptr(mean), _ptr(rstd)
-    r.out0, r.out1 = out0.data_ptr(), _ptr(out1)
+    r.out0, r.out1 = _ptr(out0), _ptr(out1)
     if dy_out is not None:
         r.dy_out, r.lddy = dy_out.data_ptr(), dy_out.stride(0)
     r.mode = mode
     r.scale, r.shift = _ptr(scale), _ptr(shift)
+    if defer:
+        slots = SumSlots.on(ref.device)
+        r.out0 = r.out1 = None
+        r.defer = 1
+        if mode == 0:
+            ptr, stride = slots.forward_region(r.C)
+        else:
+            ptr, stride, clr, n = slots.backward_region(r.C)
+            r.clear, r.clear_floats = clr, n
+        r.ws, r.ws_bytes = ptr, 16 * 2 * stride * 4
+        check(_lib.load().estts_colreduce(r, _stream()), 'estts_colreduce')
+        return ptr, stride
     ws = colreduce_workspace(out0.device)
     r.ws, r.ws_bytes = ws.data_ptr(), ws.numel() * 4
     check(_lib.load().estts_colreduce(r, _stream()), 'estts_colreduce')
 
 
 def bn_finalize(s0, s1, z, M, C, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, eps=1e-3, momentum=0.99,
-                moving_var_scale=1.0):
+                moving_var_scale=1.0, slots=None):
+    """slots = (pointer, stride) of deferred sums (colreduce(0, defer=True) or gemm(stats=...)): s0 / s1 are then ignored and
+    z is the [C] vector (or matrix whose row 0) the moments were taken about."""
+    if slots is not None:
+        check(_lib.load().estts_bn_finalize_slots(slots[0], slots[1], z.data_ptr(), M, C, eps, momentum, moving_var_scale,
+                                                  gamma.data_ptr(), beta.data_ptr(), _ptr(moving_mean), _ptr(moving_var),
+                                                  mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()),
+              'estts_bn_finalize_slots')
+        return
     check(_lib.load().estts_bn_finalize(s0.data_ptr(), s1.data_ptr(), z.data_ptr(), M, C, eps, momentum, moving_var_scale, gamma.data_ptr(),
                                         beta.data_ptr(), _ptr(moving_mean), _ptr(moving_var), mean.data_ptr(), rstd.data_ptr(),
                                         scale.data_ptr(), shift.data_ptr(), _stream()), 'estts_bn_finalize')
@@ -187,9 +253,16 @@ def affine_act(z, out, scale=None, shift=None, act=None, residual=None, r_mod=0,
     return out
 
 
-def bn_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dz, M=None, C=None):
+def bn_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dz, M=None, C=None, slots=None):
+    """slots = (pointer, stride) of deferred mode-2 sums: they are the dbeta / dgamma used, and their totals are added to the
+    dgamma / dbeta tensors (the parameter gradients)."""
     M = z.shape[0] if M is None else M
     C = z.shape[1] if C is None else C
+    if slots is not None:
+        check(_lib.load().estts_bn_bwd_slots(dy.data_ptr(), dy.stride(0), z.data_ptr(), z.stride(0), mean.data_ptr(), rstd.data_ptr(),
+                                             gamma.data_ptr(), slots[0], slots[1], dgamma.data_ptr(), dbeta.data_ptr(),
+                                             dz.data_ptr(), dz.stride(0), M, C, _stream()), 'estts_bn_bwd_slots')
+        return dz
     check(_lib.load().estts_bn_bwd(dy.data_ptr(), dy.stride(0), z.data_ptr(), z.stride(0), mean.data_ptr(), rstd.data_ptr(),
                                    gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), dz.stride(0), M, C,
                                    _stream()), 'estts_bn_bwd')

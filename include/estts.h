@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 28
+#define ESTTS_ABI_VERSION 29
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -130,6 +130,13 @@ typedef struct estts_gemm_args {
     float* ln_out;
     int32_t ln_ldy, ln_ldx, ln_ldo, ln_act;
     float ln_eps;
+    /* Column moments of the output (stat_slots != NULL), for a BatchNormalization in training mode that follows the layer
+     * (CNNResNorm, TransformerTTS/model/layers.py:35-47): sum over the M rows of (C[m, c] - k[c]) and of its square, k =
+     * stat_shift or 0, added with float atomics to 16 copies laid out as estts_colreduce's deferred sums
+     * ([copy][sum 0 / 1][ceil(N / 256) * 256] floats, zero before the launch) and consumed by estts_bn_finalize_slots.
+     * The large-M tiles (5..8) sum inside their epilogue; any other kernel is followed by a reduction pass over C
+     * (same result layout).  Not with batch > 1 or a LayerNorm prologue. */
+    float* stat_slots; const float* stat_shift;
 } estts_gemm_args;
 
 int estts_gemm(const estts_gemm_args* args, void* stream);
@@ -532,6 +539,12 @@ typedef struct estts_colreduce_args {
     float* ws; int64_t ws_bytes;   /* optional scratch, ZERO before the first call (every call leaves it zero): 16 copies of
                                       the two sums, 128 * ceil(C / 256) * 256 bytes, over which the row splits spread their
                                       float atomics; NULL = all splits add into out0 / out1 directly */
+    int32_t defer;                 /* 1 (modes 0 / 2): leave the sums in the 16 copies at ws, laid out [copy][sum 0 / 1]
+                                      [ceil(C / 256) * 256], for the launch that consumes them (estts_bn_finalize_slots,
+                                      estts_bn_bwd_slots); out0 / out1 are not touched and ws is required.  In mode 0 the
+                                      moments are then taken about shift[c], or about 0 when shift is NULL. */
+    float* clear; int64_t clear_floats;   /* with defer: another region, of clear_floats floats, that this launch sets to
+                                      zero (copies an earlier consumer has finished reading), or NULL */
 } estts_colreduce_args;
 
 int estts_colreduce(const estts_colreduce_args* args, void* stream);
@@ -545,6 +558,14 @@ int estts_bn_finalize(const float* s0, const float* s1, const float* z0, int32_t
                       float moving_var_scale, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
                       float* mean, float* rstd, float* scale, float* shift, void* stream);
 
+/* The same from sums still spread over 16 copies (estts_colreduce with defer, or estts_gemm with stat_slots): copy k of
+ * s0 / s1 for column c is slots[(2 k + 0 / 1) * slot_stride + c], slot_stride = ceil(C / 256) * 256.  Adds the copies up and
+ * sets them to zero.  z0 [C]: what the moments were taken about (row 0 of the matrix, or the shift vector); it may be
+ * moving_mean itself (read before it is updated). */
+int estts_bn_finalize_slots(float* slots, int64_t slot_stride, const float* z0, int32_t M, int32_t C, float eps, float momentum,
+                            float moving_var_scale, const float* gamma, const float* beta, float* moving_mean,
+                            float* moving_var, float* mean, float* rstd, float* scale, float* shift, void* stream);
+
 /* out[m, c] = act(z[m, c] * scale[c] + shift[c]) + (R ? R[r_mod ? m % r_mod : m, c] : 0)   (scale / shift NULL = 1 / 0) */
 int estts_affine_act(const float* z, int32_t ldz, const float* scale, const float* shift, int32_t act, const float* R,
                      int32_t ldr, int32_t r_mod, float* out, int32_t ldo, int32_t M, int32_t C, void* stream);
@@ -553,6 +574,13 @@ int estts_affine_act(const float* z, int32_t ldz, const float* scale, const floa
 int estts_bn_bwd(const float* dy, int32_t lddy, const float* z, int32_t ldz, const float* mean, const float* rstd,
                  const float* gamma, const float* dgamma, const float* dbeta, float* dz, int32_t lddz, int32_t M,
                  int32_t C, void* stream);
+
+/* The same with dbeta / dgamma = the mode-2 sums still spread over 16 copies (estts_colreduce with defer; layout as for
+ * estts_bn_finalize_slots, sum 0 = dbeta, sum 1 = dgamma).  The totals are also ADDED to dgamma [C] / dbeta [C] (the
+ * parameter gradients).  The copies are left as they are: hand the region to a later estts_colreduce as `clear`. */
+int estts_bn_bwd_slots(const float* dy, int32_t lddy, const float* z, int32_t ldz, const float* mean, const float* rstd,
+                       const float* gamma, const float* slots, int64_t slot_stride, float* dgamma, float* dbeta, float* dz,
+                       int32_t lddz, int32_t M, int32_t C, void* stream);
 
 /* out[m, c] = x[m, c] * keep(seed, site, m, c) / (1 - rate): tf.keras.layers.Dropout in training mode with a
  * counter-based generator (the same call on a gradient is the backward pass).  May run in place. */

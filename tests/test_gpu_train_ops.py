@@ -285,6 +285,72 @@ def test_batchnorm_training_forward_backward(T, M, C, act):
     assert rel_err(dz, zt.grad) < 5e-5
 
 
+@pytest.mark.parametrize('sizes', [[(1000, 512), (700, 80), (5000, 1024), (77, 256)]])
+def test_batchnorm_with_deferred_sums_matches_the_two_launch_path(T, sizes):
+    """colreduce(defer=True) -> bn_finalize(slots=) / bn_bwd(slots=) against the path that adds the copies up in a launch of its
+    own; the backward regions take turns and are cleared by the next reduction, so the column count changes between calls."""
+    rng = np.random.default_rng(11)
+    for rnd, (M, C) in enumerate(sizes * 2):
+        z = dev(rng.normal(0.5, 2.0, size=(M, C)) + rng.normal(0, 3, size=C))
+        gamma, beta = dev(rng.normal(1, 0.2, size=C)), dev(rng.normal(0, 0.2, size=C))
+        dout = dev(rng.normal(size=(M, C)))
+        stats = []
+        for defer in (False, True):
+            mm, mv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+            st = torch.empty(4, C, device='cuda')
+            if defer:
+                sl = T.colreduce(0, z=z, shift=z[0], defer=True)
+                T.bn_finalize(None, None, z, M, C, gamma, beta, mm, mv, *st, slots=sl)
+            else:
+                s = torch.zeros(2, C, device='cuda')
+                T.colreduce(0, s[0], s[1], z=z)
+                T.bn_finalize(s[0], s[1], z, M, C, gamma, beta, mm, mv, *st)
+            g2 = torch.zeros(2, C, device='cuda') + (0.5 if defer else 0.0)    # totals are ADDED to the gradients
+            dy, dz = torch.empty(M, C, device='cuda'), torch.empty(M, C, device='cuda')
+            sl = T.colreduce(2, g2[0], g2[1], z=z, g=dout, act='relu', mean=st[0], rstd=st[1], dy_out=dy, scale=st[2], shift=st[3],
+                             defer=defer)
+            T.bn_bwd(dy, z, st[0], st[1], gamma, g2[1], g2[0], dz, slots=sl)
+            stats.append((st.clone(), mm, mv, (g2 - (0.5 if defer else 0.0)).clone(), dz))
+        a, b = stats
+        # (float atomics: the order of the additions differs from launch to launch)
+        assert max(rel_err(b[i], a[i]) for i in range(5)) < 2e-6, (rnd, M, C)
+    slots = T.SumSlots.on('cuda')
+    assert float(slots.buf[2].abs().max()) == 0.0          # bn_finalize cleared what it read
+    assert float(slots.buf[slots.turn].abs().max()) == 0.0  # the region the next reduction writes is clear
+
+
+@pytest.mark.parametrize('M,N,K,taps', [(19200, 256, 768, 3), (4096, 512, 256, 1), (300, 80, 256, 1), (1000, 384, 640, 5)])
+def test_gemm_sums_the_moments_of_its_output(T, M, N, K, taps):
+    """estts_gemm with stat_slots (large-M tiles: inside the epilogue; other kernels: a reduction pass behind the product) ->
+    bn_finalize(slots=): mean / rstd of the layer output about a shift vector, against float64 moments of the stored output."""
+    from estts import ops
+    rng = np.random.default_rng(M + N)
+    cin = K // taps
+    seg = 100 if taps > 1 else 0
+    x = dev(rng.normal(size=(M, cin)))
+    kernel = rng.normal(size=(K, N)) / math.sqrt(K)
+    bias = rng.normal(0, 2, size=N)
+    lin = T.TrainLinear(dev(kernel), dev(bias), taps=taps, lpad=(taps - 1) // 2).fwd
+    shift_v = dev(bias + rng.normal(0, 0.1, size=N))
+    gamma, beta = dev(rng.normal(1, 0.2, size=N)), dev(rng.normal(0, 0.2, size=N))
+    for about in (shift_v, None):
+        out = torch.empty(M, N, device='cuda')
+        ptr, stride = T.SumSlots.on('cuda').forward_region(N)
+        ops.gemm(x, lin, out, M=M, seg_len=seg, stats=(ptr, about))
+        st = torch.empty(4, N, device='cuda')
+        mm, mv = torch.zeros(N, device='cuda'), torch.ones(N, device='cuda')
+        T.bn_finalize(None, None, about if about is not None else torch.zeros(N, device='cuda'), M, N, gamma, beta, mm, mv, *st,
+                      slots=(ptr, stride))
+        o = out.double().cpu().numpy()
+        assert rel_err(st[0], o.mean(0)) < 1e-5
+        assert rel_err(st[1], 1 / np.sqrt(o.var(0) + 1e-3)) < 1e-5
+        plain = torch.empty(M, N, device='cuda')
+        ops.gemm(x, lin, plain, M=M, seg_len=seg)
+        assert torch.equal(plain, out)
+        assert float(T.SumSlots.on('cuda').buf[2].abs().max()) == 0.0
+
+
+
 def test_expand_embed_loss_adam_axpby_headscale(T):
     from estts import ops
     rng = np.random.default_rng(5)
