@@ -397,8 +397,9 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             patches = self._empty(M, conv.K)
             T.im2col(y, patches, B, H, W, Cin, Ho, Wo, 3, s, pt, pl)
             z = self._empty(M, conv.N)
-            self._lin_fwd(patches, conv, z, M)
-            st = self._bn_stats(z, norm, M, conv.N)
+            kw, summed = self._stat_request(z, norm, conv.N)
+            self._lin_fwd(patches, conv, z, M, **kw)
+            st = self._bn_stats(z, norm, M, conv.N, summed)
             nxt = self._empty(M, conv.N)
             T.affine_act(z, nxt, st[2], st[3], 'relu', M=M, C=conv.N)
             if self.gate_log is not None:
@@ -492,12 +493,18 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 patches, z, st, (Hi, Wi, Ci, Ho, Wo, pt, pl) = saved[i]
                 M = B * Ho * Wo
                 dz = self._empty(M, conv.N)
-                sums = self.store.zeros(2, conv.N)           # this call's own sum(dy) and sum(dy * xhat): bn_bwd reads them
-                T.colreduce(2, sums[0], sums[1], z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz,
-                            M=M, C=conv.N, scale=st[2], shift=st[3])
-                self._bn_input_grad(batch, dz, z, st, norm, sums, dz, M, conv.N)
-                T.axpby(sums[0].view(1, -1), norm.dbeta.view(1, -1), alpha=1.0, beta=1.0, M=1, D=conv.N)
-                T.axpby(sums[1].view(1, -1), norm.dgamma.view(1, -1), alpha=1.0, beta=1.0, M=1, D=conv.N)
+                if batch and self.fold_sums and conv.N <= T.SumSlots.MAX_C:
+                    # this call's own sum(dy) and sum(dy * xhat) go to bn_bwd in their copies; it adds them to the gradients
+                    sl = T.colreduce(2, z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz, M=M, C=conv.N,
+                                     scale=st[2], shift=st[3], defer=True)
+                    self._bn_input_grad(batch, dz, z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N, slots=sl)
+                else:
+                    sums = self.store.zeros(2, conv.N)       # this call's own sums: bn_bwd reads them
+                    T.colreduce(2, sums[0], sums[1], z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz,
+                                M=M, C=conv.N, scale=st[2], shift=st[3])
+                    self._bn_input_grad(batch, dz, z, st, norm, sums, dz, M, conv.N)
+                    T.axpby(sums[0].view(1, -1), norm.dbeta.view(1, -1), alpha=1.0, beta=1.0, M=1, D=conv.N)
+                    T.axpby(sums[1].view(1, -1), norm.dgamma.view(1, -1), alpha=1.0, beta=1.0, M=1, D=conv.N)
                 if i == 0 and not input_grad:
                     self._lin_bwd(patches, conv, dz, M)
                 else:

@@ -354,12 +354,23 @@ class WaveRNNTrainer:
         cur.wait_stream(sb)
 
     # ------------------------------------------------------------------ pieces of the step
-    def _bn_train(self, z, bn, M, C):
-        sums = torch.zeros(2, C, dtype=torch.float32, device=self.device)
-        T_.colreduce(0, sums[0], sums[1], z=z, M=M, C=C)
+    def _bn_gemm(self, x, conv, bn, z):
+        """z = conv(x) with the moments of z summed by the same call (about the moving mean, which is known beforehand); returns
+        the statistics of _bn_train."""
+        C = conv.lin.fwd.N
+        ptr, stride = T_.SumSlots.on(self.device).forward_region(C)
+        ops.gemm(x, conv.lin.fwd, z, precision=self.precision, stats=(ptr, bn.mm))
+        return self._bn_train(z, bn, z.shape[0], C, summed=(ptr, stride))
+
+    def _bn_train(self, z, bn, M, C, summed=None):
+        """(mean, rstd, scale, shift) from batch statistics; moving statistics updated (torch.nn.BatchNorm1d: momentum 0.1,
+        unbiased moving variance).  summed: (pointer, stride) of moments already taken about the moving mean."""
         st = torch.empty(4, C, dtype=torch.float32, device=self.device)
-        T_.bn_finalize(sums[0], sums[1], z, M, C, bn.gamma, bn.beta, bn.mm, bn.mv, st[0], st[1], st[2], st[3], eps=1e-5,
-                       momentum=0.9, moving_var_scale=M / max(M - 1, 1))
+        about = bn.mm
+        if summed is None:
+            summed, about = T_.colreduce(0, z=z, M=M, C=C, shift=z[0], defer=True), z
+        T_.bn_finalize(None, None, about, M, C, bn.gamma, bn.beta, bn.mm, bn.mv, st[0], st[1], st[2], st[3], eps=1e-5,
+                       momentum=0.9, moving_var_scale=M / max(M - 1, 1), slots=summed)
         return st
 
     def _lin_bwd(self, x, L, dy, M, dx=None, residual=None):
@@ -375,20 +386,17 @@ class WaveRNNTrainer:
         Mr, C, pr = ws['Mr'], self.compute_dims, self.precision
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)   # noqa: E731
         z = e(Mr, C)
-        ops.gemm(ws['unf'], self.conv_in.lin.fwd, z, precision=pr)
-        st0 = self._bn_train(z, self.bn_in, Mr, C)
+        st0 = self._bn_gemm(ws['unf'], self.conv_in, self.bn_in, z)
         x = e(Mr, C)
         T_.affine_act(z, x, st0[2], st0[3], 'relu')
         saved = []
         for c1, b1, c2, b2 in self.blocks:
             z1 = e(Mr, C)
-            ops.gemm(x, c1.lin.fwd, z1, precision=pr)
-            s1 = self._bn_train(z1, b1, Mr, C)
+            s1 = self._bn_gemm(x, c1, b1, z1)
             a = e(Mr, C)
             T_.affine_act(z1, a, s1[2], s1[3], 'relu')
             z2 = e(Mr, C)
-            ops.gemm(a, c2.lin.fwd, z2, precision=pr)
-            s2 = self._bn_train(z2, b2, Mr, C)
+            s2 = self._bn_gemm(a, c2, b2, z2)
             nx = e(Mr, C)
             T_.affine_act(z2, nx, s2[2], s2[3], None, residual=x)
             saved.append((x, z1, s1, a, z2, s2))
@@ -401,21 +409,20 @@ class WaveRNNTrainer:
             self._lin_bwd(x_last, self.conv_out, d_aux, Mr, dx=dx)
             for (c1, b1, c2, b2), (xin, z1, s1, a, z2, s2) in zip(reversed(self.blocks), reversed(saved)):
                 dz2 = e(Mr, C)
-                T_.colreduce(2, b2.dbeta, b2.dgamma, z=z2, g=dx, mean=s2[0], rstd=s2[1], M=Mr, C=C)
-                T_.bn_bwd(dx, z2, s2[0], s2[1], b2.gamma, b2.dgamma, b2.dbeta, dz2, M=Mr, C=C)
+                sl = T_.colreduce(2, z=z2, g=dx, mean=s2[0], rstd=s2[1], M=Mr, C=C, defer=True)
+                T_.bn_bwd(dx, z2, s2[0], s2[1], b2.gamma, b2.dgamma, b2.dbeta, dz2, M=Mr, C=C, slots=sl)
                 da = e(Mr, C)
                 self._lin_bwd(a, c2, dz2, Mr, dx=da)
                 dz1 = e(Mr, C)
-                T_.colreduce(2, b1.dbeta, b1.dgamma, z=z1, g=da, a=a, act='relu', mean=s1[0], rstd=s1[1], dy_out=dz1, M=Mr, C=C)
-                T_.bn_bwd(dz1, z1, s1[0], s1[1], b1.gamma, b1.dgamma, b1.dbeta, dz1, M=Mr, C=C)
+                sl = T_.colreduce(2, z=z1, g=da, a=a, act='relu', mean=s1[0], rstd=s1[1], dy_out=dz1, M=Mr, C=C, defer=True)
+                T_.bn_bwd(dz1, z1, s1[0], s1[1], b1.gamma, b1.dgamma, b1.dbeta, dz1, M=Mr, C=C, slots=sl)
                 ndx = e(Mr, C)
                 self._lin_bwd(xin, c1, dz1, Mr, dx=ndx, residual=dx)
                 dx = ndx
             dz = e(Mr, C)
             x0 = saved[0][0] if saved else x_last
-            T_.colreduce(2, self.bn_in.dbeta, self.bn_in.dgamma, z=z, g=dx, a=x0, act='relu', mean=st0[0], rstd=st0[1], dy_out=dz,
-                         M=Mr, C=C)
-            T_.bn_bwd(dz, z, st0[0], st0[1], self.bn_in.gamma, self.bn_in.dgamma, self.bn_in.dbeta, dz, M=Mr, C=C)
+            sl = T_.colreduce(2, z=z, g=dx, a=x0, act='relu', mean=st0[0], rstd=st0[1], dy_out=dz, M=Mr, C=C, defer=True)
+            T_.bn_bwd(dz, z, st0[0], st0[1], self.bn_in.gamma, self.bn_in.dgamma, self.bn_in.dbeta, dz, M=Mr, C=C, slots=sl)
             T_.wgrad(ws['unf'], dz, self.conv_in.dk, M=Mr, precision=self.precision)
 
         tape.append(backward)
