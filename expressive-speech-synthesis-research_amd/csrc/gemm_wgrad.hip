@@ -187,6 +187,230 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
         }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// 1-D convolutions whose channel count is a multiple of 64: a workgroup owns 64 channels x 64 outputs for ALL taps.  The
+// taps of a convolution read the same input rows one row apart, so one staged tile of 32 + TAPS - 1 input rows (and one dY
+// tile) feeds TAPS times the matrix work of wgrad_kernel: the fragment of tap t is the same transposing LDS read t rows
+// further down.  A pair (output row, tap) whose input row falls outside the row's sequence must not contribute: steps
+// that touch a sequence border (uniform test) clear those rows in the A fragment registers; all other steps skip that.
+// ------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NSPLIT, int TAPS>
+__global__ __launch_bounds__(256, TAPS == 3 ? 3 : 2) void wgrad_conv_kernel(const estts_gemm_args ga, const float* dY, const int lddy, float* dW,
+                                                         const int lddw, const int rows_per_split, float* db, const int ctiles,
+                                                         const int ntiles, const int nsplits) {
+    constexpr int NS = (NSPLIT > 1) ? 2 : 1;
+    constexpr int AR = 32 + TAPS - 1;   // staged input rows per step
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][AR * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ys[2][NS][32 * LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int per_xcd = gridDim.x >> 3;   // same workgroup order as wgrad_kernel, channel tile fastest
+    const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (vid >= ctiles * ntiles * nsplits) return;
+    const int cx = vid % ctiles;
+    const int c0 = cx * 64, n0 = (vid / ctiles) % ntiles * 64;
+    const int m_begin = vid / (ctiles * ntiles) * rows_per_split;
+    const int m_end = min(m_begin + rows_per_split, ga.M);
+
+    const int chunk = tid & 15;
+    const int r0 = tid >> 4;
+    const int ncol = n0 + chunk * 4;
+    const bool ycol_ok = ncol < ga.N;
+    const int seg = ga.conv_w, pl = ga.conv_pl;
+    const float* a_col = ga.A + c0 + chunk * 4;
+    const bool want_db = db != nullptr && cx == 0;     // uniform
+
+    float4 a_reg[3], y_reg[2];
+    bool a_ok[3], y_ok[2];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i == 2 && r0 >= TAPS - 1) break;          // rows 32 .. AR - 1 of the tile: the first TAPS - 1 row lanes
+            const int row = m0 - pl + r0 + 16 * i;         // input row of tile row r0 + 16 i
+            a_ok[i] = row >= 0 && row < ga.M;
+            a_reg[i] = *reinterpret_cast<const float4*>(a_col + (a_ok[i] ? (long)row * ga.lda : 0L));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + r0 + 16 * i;
+            y_ok[i] = row < ga.M && ycol_ok;
+            y_reg[i] = *reinterpret_cast<const float4*>(dY + (y_ok[i] ? (long)row * lddy + ncol : 0L));
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i == 2 && r0 >= TAPS - 1) break;
+            const int o = (r0 + 16 * i) * LD + chunk * 4;
+            bf16x4 ah, al;
+            split_bf16x4(zero_unless(a_ok[i], a_reg[i]), ah, al);
+            *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = ah;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = al;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = (r0 + 16 * i) * LD + chunk * 4;
+            const float4 yz = zero_unless(y_ok[i], y_reg[i]);
+            if (want_db) { bsum.x += yz.x; bsum.y += yz.y; bsum.z += yz.z; bsum.w += yz.w; }
+            bf16x4 yh, yl;
+            split_bf16x4(yz, yh, yl);
+            *reinterpret_cast<bf16x4*>(&Ys[buf][0][o]) = yh;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(&Ys[buf][NS - 1][o]) = yl;
+        }
+    };
+
+    f32x4 acc[TAPS][2][2];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frag = (4 * g + (i16 >> 2)) * LD + 4 * (i16 & 3);
+    if (m_begin < m_end) load(m_begin);
+    int buf = 0;
+    int pos0 = m_begin % seg;   // position of the step's first output row inside its sequence
+    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
+        stage(buf);
+        __syncthreads();
+        if (m0 + 32 < m_end) load(m0 + 32);
+        // rows pos .. pos + 31 (mod seg): every tap of every row stays inside the sequence when pos >= pl and the last row is
+        // at most seg - (TAPS - pl)
+        const bool border = pos0 < pl || pos0 + 31 > seg - (TAPS - pl);
+        bf16x8 yf[NS][2];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const __bf16* py = &Ys[buf][s][frag + wn * 32 + i * 16];
+                yf[s][i] = tr_read_pair(py, py + 16 * LD);
+            }
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            bf16x8 af[NS][2];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const __bf16* pa = &As[buf][s][frag + t * LD + wk * 32 + i * 16];
+                    af[s][i] = tr_read_pair(pa, pa + 16 * LD);
+                }
+            if (border) {   // uniform: this lane's eight rows are 4 g + e and 16 + 4 g + e, e = 0..3
+                unsigned keep[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const int e = 2 * d + hlf;
+                        const int slot = (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4));
+                        int q = pos0 + slot;                    // position of the row inside its sequence
+                        if (seg >= 32) q -= q >= seg ? seg : 0;
+                        else q %= seg;
+                        const int p = q + t - pl;
+                        if (p >= 0 && p < seg) w |= 0xffffu << (16 * hlf);
+                    }
+                    keep[d] = w;
+                }
+                const u32x4 kv = {keep[0], keep[1], keep[2], keep[3]};
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[s][i] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, af[s][i]) & kv);
+            }
+            if (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[NS - 1][i], yf[0][j], acc[t][i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], yf[NS - 1][j], acc[t][i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], yf[0][j], acc[t][i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+        pos0 = (pos0 + 32) % seg;
+    }
+
+    if (want_db) {   // uniform over the workgroup
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(&As[0][0][0]);   // [16 row lanes][64 columns]
+        *reinterpret_cast<float4*>(red + r0 * 64 + chunk * 4) = bsum;
+        __syncthreads();
+        if (tid < 64 && n0 + tid < ga.N) {
+            float t = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[r * 64 + tid];
+            atomic_add_f32(db + n0 + tid, t);
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 32 + j * 16 + i16;
+                if (col >= ga.N) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = t * ga.c_per_tap + c0 + wk * 32 + i * 16 + 4 * g + r;
+                    atomic_add_f32(dW + (long)row * lddw + col, acc[t][i][j][r]);
+                }
+            }
+}
+
+// Row splits of the all-taps kernel: one round of workgroups (measured on MI355X, tools/tune_wgrad.py: 19200 x 256 x 1536,
+// three taps: 93 / 67 / 66 / 77 us with 8 / 16 / 24 / 32 splits of its 32 tiles; 19200 x 256 x 1280, five taps: 65 / 57 / 62 us
+// with 16 / 24 / 32 splits of its 16 tiles).
+int wgrad_conv_splits(const estts_wgrad_args& a) {
+    const int tiles = (a.c_per_tap / 64) * ((a.N + 63) / 64);
+    static const int target = [] { const char* e = getenv("ESTTS_WGRAD_CONV_WGS"); return e ? atoi(e) : 0; }();   // for measurements
+    int splits = (target > 0 ? target : (a.taps == 3 ? 512 : 384)) / tiles;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+template <int TAPS>
+int launch_wgrad_conv(const estts_gemm_args& ga, const estts_wgrad_args& a, hipStream_t st) {
+    const int ctiles = a.c_per_tap / 64, ntiles = (a.N + 63) / 64;
+    const int tiles = ctiles * ntiles;
+    int splits = a.splits;
+    if (splits <= 0) splits = wgrad_conv_splits(a);
+    const int steps = (a.M + 31) / 32;
+    const int rows_per_split = ((steps + splits - 1) / splits) * 32;
+    splits = (a.M + rows_per_split - 1) / rows_per_split;
+    const long total = (long)tiles * splits;
+    ESTTS_CHECK_ARG(total < (1L << 30), "estts_gemm_wgrad: too many workgroups");
+    dim3 grid((unsigned)((total + 7) / 8 * 8));
+    if (a.precision == 3)
+        hipLaunchKernelGGL((wgrad_conv_kernel<3, TAPS>), grid, dim3(256), 0, st, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
+                           ctiles, ntiles, splits);
+    else
+        hipLaunchKernelGGL((wgrad_conv_kernel<1, TAPS>), grid, dim3(256), 0, st, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
+                           ctiles, ntiles, splits);
+    ESTTS_CHECK_LAUNCH("estts_gemm_wgrad");
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream) {
@@ -218,6 +442,15 @@ extern "C" int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream) {
     ga.conv_stride = 1;
     ga.conv_pt = 0;
     ga.conv_pl = a.tap_lpad;
+
+    // convolutions over whole 64-channel tiles: all taps from one staged tile (ESTTS_WGRAD_PER_TAP=1: the per-tap kernel, for
+    // measurements)
+    static const bool per_tap = [] { const char* e = getenv("ESTTS_WGRAD_PER_TAP"); return e && atoi(e) != 0; }();
+    // (a workgroup of that kernel adds TAPS tiles to dW at its end: it pays from about 16 steps per workgroup -- 3200 x 512 x
+    // 1536, three taps: 37 us at best against 35 us per tap)
+    if (!per_tap && (a.taps == 3 || a.taps == 5) && a.c_per_tap % 64 == 0 && a.tap_lpad >= 0 && a.tap_lpad < a.taps &&
+        (a.splits > 0 || a.M / wgrad_conv_splits(a) >= 512))
+        return a.taps == 3 ? launch_wgrad_conv<3>(ga, a, (hipStream_t)stream) : launch_wgrad_conv<5>(ga, a, (hipStream_t)stream);
 
     const int tiles = ((a.K + 63) / 64) * ((a.N + 63) / 64);
     int splits = a.splits;

@@ -461,6 +461,8 @@ int estts_pack_weights(const estts_pack_job* jobs, int32_t n_jobs, int64_t total
  *   dW[tap * c_per_tap + c, n] += sum_m A[row(m) + tap - tap_lpad, c] * dY[m, n]
  * (same row addressing as estts_gemm; float32 atomic accumulation: dW must be zeroed by the caller and the
  * summation order is not fixed).  splits: number of row ranges worked on concurrently, 0 = automatic.
+ * Convolutions of 3 or 5 taps over a multiple of 64 channels run, when a workgroup gets enough rows (automatic) or splits
+ * is given, as a kernel that stages every input tile once for all taps.
  * Replaces: the kernel gradients tf.GradientTape produces for Dense / Conv1D (models.py:402). */
 typedef struct estts_wgrad_args {
     const float* A; int32_t lda;

@@ -91,6 +91,29 @@ def test_wgrad_one_tap_shifted(T, B, seg, K, N):
     assert rel_err(db, dy.sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize('taps,lpad,cin,N,B,seg,prec', [(3, 1, 64, 72, 5, 37, 'bf16x3'), (3, 1, 128, 256, 7, 100, 'bf16x3'),
+                                                        (5, 2, 64, 80, 3, 50, 'bf16x3'), (5, 4, 128, 64, 9, 19, 'bf16x3'),
+                                                        (3, 2, 192, 40, 40, 7, 'bf16x3'), (3, 0, 64, 64, 2, 600, 'bf16x3'),
+                                                        (5, 2, 256, 256, 32, 600, 'bf16x3'), (3, 1, 64, 72, 5, 37, 'bf16')])
+def test_wgrad_all_taps_from_one_staged_tile(T, taps, lpad, cin, N, B, seg, prec):
+    """Convolutions over whole 64-channel tiles take the kernel that stages the input rows once for all taps: sequence
+    borders inside a 32-row step, sequences shorter than a step, causal padding (lpad = taps - 1) and row counts that are not
+    multiples of 32, against float64; the bias gradient rides along."""
+    rng = np.random.default_rng(taps * 1000 + cin + seg)
+    M, K = B * seg, taps * cin
+    x = rng.normal(size=(M, cin))
+    dy = rng.normal(size=(M, N))
+    xp = np.pad(x.reshape(B, seg, cin), ((0, 0), (lpad, taps - 1 - lpad), (0, 0)))
+    ref = np.concatenate([np.einsum('bsc,bsn->cn', xp[:, t:t + seg], dy.reshape(B, seg, N)) for t in range(taps)], 0)
+    dw = torch.zeros(K, N, device='cuda')
+    db = torch.zeros(N, device='cuda')
+    # (an explicit number of row ranges selects that kernel whatever the size; left to itself the library takes it from
+    # about 512 rows per workgroup, which the 19200-row case reaches)
+    T.wgrad(dev(x), dev(dy), dw, taps=taps, lpad=lpad, seg_len=seg, precision=prec, db=db, splits=0 if M >= 19200 else 2)
+    assert rel_err(dw, ref) < (3e-5 if prec == 'bf16x3' else 2e-2)
+    assert rel_err(db, dy.sum(0)) < 1e-5
+
+
 def test_wgrad_large_rows_many_splits(T):
     rng = np.random.default_rng(0)
     M, K, N = 4100, 192, 136
