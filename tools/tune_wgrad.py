@@ -10,8 +10,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import estts  # noqa: E402,F401
 from estts import train_ops as T  # noqa: E402
 
-SHAPES = [(19200, 256, 1536, 3, 600), (19200, 512, 768, 3, 600), (3200, 512, 1536, 3, 100), (19200, 256, 1280, 5, 600),
-          (19200, 80, 1280, 5, 600), (19200, 256, 768, 1, 0)]
+if os.environ.get('TUNE_SMALL'):      # the B = 8 step of the autoregressive trainer, the B = 32 encoder
+    SHAPES = [(4800, 256, 1536, 3, 600), (4800, 512, 768, 3, 600), (4800, 256, 1280, 5, 600), (3200, 512, 1536, 3, 100),
+              (800, 512, 1536, 3, 100)]
+else:
+  SHAPES = [(19200, 256, 1536, 3, 600), (19200, 512, 768, 3, 600), (3200, 512, 1536, 3, 100), (19200, 256, 1280, 5, 600),
+            (19200, 80, 1280, 5, 600), (19200, 256, 768, 1, 0)]
 SPLITS = [int(v) for v in os.environ.get('TUNE_SPLITS', '0').split(',')]      # 0 = the library's own choice
 ROTATE = int(os.environ.get('TUNE_ROTATE', '1'))     # operand sets used in turn: 8 of them no longer fit the Infinity Cache
 for M, N, K, taps, seg in SHAPES:
