@@ -77,6 +77,8 @@ def time_kernels(trace, reps=20, rounds=3):
             rows.append((kind, info, best))
             del g
     torch.cuda.synchronize()
+    from estts import train_ops
+    train_ops.SumSlots.reset_all()      # a replayed layer that sums its output's moments leaves them where no consumer clears them
     return rows
 
 

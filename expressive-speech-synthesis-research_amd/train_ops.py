@@ -170,6 +170,13 @@ class SumSlots:
             cls._per_device[key] = cls(torch.device('cuda', key))
         return cls._per_device[key]
 
+    @classmethod
+    def reset_all(cls):
+        """Zero every region (after launches that left sums nobody consumed, e.g. a producer replayed on its own for timing)."""
+        for s in cls._per_device.values():
+            s.buf.zero_()
+            s.used, s.turn = [0, 0], 0
+
     @staticmethod
     def stride(C):
         return (C + 255) // 256 * 256
