@@ -268,10 +268,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const estts_gemm_ar
     const float b1 = p.b1 ? p.b1[col] : 0.0f;
     const float s2 = p.s2 ? p.s2[col] : 1.0f;
     const float b2 = p.s2 ? p.b2[col] : 0.0f;
+    float res[4];   // R first: it may be C itself, which keeps a load behind every store that precedes it
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = m0 + (wave >> 1) * 16 + g * 4 + r;
-        if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value(p, out[r], row, col, s1, b1, s2, b2);
+        res[r] = (p.R && row < p.M) ? epilogue_residual(p, row, col) : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + (wave >> 1) * 16 + g * 4 + r;
+        if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value_r(p, out[r], row, col, s1, b1, s2, b2, res[r]);
     }
 }
 
@@ -438,12 +444,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const estts_gemm_args p, cons
         const float b1 = p.b1 ? p.b1[col] : 0.0f;
         const float s2 = p.s2 ? p.s2[col] : 1.0f;
         const float b2 = p.s2 ? p.b2[col] : 0.0f;
+        float res[MI][4];   // R first (see gemm_small_kernel)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * (BM / WM) + i * 16 + row_l + r;
+                res[i][r] = (p.R && row < p.M) ? epilogue_residual(p, row, col) : 0.0f;
+            }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (BM / WM) + i * 16 + row_l + r;
-                if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value(p, acc[i][j][r], row, col, s1, b1, s2, b2);
+                if (row < p.M) p.C[(long)row * p.ldc + col] = epilogue_value_r(p, acc[i][j][r], row, col, s1, b1, s2, b2, res[i][r]);
             }
         }
     }
@@ -655,11 +669,20 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
         float q0 = 0.0f, q1 = 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // the tile's 16 values of R first: R may be C itself (accumulation), so the compiler has to keep every load behind
+            // the stores before it, and loads left between the stores become 16 dependent round trips
+            // (19200 x 256 x 256 with R: 28.3 us against 18.9 us without)
+            float res[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                res[e] = (p.R && row < p.M) ? epilogue_residual(p, row, col) : 0.0f;
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row < p.M) {
-                    const float v = epilogue_value(p, acc[i][j][e], row, col, s1, b1, s2, b2);
+                    const float v = epilogue_value_r(p, acc[i][j][e], row, col, s1, b1, s2, b2, res[e]);
                     p.C[(long)row * p.ldc + col] = v;
                     const float d = v - k0;
                     q0 += d;

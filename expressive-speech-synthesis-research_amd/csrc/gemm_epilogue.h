@@ -2,19 +2,27 @@
 #pragma once
 #include "common.h"
 
-__device__ __forceinline__ float epilogue_value(const estts_gemm_args& p, float acc, int row, int col, float s1,
-                                                float b1, float s2, float b2) {
+// `res`: the value of R for this element, loaded by the caller (ignored when there is no R)
+__device__ __forceinline__ float epilogue_value_r(const estts_gemm_args& p, float acc, int row, int col, float s1,
+                                                  float b1, float s2, float b2, float res) {
     float v = acc * s1 + b1;
     v = apply_act(v, p.act);
     if (p.drop_rate > 0.0f)
         v = dropout_keep(p.drop_seed, p.drop_site, (uint32_t)(p.drop_row0 + row), (uint32_t)col, p.drop_rate) ? v / (1.0f - p.drop_rate) : 0.0f;
     v *= p.alpha;
-    if (p.R) {
-        const int rr = p.r_mod > 0 ? row % p.r_mod : row;
-        v += p.R[(long)rr * p.ldr + col];
-    }
+    if (p.R) v += res;
     if (p.s2) v = v * s2 + b2;
     return v;
+}
+
+__device__ __forceinline__ float epilogue_residual(const estts_gemm_args& p, int row, int col) {
+    const int rr = p.r_mod > 0 ? row % p.r_mod : row;
+    return p.R[(long)rr * p.ldr + col];
+}
+
+__device__ __forceinline__ float epilogue_value(const estts_gemm_args& p, float acc, int row, int col, float s1,
+                                                float b1, float s2, float b2) {
+    return epilogue_value_r(p, acc, row, col, s1, b1, s2, b2, p.R ? epilogue_residual(p, row, col) : 0.0f);
 }
 
 
