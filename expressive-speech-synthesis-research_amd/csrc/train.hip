@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* s0, const
                                                           float eps, float momentum, float mv_scale, const float* gamma,
                                                           const float* beta,
                                                           float* moving_mean, float* moving_var, float* mean, float* rstd,
-                                                          float* scale, float* shift, float* slots, long slot_stride) {
+                                                          float* scale, float* shift, float* slots, long slot_stride,
+                                                          float* about_next) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float t0 = s0[c], t1 = s1[c];
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* s0, const
     const float var = fmaxf(t1 / (float)M - a * a, 0.0f);
     const float rs = rsqrtf(var + eps);
     mean[c] = mu;
+    if (about_next) about_next[c] = mu;   // (may be z0 itself: read above, by this thread alone)
     rstd[c] = rs;
     const float sc = gamma[c] * rs;
     scale[c] = sc;
@@ -1107,7 +1109,8 @@ extern "C" int estts_bn_finalize(const float* s0, const float* s1, const float* 
     ESTTS_CHECK_ARG(s0 && s1 && z0 && gamma && beta && mean && rstd && scale && shift && M > 0 && C > 0, "estts_bn_finalize: bad arguments");
     ESTTS_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "estts_bn_finalize: moving statistics go together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s0, s1, z0, M, C, eps, momentum,
-                       moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, (float*)nullptr, 0L);
+                       moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, (float*)nullptr, 0L,
+                       (float*)nullptr);
     ESTTS_CHECK_LAUNCH("estts_bn_finalize");
     return 0;
 }
@@ -1115,13 +1118,13 @@ extern "C" int estts_bn_finalize(const float* s0, const float* s1, const float* 
 extern "C" int estts_bn_finalize_slots(float* slots, int64_t slot_stride, const float* z0, int32_t M, int32_t C, float eps,
                                        float momentum, float moving_var_scale, const float* gamma, const float* beta,
                                        float* moving_mean, float* moving_var, float* mean, float* rstd, float* scale,
-                                       float* shift, void* stream) {
+                                       float* shift, float* about_next, void* stream) {
     ESTTS_CHECK_ARG(slots && z0 && gamma && beta && mean && rstd && scale && shift && M > 0 && C > 0, "estts_bn_finalize_slots: bad arguments");
     ESTTS_CHECK_ARG(slot_stride == ((int64_t)(C + 255) / 256) * 256, "estts_bn_finalize_slots: slot_stride must be C rounded up to 256");
     ESTTS_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "estts_bn_finalize_slots: moving statistics go together");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, slots, slots, z0, M, C, eps,
                        momentum, moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, slots,
-                       (long)slot_stride);
+                       (long)slot_stride, about_next);
     ESTTS_CHECK_LAUNCH("estts_bn_finalize_slots");
     return 0;
 }

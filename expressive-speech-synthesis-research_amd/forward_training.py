@@ -413,10 +413,11 @@ class ForwardTransformerTrainer:
 
     def _bn_train(self, z, norm, M, C, summed=None):
         """Batch statistics of z [M, C] -> (mean, rstd, scale, shift); updates the moving statistics (momentum 0.99).
-        summed: the (pointer, stride) the layer's own launch already left the moments in, taken about the moving mean
+        summed: the (pointer, stride) the layer's own launch already left the moments in, taken about _bn_shift(norm)
         (_stat_request); otherwise a reduction pass over z builds them.  Either way the sums stay spread over their 16 copies
         until estts_bn_finalize_slots adds them up."""
         st = self._empty(4, C)
+        about_next = None
         if summed is None and not (self.fold_sums and C <= T.SumSlots.MAX_C):
             sums = self.store.zeros(2, C)
             T.colreduce(0, sums[0], sums[1], z=z, M=M, C=C)
@@ -425,18 +426,28 @@ class ForwardTransformerTrainer:
         if summed is None:
             summed, about = T.colreduce(0, z=z, M=M, C=C, shift=z[0], defer=True), z
         else:
-            about = norm.mm
-        T.bn_finalize(None, None, about, M, C, norm.gamma, norm.beta, norm.mm, norm.mv, st[0], st[1], st[2], st[3], slots=summed)
+            about = about_next = self._bn_shift(norm, C)
+        T.bn_finalize(None, None, about, M, C, norm.gamma, norm.beta, norm.mm, norm.mv, st[0], st[1], st[2], st[3], slots=summed,
+                      about_next=about_next)
         return st
 
+    def _bn_shift(self, norm, C):
+        """The vector the layer's launch takes the moments of its output about: the batch mean of the layer's previous step
+        (zero before the first), kept per normalisation layer.  Any shift is exact in exact arithmetic; one within a few
+        deviations of the mean keeps E[(x - k)^2] - E[x - k]^2 from cancelling in float32."""
+        shifts = self.__dict__.setdefault('_bn_shifts', {})
+        k = shifts.get(id(norm))
+        if k is None:
+            k = shifts[id(norm)] = torch.zeros(C, dtype=torch.float32, device=self.device)
+        return k
+
     def _stat_request(self, z, norm, C):
-        """(gemm keyword arguments, slots) that make the layer's own launch sum the moments of its output z for `norm`: about
-        the moving mean, an estimate of the batch mean that is known before the launch (the shift only conditions the
-        variance's subtraction; any value is exact in exact arithmetic)."""
+        """(gemm keyword arguments, slots) that make the layer's own launch sum the moments of its output z for `norm`, about
+        the batch mean of the previous step (_bn_shift)."""
         if not (self._bn_batch and self.fold_sums) or C > T.SumSlots.MAX_C:
             return {}, None
         ptr, stride = T.SumSlots.on(z.device).forward_region(C)
-        return {'stats': (ptr, norm.mm)}, (ptr, stride)
+        return {'stats': (ptr, self._bn_shift(norm, C))}, (ptr, stride)
 
     def _bn_eval(self, norm, C):
         """(mean, rstd, scale, shift) of a BatchNormalization layer in inference mode: its moving statistics, left untouched

@@ -237,13 +237,15 @@ def colreduce(mode, out0=None, out1=None, z=None, g=None, a=None, act=None, mean
 
 
 def bn_finalize(s0, s1, z, M, C, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, eps=1e-3, momentum=0.99,
-                moving_var_scale=1.0, slots=None):
+                moving_var_scale=1.0, slots=None, about_next=None):
     """slots = (pointer, stride) of deferred sums (colreduce(0, defer=True) or gemm(stats=...)): s0 / s1 are then ignored and
-    z is the [C] vector (or matrix whose row 0) the moments were taken about."""
+    z is the [C] vector (or matrix whose row 0) the moments were taken about; about_next [C] also receives the batch mean (the
+    shift of the layer's next step; may be z)."""
     if slots is not None:
         check(_lib.load().estts_bn_finalize_slots(slots[0], slots[1], z.data_ptr(), M, C, eps, momentum, moving_var_scale,
                                                   gamma.data_ptr(), beta.data_ptr(), _ptr(moving_mean), _ptr(moving_var),
-                                                  mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()),
+                                                  mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                  _ptr(about_next), _stream()),
               'estts_bn_finalize_slots')
         return
     check(_lib.load().estts_bn_finalize(s0.data_ptr(), s1.data_ptr(), z.data_ptr(), M, C, eps, momentum, moving_var_scale, gamma.data_ptr(),

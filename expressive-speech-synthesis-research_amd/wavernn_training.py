@@ -355,22 +355,24 @@ class WaveRNNTrainer:
 
     # ------------------------------------------------------------------ pieces of the step
     def _bn_gemm(self, x, conv, bn, z):
-        """z = conv(x) with the moments of z summed by the same call (about the moving mean, which is known beforehand); returns
-        the statistics of _bn_train."""
+        """z = conv(x) with the moments of z summed by the same call, about the batch mean of the layer's previous step (zero
+        before the first); returns the statistics of _bn_train."""
         C = conv.lin.fwd.N
+        if not hasattr(bn, 'shift_est'):
+            bn.shift_est = torch.zeros(C, dtype=torch.float32, device=self.device)
         ptr, stride = T_.SumSlots.on(self.device).forward_region(C)
-        ops.gemm(x, conv.lin.fwd, z, precision=self.precision, stats=(ptr, bn.mm))
+        ops.gemm(x, conv.lin.fwd, z, precision=self.precision, stats=(ptr, bn.shift_est))
         return self._bn_train(z, bn, z.shape[0], C, summed=(ptr, stride))
 
     def _bn_train(self, z, bn, M, C, summed=None):
         """(mean, rstd, scale, shift) from batch statistics; moving statistics updated (torch.nn.BatchNorm1d: momentum 0.1,
-        unbiased moving variance).  summed: (pointer, stride) of moments already taken about the moving mean."""
+        unbiased moving variance).  summed: (pointer, stride) of moments already taken about bn.shift_est."""
         st = torch.empty(4, C, dtype=torch.float32, device=self.device)
-        about = bn.mm
+        about = about_next = getattr(bn, 'shift_est', None)
         if summed is None:
-            summed, about = T_.colreduce(0, z=z, M=M, C=C, shift=z[0], defer=True), z
+            summed, about, about_next = T_.colreduce(0, z=z, M=M, C=C, shift=z[0], defer=True), z, None
         T_.bn_finalize(None, None, about, M, C, bn.gamma, bn.beta, bn.mm, bn.mv, st[0], st[1], st[2], st[3], eps=1e-5,
-                       momentum=0.9, moving_var_scale=M / max(M - 1, 1), slots=summed)
+                       momentum=0.9, moving_var_scale=M / max(M - 1, 1), slots=summed, about_next=about_next)
         return st
 
     def _lin_bwd(self, x, L, dy, M, dx=None, residual=None):

@@ -563,10 +563,12 @@ int estts_bn_finalize(const float* s0, const float* s1, const float* z0, int32_t
 /* The same from sums still spread over 16 copies (estts_colreduce with defer, or estts_gemm with stat_slots): copy k of
  * s0 / s1 for column c is slots[(2 k + 0 / 1) * slot_stride + c], slot_stride = ceil(C / 256) * 256.  Adds the copies up and
  * sets them to zero.  z0 [C]: what the moments were taken about (row 0 of the matrix, or the shift vector); it may be
- * moving_mean itself (read before it is updated). */
+ * moving_mean itself (read before it is updated).  about_next [C] (or NULL) also receives the batch mean: the shift for the
+ * same layer's next step (the closer the shift to the mean, the less the variance loses in its subtraction); it may be z0. */
 int estts_bn_finalize_slots(float* slots, int64_t slot_stride, const float* z0, int32_t M, int32_t C, float eps, float momentum,
                             float moving_var_scale, const float* gamma, const float* beta, float* moving_mean,
-                            float* moving_var, float* mean, float* rstd, float* scale, float* shift, void* stream);
+                            float* moving_var, float* mean, float* rstd, float* scale, float* shift, float* about_next,
+                            void* stream);
 
 /* out[m, c] = act(z[m, c] * scale[c] + shift[c]) + (R ? R[r_mod ? m % r_mod : m, c] : 0)   (scale / shift NULL = 1 / 0) */
 int estts_affine_act(const float* z, int32_t ldz, const float* scale, const float* shift, int32_t act, const float* R,

@@ -342,6 +342,28 @@ def test_batchnorm_with_deferred_sums_matches_the_two_launch_path(T, sizes):
     assert float(slots.buf[slots.turn].abs().max()) == 0.0  # the region the next reduction writes is clear
 
 
+def test_batch_mean_of_the_previous_step_conditions_the_variance(T):
+    """bn_finalize(about_next=k) hands the batch mean to the next step's moments: with a mean 300 deviations off zero the first
+    step (k = 0) loses digits of the variance in float32, the second (k = previous mean) does not."""
+    rng = np.random.default_rng(5)
+    M, C = 20000, 256
+    gamma, beta = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+    k = torch.zeros(C, device='cuda')
+    errs = []
+    offs = rng.normal(0, 5, size=C)          # the channel means drift little from step to step
+    for step in range(2):
+        z = rng.normal(300.0, 1.0, size=(M, C)) + offs + 0.05 * step
+        zd = dev(z)
+        sl = T.colreduce(0, z=zd, shift=k, defer=True)
+        st = torch.empty(4, C, device='cuda')
+        T.bn_finalize(None, None, k, M, C, gamma, beta, torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), *st, slots=sl,
+                      about_next=k)
+        z32 = zd.double().cpu().numpy()
+        errs.append(rel_err(st[1], 1 / np.sqrt(z32.var(0) + 1e-3)))
+        assert rel_err(k, z32.mean(0)) < 1e-6
+    assert errs[1] < 1e-5 and errs[0] > 10 * errs[1], errs
+
+
 @pytest.mark.parametrize('M,N,K,taps', [(19200, 256, 768, 3), (4096, 512, 256, 1), (300, 80, 256, 1), (1000, 384, 640, 5)])
 def test_gemm_sums_the_moments_of_its_output(T, M, N, K, taps):
     """estts_gemm with stat_slots (large-M tiles: inside the epilogue; other kernels: a reduction pass behind the product) ->
