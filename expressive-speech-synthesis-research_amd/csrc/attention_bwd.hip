@@ -264,8 +264,13 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const estts_attentio
 // tile is fetched from L2 and split once per 64 owned rows instead of once per 16: at batch 32 the kernel above is bound
 // by exactly that traffic.  Every wave keeps the whole sum of its own rows, so nothing is merged at the end.  The weights
 // and delta of the next tile are fetched together with its rows, one tile ahead of their use.
+// workgroups per CU the register budget must allow (depth 64, split operands: the dQ pass compiles to 132 registers and the
+// dK / dV pass to 176 left alone, each one step above an occupancy threshold)
 template <int DH, int NS, bool OWN_Q>
-__global__ __launch_bounds__(256) void attention_bwd_wide_kernel(const estts_attention_bwd_args p) {
+constexpr int bwd_wide_occupancy() { return (DH == 64 && NS == 2) ? (OWN_Q ? 4 : 3) : 1; }
+
+template <int DH, int NS, bool OWN_Q>
+__global__ __launch_bounds__(256, (bwd_wide_occupancy<DH, NS, OWN_Q>())) void attention_bwd_wide_kernel(const estts_attention_bwd_args p) {
     constexpr int KS = DH / 32;
     constexpr int NT = DH / 16;
     constexpr int LD = DH + 8;
