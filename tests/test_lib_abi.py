@@ -56,3 +56,33 @@ def test_struct_sizes_match_header_layout(tmp_path):
     for name, cls in pairs.items():
         assert ctypes.sizeof(cls) == int(sizes[name]), name
     assert ctypes.sizeof(_lib.GemmArgs) == 352
+
+
+def test_deferred_sum_arguments_are_validated_before_any_launch():
+    """The argument checks of the BatchNorm sum entry points run before any HIP call (fake, never dereferenced pointers)."""
+    lib = _lib.load()
+    fake = 0x1000
+
+    def err():
+        return lib.estts_last_error().decode()
+
+    c = _lib.ColreduceArgs()
+    c.z, c.ldz, c.M, c.C, c.mode, c.defer = fake, 256, 64, 256, 0, 1            # defer without a workspace
+    assert lib.estts_colreduce(c, None) != 0 and 'defer needs ws' in err()
+    c.ws, c.ws_bytes = fake, 16 * 2 * 256 * 4 - 4                               # ... or with one that is too small
+    assert lib.estts_colreduce(c, None) != 0 and 'defer needs ws' in err()
+    c.ws_bytes, c.mode, c.g, c.ldg = 16 * 2 * 256 * 4, 1, fake, 256             # defer is for modes 0 and 2
+    assert lib.estts_colreduce(c, None) != 0 and 'modes 0 and 2' in err()
+    c.mode, c.clear, c.clear_floats = 0, fake + 64, 1024                        # the region to clear overlaps the sums
+    assert lib.estts_colreduce(c, None) != 0 and 'overlap' in err()
+
+    args = [fake, 512, fake, 64, 256, 1e-3, 0.99, 1.0] + [fake] * 9 + [None]     # stride 512 for 256 columns
+    assert lib.estts_bn_finalize_slots(*args) != 0 and 'slot_stride' in err()
+    args = [fake, 256, fake, 256, fake, fake, fake, fake, 512, fake, fake, fake, 256, 64, 256, None]
+    assert lib.estts_bn_bwd_slots(*args) != 0 and 'slot_stride' in err()
+
+    g = _lib.GemmArgs()
+    g.A, g.lda, g.taps, g.c_per_tap, g.W_hi, g.W_lo, g.ldw = fake, 64, 1, 64, fake, fake, 64
+    g.M, g.N, g.K, g.C, g.ldc, g.precision, g.alpha = 19200, 256, 64, fake, 256, 3, 1.0
+    g.stat_slots, g.batch = fake, 2
+    assert lib.estts_gemm(g, None) != 0 and 'stat_slots' in err()
