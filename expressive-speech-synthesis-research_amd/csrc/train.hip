@@ -506,23 +506,44 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
     float acc_db = 0.f;
     const float keep = f.drop_rate > 0.f ? 1.0f / (1.0f - f.drop_rate) : 1.0f;
 
+    // the LayerNorm parameters of this lane's columns stay in registers for all rows
+    float4 p_ga[NCH], p_ba[NCH], p_gb[NCH], p_bb[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        p_ga[i] = p_ba[i] = p_gb[i] = p_bb[i] = zero;
+        if (lane + 64 * i < dq) {
+            const int c = (lane + 64 * i) * 4;
+            if (f.ga) { p_ga[i] = ld4(f.ga + c); p_ba[i] = ld4(f.ba + c); }
+            if (f.gb) { p_gb[i] = ld4(f.gb + c); p_bb[i] = ld4(f.bb + c); }
+        }
+    }
+
     for (int row = blockIdx.x * 4 + wave; row < f.M; row += gridDim.x * 4) {
         float4 xh1[NCH], r[NCH], xh2[NCH], d[NCH];
         float rstd1 = 1.f, rstd2 = 1.f;
-        // ---- recompute the forward pass
+        // every operand of the row is requested here, before the first reduction waits for one of them: left where they are
+        // used, the loads of x, dout and the old dx each start only after the wave reductions before them (three to four
+        // dependent round trips per row)
+        float4 x_in[NCH], dx_old[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            xh1[i] = r[i] = xh2[i] = d[i] = zero;
-            if (lane + 64 * i < dq) r[i] = ld4(f.y + (long)row * f.ldy + (lane + 64 * i) * 4);
+            xh1[i] = r[i] = xh2[i] = d[i] = x_in[i] = dx_old[i] = zero;
+            if (lane + 64 * i < dq) {
+                const int c = (lane + 64 * i) * 4;
+                r[i] = ld4(f.y + (long)row * f.ldy + c);
+                if (f.x) x_in[i] = ld4(f.x + (long)row * f.ldx + c);
+                if (p.dout) d[i] = ld4(p.dout + (long)row * p.lddout + c);
+                if (p.dx && p.dx_accumulate) dx_old[i] = ld4(p.dx + (long)row * p.lddx + c);
+            }
         }
+        // ---- recompute the forward pass
         if (f.ga) {
             const RowStats s = row_stats<NCH>(r, lane, dq, f.D, f.eps);
             rstd1 = s.rstd;
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
                 if (lane + 64 * i < dq) {
-                    const int c = (lane + 64 * i) * 4;
-                    const float4 ga = ld4(f.ga + c), ba = ld4(f.ba + c);
+                    const float4 ga = p_ga[i], ba = p_ba[i];
                     F4_OP(xh1[i], (f4e(r[i], e) - s.mean) * s.rstd);
                     F4_OP(r[i], f4e(xh1[i], e) * f4e(ga, e) + f4e(ba, e));
                 }
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
                 if (f.drop_rate > 0.f) F4_OP(km[i], dropout_keep(f.drop_seed, f.drop_site, row, c + e, f.drop_rate) ? keep : 0.0f);
                 F4_OP(xh2[i], f4e(r[i], e) * f4e(km[i], e));
                 if (f.x) {
-                    const float4 x = ld4(f.x + (long)row * f.ldx + c);
+                    const float4 x = x_in[i];
                     F4_OP(xh2[i], f4e(xh2[i], e) + f4e(x, e));
                 }
             }
@@ -552,16 +573,12 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
                 if (lane + 64 * i < dq) {
-                    const int c = (lane + 64 * i) * 4;
-                    const float4 gb = ld4(f.gb + c), bb = ld4(f.bb + c);
+                    const float4 gb = p_gb[i], bb = p_bb[i];
                     F4_OP(xh2[i], (f4e(xh2[i], e) - s.mean) * s.rstd);
                     F4_OP(out[i], f4e(xh2[i], e) * f4e(gb, e) + f4e(bb, e));
                 }
         }
-        // ---- gradient w.r.t. out
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            if (p.dout && lane + 64 * i < dq) d[i] = ld4(p.dout + (long)row * p.lddout + (lane + 64 * i) * 4);
+        // ---- gradient w.r.t. out (d holds dout already)
         if (p.ddot) {
             float dot = 0.f;
 #pragma unroll
@@ -587,7 +604,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
                 if (lane + 64 * i < dq) {
-                    const float4 gb = ld4(f.gb + (lane + 64 * i) * 4);
+                    const float4 gb = p_gb[i];
                     F4_OP(acc_gb[i], f4e(acc_gb[i], e) + f4e(d[i], e) * f4e(xh2[i], e));
                     F4_OP(acc_bb[i], f4e(acc_bb[i], e) + f4e(d[i], e));
                     F4_OP(d[i], f4e(d[i], e) * f4e(gb, e));
@@ -602,7 +619,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
                 if (p.dx) {
                     float4 o = d[i];
                     if (p.dx_accumulate) {
-                        const float4 old = ld4(p.dx + (long)row * p.lddx + c);
+                        const float4 old = dx_old[i];
                         o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
                     }
                     st4(p.dx + (long)row * p.lddx + c, o);
@@ -614,7 +631,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const estts_rownorm_bw
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
                 if (lane + 64 * i < dq) {
-                    const float4 ga = ld4(f.ga + (lane + 64 * i) * 4);
+                    const float4 ga = p_ga[i];
                     F4_OP(acc_ga[i], f4e(acc_ga[i], e) + f4e(d[i], e) * f4e(xh1[i], e));
                     F4_OP(acc_ba[i], f4e(acc_ba[i], e) + f4e(d[i], e));
                     F4_OP(d[i], f4e(d[i], e) * f4e(ga, e));
