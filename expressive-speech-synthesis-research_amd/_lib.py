@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -98,6 +98,14 @@ class ColreduceArgs(C.Structure):
                 ('defer', _i32), ('clear', _vp), ('clear_floats', _i64)]
 
 
+class GruFusedArgs(C.Structure):
+    _fields_ = [('gi', _vp), ('ldgi', _i32), ('gh', _vp), ('ldgh', _i32), ('h_prev', _vp), ('ldhp', _i32),
+                ('W_hi', _vp), ('W_lo', _vp), ('ldw', _i32), ('bias', _vp), ('h_out', _vp), ('ldho', _i32),
+                ('x_res', _vp), ('ldx', _i32), ('out', _vp), ('ldo', _i32), ('dgh_next', _vp), ('lddghn', _i32),
+                ('dh', _vp), ('lddh', _i32), ('dgi', _vp), ('lddgi', _i32), ('dgh', _vp), ('lddgh', _i32),
+                ('dhd', _vp), ('lddhd', _i32), ('M', _i32), ('H', _i32), ('precision', _i32)]
+
+
 class WavernnPrepArgs(C.Structure):
     _fields_ = [('mel', _vp), ('mel_off', _vp), ('aux', _vp), ('aux_off', _vp), ('fir', _vp), ('ntaps', _i32),
                 ('fir_kmin', _i32), ('seq_utt', _vp), ('seq_start', _vp), ('utt_samples', _vp), ('x_prev', _vp),
@@ -162,6 +170,8 @@ SIGNATURES = {
     'estts_bn_finalize': (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'estts_affine_act': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     'estts_bn_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    'estts_gru_fused_fwd': (_i32, [C.POINTER(GruFusedArgs), _vp]),
+    'estts_gru_fused_bwd': (_i32, [C.POINTER(GruFusedArgs), _vp]),
     'estts_bn_finalize_slots': (_i32, [_vp, _i64, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'estts_bn_bwd_slots': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'estts_dropout': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _u32, _u32, _vp]),

@@ -356,6 +356,43 @@ def gru_step_bwd(gi, gh, h_prev, dh, dh_rec, dgi, dgh, dh_prev):
           'estts_gru_step_bwd')
 
 
+def _gru_fused_common(gi, gh, h_prev, lin, precision):
+    a = _lib.GruFusedArgs()
+    a.gi, a.ldgi, a.gh, a.ldgh = gi.data_ptr(), gi.stride(0), gh.data_ptr(), gh.stride(0)
+    a.h_prev, a.ldhp = h_prev.data_ptr(), h_prev.stride(0)
+    a.W_hi, a.W_lo, a.ldw = lin.w_hi.data_ptr(), lin.w_lo.data_ptr(), lin.ldw
+    a.M, a.H = h_prev.shape
+    a.precision = PRECISION[precision]
+    return a
+
+
+def gru_fused_fwd(gi, gh, h_prev, lin, h_out, x_res=None, out=None, precision='bf16x3'):
+    """One GRU step forward in one launch: gh = h_prev (*) lin (W_hh packed for estts_gemm, its bias included), gates, h_out
+    (and out = h_out + x_res); see estts_gru_fused_fwd."""
+    a = _gru_fused_common(gi, gh, h_prev, lin, precision)
+    if (lin.N, lin.K) != (3 * a.H, a.H) or lin.s1 is not None:
+        raise ValueError('gru_fused_fwd: the weight must be W_hh [3H x H] without an output scale')
+    a.bias = _ptr(lin.b1)
+    a.h_out, a.ldho = h_out.data_ptr(), h_out.stride(0)
+    if x_res is not None:
+        a.x_res, a.ldx = x_res.data_ptr(), x_res.stride(0)
+    if out is not None:
+        a.out, a.ldo = out.data_ptr(), out.stride(0)
+    check(_lib.load().estts_gru_fused_fwd(a, _stream()), 'estts_gru_fused_fwd')
+
+
+def gru_fused_bwd(gi, gh, h_prev, dh, dgh_next, lin_bwd, dgi, dgh, dhd, precision='bf16x3'):
+    """The hidden-state gradient reaching a step from the next one (dgh_next (*) lin_bwd + dhd) and the step's gate gradients in
+    one launch; see estts_gru_fused_bwd."""
+    a = _gru_fused_common(gi, gh, h_prev, lin_bwd, precision)
+    if (lin_bwd.N, lin_bwd.K) != (a.H, 3 * a.H) or lin_bwd.s1 is not None or lin_bwd.b1 is not None:
+        raise ValueError('gru_fused_bwd: the weight must be the transposed pack [H x 3H] of W_hh without scale or bias')
+    a.dgh_next, a.lddghn, a.dh, a.lddh = dgh_next.data_ptr(), dgh_next.stride(0), dh.data_ptr(), dh.stride(0)
+    a.dgi, a.lddgi, a.dgh, a.lddgh = dgi.data_ptr(), dgi.stride(0), dgh.data_ptr(), dgh.stride(0)
+    a.dhd, a.lddhd = dhd.data_ptr(), dhd.stride(0)
+    check(_lib.load().estts_gru_fused_bwd(a, _stream()), 'estts_gru_fused_bwd')
+
+
 def wavernn_prep_bwd(dxin, da2, da3, da4, mel, mel_off, d_aux, dfir, fir_kmin, n_utt, frames, feat, d, hop, pad):
     a = _lib.WavernnPrepBwdArgs()
     a.dxin, a.ld_dxin = dxin.data_ptr(), dxin.stride(0)

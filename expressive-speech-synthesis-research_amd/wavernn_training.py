@@ -66,6 +66,9 @@ class WaveRNNTrainer:
         self.hop_length, self.sample_rate = hop_length, sample_rate
         self.device = torch.device(device)
         self.precision = precision
+        # a recurrent step as ONE launch (product + gates, estts_gru_fused_fwd / _bwd) instead of two; False: estts_gemm followed
+        # by estts_gru_step_fwd / _bwd (for comparisons)
+        self.fused_gru = True
         self.use_graph = use_graph
         self.step = 0
         self.lr, self.beta1, self.beta2, self.eps = 1e-4, 0.9, 0.999, 1e-8      # torch.optim.Adam defaults, hp.voc_lr
@@ -291,6 +294,10 @@ class WaveRNNTrainer:
         xr3, out3 = x_res.view(B, T, -1), out.view(B, T, -1)
         for t in range(t0, T if t1 is None else t1):
             hp = ws['h0'] if t == 0 else H3[:, t - 1]
+            if self.fused_gru:       # the recurrent product with the gates as its epilogue: one launch per step
+                T_.gru_fused_fwd(gi3[:, t], gh3[:, t], hp, hh.lin.fwd, H3[:, t], x_res=xr3[:, t, :out_cols],
+                                 out=out3[:, t, :out_cols], precision=self.precision)
+                continue
             ops.gemm(hp, hh.lin.fwd, gh3[:, t], precision=self.precision, workspace=gemm_ws)
             T_.gru_step_fwd(gi3[:, t], gh3[:, t], hp, H3[:, t], x_res=xr3[:, t, :out_cols], out=out3[:, t, :out_cols])
 
@@ -301,7 +308,21 @@ class WaveRNNTrainer:
         gi3, gh3, H3 = gi.view(B, T, 3 * R), gh.view(B, T, 3 * R), H.view(B, T, R)
         dgi3, dgh3 = dgi.view(B, T, 3 * R), dgh.view(B, T, 3 * R)
         do3 = dout.view(B, T, -1)
-        for t in range((T if t_hi is None else t_hi) - 1, t_lo - 1, -1):
+        t_hi = T if t_hi is None else t_hi
+        if self.fused_gru:
+            # one launch per step: the product that carries the state gradient from step t to step t - 1 has the gate
+            # gradients of step t - 1 as its epilogue.  Steps t_hi - 1 .. t_lo are therefore the launches t = t_hi .. t_lo + 1
+            # (each reads dout of step t - 1 only, which may not exist yet below t_lo); the last step of the window has no
+            # successor: its gate gradients come from the plain kernel
+            if t_hi == T:
+                hp = ws['h0'] if T == 1 else H3[:, T - 2]
+                T_.gru_step_bwd(gi3[:, T - 1], gh3[:, T - 1], hp, do3[:, T - 1, :R], None, dgi3[:, T - 1], dgh3[:, T - 1], dhd)
+            for t in range(min(t_hi, T - 1), t_lo, -1):
+                hp = ws['h0'] if t == 1 else H3[:, t - 2]
+                T_.gru_fused_bwd(gi3[:, t - 1], gh3[:, t - 1], hp, do3[:, t - 1, :R], dgh3[:, t], hh.lin.bwd, dgi3[:, t - 1],
+                                 dgh3[:, t - 1], dhd, precision=self.precision)
+            return
+        for t in range(t_hi - 1, t_lo - 1, -1):
             hp = ws['h0'] if t == 0 else H3[:, t - 1]
             T_.gru_step_bwd(gi3[:, t], gh3[:, t], hp, do3[:, t, :R], None if t == T - 1 else dhr, dgi3[:, t], dgh3[:, t], dhd)
             if t > 0:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 29
+#define ESTTS_ABI_VERSION 30
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -672,6 +672,39 @@ int estts_gru_step_fwd(const float* gi, int32_t ldgi, const float* gh, int32_t l
 int estts_gru_step_bwd(const float* gi, int32_t ldgi, const float* gh, int32_t ldgh, const float* h_prev, int32_t ldhp,
                        const float* dh, int32_t lddh, const float* dh_rec, int32_t lddhr, float* dgi, int32_t lddgi,
                        float* dgh, int32_t lddgh, float* dh_prev, int32_t lddhp, int32_t M, int32_t H, void* stream);
+
+/* One GRU time step of a training recurrence in a single launch: the recurrent product with the gate arithmetic as its
+ * epilogue (torch.nn.GRU gate order r, z, n: WaveRNN/models/fatchord_version.py:117-125, and the GST reference encoder's GRU,
+ * TransformerTTS/model/layers.py:437-451).  A recurrence is a chain of dependent launches that costs per launch, so one launch
+ * per step instead of two (estts_gemm + estts_gru_step_fwd / _bwd) shortens the chain by about 40 %.
+ *   estts_gru_fused_fwd:  gh = h_prev W_hh^T + bias;  r = s(gi_r + gh_r);  z = s(gi_z + gh_z);  n = tanh(gi_n + r gh_n);
+ *                         h_out = (1 - z) n + z h_prev;  out = h_out (+ x_res) when out != NULL.  gh [M, 3H] is stored (the
+ *                         backward pass recomputes the gates from gi and gh).  W: W_hh [3H x H] packed as an estts_gemm weight.
+ *   estts_gru_fused_bwd:  d = dh + dgh_next W + dhd  (the gradient of step t's state: from above, through the gates of step
+ *                         t + 1, and through its z path), then the gate gradients of step t exactly as estts_gru_step_bwd:
+ *                         dgi, dgh [M, 3H] and dhd <- d z (same buffer: read, then overwritten).  W: the transposed pack
+ *                         [H x 3H] (the weight estts_gemm uses for the data gradient).  gi, gh, h_prev, dh: step t's.
+ * H a multiple of 16, H <= 1536 forward / 3H <= 1536 backward; h_out != h_prev and dgh != dgh_next (other workgroups of the
+ * launch still read them). */
+typedef struct estts_gru_fused_args {
+    const float* gi; int32_t ldgi;
+    float* gh; int32_t ldgh;
+    const float* h_prev; int32_t ldhp;
+    const uint16_t* W_hi; const uint16_t* W_lo; int32_t ldw;
+    const float* bias;
+    float* h_out; int32_t ldho;
+    const float* x_res; int32_t ldx;
+    float* out; int32_t ldo;
+    const float* dgh_next; int32_t lddghn;
+    const float* dh; int32_t lddh;
+    float* dgi; int32_t lddgi;
+    float* dgh; int32_t lddgh;
+    float* dhd; int32_t lddhd;
+    int32_t M, H, precision;
+} estts_gru_fused_args;
+
+int estts_gru_fused_fwd(const estts_gru_fused_args* args, void* stream);
+int estts_gru_fused_bwd(const estts_gru_fused_args* args, void* stream);
 
 /* Backward of estts_wavernn_prep for teacher-forced windows: every utterance has `frames` frames of `hop` samples and
  * row (u * frames + f) * hop + ph of the gradient matrices belongs to frame f, phase ph.

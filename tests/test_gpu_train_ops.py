@@ -396,6 +396,63 @@ def test_gemm_sums_the_moments_of_its_output(T, M, N, K, taps):
 
 
 
+@pytest.mark.parametrize('M,H,prec', [(32, 512, 'bf16x3'), (8, 128, 'bf16x3'), (37, 64, 'bf16x3'), (32, 512, 'bf16')])
+def test_gru_step_in_one_launch_matches_product_plus_gate_kernel(T, M, H, prec):
+    """estts_gru_fused_fwd / _bwd against estts_gemm followed by estts_gru_step_fwd / _bwd on the same operands (row strides of a
+    [B, T, .] recurrence buffer), and the forward step against float64."""
+    from estts import ops
+    rng = np.random.default_rng(M + H)
+    Tn = 3                                                        # rows are one time step of [M, Tn, .] buffers
+    w_hh = rng.normal(0, 1 / math.sqrt(H), size=(3 * H, H))
+    b_hh = rng.normal(0, 0.1, size=3 * H)
+    lin = T.TrainLinear(dev(w_hh.T.copy()), dev(b_hh))            # kernel [K = H, N = 3H]
+    gi = dev(rng.normal(size=(M, Tn, 3 * H)))
+    hs = dev(rng.normal(0, 0.5, size=(M, Tn, H)))
+    xr = dev(rng.normal(size=(M, Tn, H + 8)))
+    hp = hs[:, 0]
+    outs = []
+    for fused in (False, True):
+        gh = torch.zeros(M, Tn, 3 * H, device='cuda')
+        hn = torch.zeros(M, Tn, H, device='cuda')
+        out = torch.zeros(M, Tn, H + 8, device='cuda')
+        if fused:
+            T.gru_fused_fwd(gi[:, 1], gh[:, 1], hp, lin.fwd, hn[:, 1], x_res=xr[:, 1, :H], out=out[:, 1, :H], precision=prec)
+        else:
+            ops.gemm(hp, lin.fwd, gh[:, 1], precision=prec)
+            T.gru_step_fwd(gi[:, 1], gh[:, 1], hp, hn[:, 1], x_res=xr[:, 1, :H], out=out[:, 1, :H])
+        outs.append((gh, hn, out))
+    tol = 2e-5 if prec == 'bf16x3' else 2e-2
+    for a, b in zip(*outs):
+        assert rel_err(b, a) < tol
+    g64 = hp.double().cpu().numpy() @ w_hh.T + b_hh
+    i64 = gi[:, 1].double().cpu().numpy()
+    sg = lambda x: 1 / (1 + np.exp(-x))                           # noqa: E731
+    r, z = sg(i64[:, :H] + g64[:, :H]), sg(i64[:, H:2 * H] + g64[:, H:2 * H])
+    n = np.tanh(i64[:, 2 * H:] + r * g64[:, 2 * H:])
+    h_ref = (1 - z) * n + z * hp.double().cpu().numpy()
+    assert rel_err(outs[1][1][:, 1], h_ref) < (3e-5 if prec == 'bf16x3' else 2e-2)
+    assert float(outs[1][1][:, 0].abs().max()) == 0.0 and float(outs[1][2][:, 1, H:].abs().max()) == 0.0    # nothing beside the step
+    # backward: the state gradient from step t + 1 and the gate gradients of step t
+    gh = outs[0][0]
+    dgh_next = dev(rng.normal(0, 0.3, size=(M, Tn, 3 * H)))
+    dh = dev(rng.normal(size=(M, Tn, H + 8)))
+    dhd0 = dev(rng.normal(0, 0.3, size=(M, H)))
+    res = []
+    for fused in (False, True):
+        dgi = torch.zeros(M, Tn, 3 * H, device='cuda')
+        dgh = dgh_next.clone()
+        dhd = dhd0.clone()
+        if fused:
+            T.gru_fused_bwd(gi[:, 1], gh[:, 1], hp, dh[:, 1, :H], dgh[:, 2], lin.bwd, dgi[:, 1], dgh[:, 1], dhd, precision=prec)
+        else:
+            dhr = torch.empty(M, H, device='cuda')
+            ops.gemm(dgh[:, 2], lin.bwd, dhr, precision=prec, residual=dhd)
+            T.gru_step_bwd(gi[:, 1], gh[:, 1], hp, dh[:, 1, :H], dhr, dgi[:, 1], dgh[:, 1], dhd)
+        res.append((dgi, dgh, dhd))
+    for a, b in zip(*res):
+        assert rel_err(b, a) < tol
+
+
 def test_expand_embed_loss_adam_axpby_headscale(T):
     from estts import ops
     rng = np.random.default_rng(5)
