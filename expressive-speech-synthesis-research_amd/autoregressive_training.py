@@ -194,6 +194,8 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
     """The reference's AutoregressiveTransformer as `train_models_step` uses it: `input_reshape`, `train_step` (forward,
     losses, gradients, optimizer), `set_constants`, `step`, `weights()`."""
 
+    fused_gru = True     # the reference encoder's GRU steps as one launch each (estts_gru_fused_fwd / _bwd); False: two
+
     def __init__(self, weights, config, device='cuda', precision='bf16x3', seed=0, process_group=None, bucket_mb=25):
         self._init_common(config, device, precision, seed, process_group, bucket_mb)
         cfg, dev = self.config, self.device
@@ -417,6 +419,9 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         hs[0].zero_()
         ghs = self._empty(steps, B, 3 * u)
         for t in range(steps):
+            if self.fused_gru:       # recurrent product + gates in one launch
+                T.gru_fused_fwd(gi3[:, t], ghs[t], hs[t], G.gru_hh.lin.fwd, hs[t + 1], precision=self.precision)
+                continue
             self._lin_fwd(hs[t], G.gru_hh, ghs[t], B)
             T.gru_step_fwd(gi3[:, t], ghs[t], hs[t], hs[t + 1])
         cat = self._empty(B, u + sd)
@@ -478,7 +483,15 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             dgh = self._empty(steps, B, 3 * u)
             zero = torch.zeros(B, u, dtype=torch.float32, device=self.device)
             rec = None
-            for t in reversed(range(steps)):
+            if self.fused_gru:
+                # the last step's gate gradients from the plain kernel; then one launch per step: the product that carries the
+                # state gradient from step t to step t - 1, with the gate gradients of step t - 1 as its epilogue
+                dhd = self._empty(B, u)
+                T.gru_step_bwd(gi3[:, steps - 1], ghs[steps - 1], hs[steps - 1], dh, None, dgi[:, steps - 1], dgh[steps - 1], dhd)
+                for t in range(steps - 1, 0, -1):
+                    T.gru_fused_bwd(gi3[:, t - 1], ghs[t - 1], hs[t - 1], zero, dgh[t], G.gru_hh.lin.bwd, dgi[:, t - 1], dgh[t - 1],
+                                    dhd, precision=self.backward_precision)
+            for t in reversed(range(steps if not self.fused_gru else 0)):
                 dprev = self._empty(B, u)
                 T.gru_step_bwd(gi3[:, t], ghs[t], hs[t], dh if t == steps - 1 else zero, rec, dgi[:, t], dgh[t], dprev)
                 ops.gemm(dgh[t], G.gru_hh.lin.bwd, dprev, M=B, precision=self.backward_precision, residual=dprev)
