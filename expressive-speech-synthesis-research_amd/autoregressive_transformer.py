@@ -93,12 +93,11 @@ class ReferenceEncoderGST:
         gi = torch.empty(B * steps, 3 * u, **f32)
         ops.gemm(seq, self.gru_ih, gi, precision=precision)
         gi3 = gi.view(B, steps, 3 * u)
-        h = torch.zeros(B, u, **f32)
+        state = (torch.zeros(B, u, **f32), torch.empty(B, u, **f32))
         gh = torch.empty(B, 3 * u, **f32)
-        hout = torch.empty(B, u, **f32)
-        for t in range(steps):
-            ops.gemm(h, self.gru_hh, gh, precision=precision)
-            ops.gru_gates(gi3[:, t], gh, h, hout)
+        for t in range(steps):       # recurrent product + gates in one launch per step; the state alternates between two buffers
+            ops.gru_step(gi3[:, t], gh, state[t & 1], self.gru_hh, state[(t + 1) & 1], precision=precision)
+        h = state[steps & 1]
         qcat = torch.empty(B, u + self.sd, **f32)
         ops.gemm(h, self.rnn_proj, qcat[:, :u], precision=precision)
         q = torch.empty(B, self.sd, **f32)

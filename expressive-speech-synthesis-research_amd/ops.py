@@ -465,6 +465,26 @@ def gru_gates(gi, gh, h, out, x_res=None, M=None, H=None):
     return out
 
 
+def gru_step(gi, gh, h_prev, lin, h_out, precision='bf16x3', site=None):
+    """One GRU step in one launch (estts_gru_fused_fwd): gh = h_prev (*) lin (W_hh [3H x H] with its bias; stored), gates in the
+    order r, z, n, h_out = the new state.  h_out must be another buffer than h_prev (other workgroups still read it)."""
+    precision = precision_at(precision, site)
+    a = _lib.GruFusedArgs()
+    a.gi, a.ldgi, a.gh, a.ldgh = gi.data_ptr(), gi.stride(0), gh.data_ptr(), gh.stride(0)
+    a.h_prev, a.ldhp = h_prev.data_ptr(), h_prev.stride(0)
+    a.W_hi, a.W_lo, a.ldw = lin.w_hi.data_ptr(), lin.w_lo.data_ptr(), lin.ldw
+    a.bias = _ptr(lin.b1)
+    a.h_out, a.ldho = h_out.data_ptr(), h_out.stride(0)
+    a.M, a.H = h_prev.shape
+    a.precision = PRECISION[precision]
+    if (lin.N, lin.K) != (3 * a.H, a.H) or lin.s1 is not None:
+        raise ValueError('gru_step: the weight must be W_hh [3H x H] without an output scale')
+    check(_lib.load().estts_gru_fused_fwd(a, _stream()), 'estts_gru_fused_fwd')
+    _record('gru_step', {'M': a.M, 'H': a.H, 'flops': 6.0 * a.M * a.H * a.H, 'bytes': 4.0 * a.M * a.H * 9 + 12.0 * a.H * a.H},
+            _lib.load().estts_gru_fused_fwd, a, keep=(gi, gh, h_prev, lin, h_out))
+    return h_out
+
+
 def row_zero_mask(x, mask, M=None, D=None):
     M = x.shape[0] if M is None else M
     D = x.shape[1] if D is None else D
