@@ -453,6 +453,8 @@ def train_wavernn_bench(args, rank, world, dist):
     B, hops = args.batch, 5
     L = hops * hp['hop_length']
     model = WaveRNNTrainer.from_hparams(hp, precision=args.precision)
+    if os.environ.get('ESTTS_BENCH_WAVERNN_CHUNK'):      # steps between hand-overs of the two overlapped recurrences (measurements)
+        model.CHUNK = int(os.environ['ESTTS_BENCH_WAVERNN_CHUNK'])
     w = weights.init_wavernn(hp, seed=1234)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
     rng = np.random.default_rng(7 + rank)
