@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -172,6 +172,8 @@ SIGNATURES = {
     'estts_bn_bwd': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'estts_gru_fused_fwd': (_i32, [C.POINTER(GruFusedArgs), _vp]),
     'estts_gru_fused_bwd': (_i32, [C.POINTER(GruFusedArgs), _vp]),
+    'estts_gru_fused_fwd2': (_i32, [C.POINTER(GruFusedArgs), C.POINTER(GruFusedArgs), _vp]),
+    'estts_gru_fused_bwd2': (_i32, [C.POINTER(GruFusedArgs), C.POINTER(GruFusedArgs), _vp]),
     'estts_bn_finalize_slots': (_i32, [_vp, _i64, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'estts_bn_bwd_slots': (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'estts_dropout': (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _u32, _u32, _vp]),

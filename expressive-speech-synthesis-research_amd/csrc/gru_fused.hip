@@ -97,14 +97,18 @@ __device__ __forceinline__ void reduce_tiles(float* red, const f32x4 (&acc)[NT],
     }
 }
 
+// blockIdx.z selects the argument block: two independent steps of the same width (the two layers of a WaveRNN window, one
+// running a chunk of steps behind the other) share a launch, so that two recurrences cost one chain of launches
 template <int NSPLIT, int S>
-__global__ __launch_bounds__(NW * 64) void gru_fused_fwd_kernel(const estts_gru_fused_args p) {
+__global__ __launch_bounds__(NW * 64) void gru_fused_fwd_kernel(const estts_gru_fused_args pa, const estts_gru_fused_args pb) {
     __shared__ float red[NW * 3 * 4 * 64];
+    const estts_gru_fused_args& p = blockIdx.z == 0 ? pa : pb;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
     const int H = p.H;
+    if (m0 >= p.M) return;   // (the other block has more rows; uniform over the workgroup)
     // epilogue operands of element (row, col) -- loaded by every wave (the last four discard them), before the product's loads
     const int row = min(m0 + 4 * g + (wave & 3), p.M - 1);
     const int col = j0 + i16;
@@ -134,13 +138,15 @@ __global__ __launch_bounds__(NW * 64) void gru_fused_fwd_kernel(const estts_gru_
 }
 
 template <int NSPLIT, int S>
-__global__ __launch_bounds__(NW * 64) void gru_fused_bwd_kernel(const estts_gru_fused_args p) {
+__global__ __launch_bounds__(NW * 64) void gru_fused_bwd_kernel(const estts_gru_fused_args pa, const estts_gru_fused_args pb) {
     __shared__ float red[NW * 4 * 64];
+    const estts_gru_fused_args& p = blockIdx.z == 0 ? pa : pb;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
     const int H = p.H;
+    if (m0 >= p.M) return;
     const int row = min(m0 + 4 * g + (wave & 3), p.M - 1);
     const int col = j0 + i16;
     const float* gi = p.gi + (long)row * p.ldgi + col;
@@ -178,14 +184,15 @@ __global__ __launch_bounds__(NW * 64) void gru_fused_bwd_kernel(const estts_gru_
 }
 
 template <int NSPLIT, bool FWD>
-int launch(const estts_gru_fused_args& a, hipStream_t st) {
+int launch(const estts_gru_fused_args& a, const estts_gru_fused_args* second, hipStream_t st) {
+    const estts_gru_fused_args& b = second ? *second : a;
     const int nks = ((FWD ? a.H : 3 * a.H) + 31) / 32;
     const int s = (nks + NW - 1) / NW;
-    dim3 grid(a.H / 16, (a.M + 15) / 16);
-#define ESTTS_GRU_CASE(SV)                                                                                     \
-    case SV:                                                                                                   \
-        if (FWD) hipLaunchKernelGGL((gru_fused_fwd_kernel<NSPLIT, SV>), grid, dim3(NW * 64), 0, st, a);      \
-        else hipLaunchKernelGGL((gru_fused_bwd_kernel<NSPLIT, SV>), grid, dim3(NW * 64), 0, st, a);          \
+    dim3 grid(a.H / 16, ((a.M > b.M ? a.M : b.M) + 15) / 16, second ? 2 : 1);
+#define ESTTS_GRU_CASE(SV)                                                                                        \
+    case SV:                                                                                                      \
+        if (FWD) hipLaunchKernelGGL((gru_fused_fwd_kernel<NSPLIT, SV>), grid, dim3(NW * 64), 0, st, a, b);      \
+        else hipLaunchKernelGGL((gru_fused_bwd_kernel<NSPLIT, SV>), grid, dim3(NW * 64), 0, st, a, b);          \
         break;
     switch (s) {
         ESTTS_GRU_CASE(1)
@@ -195,8 +202,8 @@ int launch(const estts_gru_fused_args& a, hipStream_t st) {
         ESTTS_GRU_CASE(6)
         default:
             if (s == 5) {
-                if (FWD) hipLaunchKernelGGL((gru_fused_fwd_kernel<NSPLIT, 6>), grid, dim3(NW * 64), 0, st, a);
-                else hipLaunchKernelGGL((gru_fused_bwd_kernel<NSPLIT, 6>), grid, dim3(NW * 64), 0, st, a);
+                if (FWD) hipLaunchKernelGGL((gru_fused_fwd_kernel<NSPLIT, 6>), grid, dim3(NW * 64), 0, st, a, b);
+                else hipLaunchKernelGGL((gru_fused_bwd_kernel<NSPLIT, 6>), grid, dim3(NW * 64), 0, st, a, b);
                 break;
             }
             estts_set_error("estts_gru_fused: H = %d is beyond one launch (H <= 1536 forward, 3 H <= 1536 backward)", a.H);
@@ -224,31 +231,58 @@ int check_common(const estts_gru_fused_args& a, const char* who) {
 
 }  // namespace
 
-extern "C" int estts_gru_fused_fwd(const estts_gru_fused_args* args, void* stream) {
-    ESTTS_CHECK_ARG(args != nullptr, "estts_gru_fused_fwd: null args");
-    const estts_gru_fused_args& a = *args;
+namespace {
+
+int check_fwd(const estts_gru_fused_args& a) {
     if (check_common(a, "estts_gru_fused_fwd") != 0) return -1;
     ESTTS_CHECK_ARG(a.h_out && a.ldho >= a.H && (!a.out || a.ldo >= a.H) && (!a.x_res || a.ldx >= a.H), "estts_gru_fused_fwd: h_out / out / x_res");
     ESTTS_CHECK_ARG((a.ldhp & 3) == 0 && ((uintptr_t)a.h_prev & 15) == 0, "estts_gru_fused_fwd: h_prev must be 16-byte aligned, ld a multiple of 4");
     ESTTS_CHECK_ARG(a.ldw >= ((a.H + 63) / 64) * 64 && (a.ldw & 63) == 0, "estts_gru_fused_fwd: ldw must be H rounded up to 64");
     ESTTS_CHECK_ARG(a.h_out != a.h_prev, "estts_gru_fused_fwd: h_out must not be h_prev (other workgroups still read it)");
-    const int r = a.precision == 3 ? launch<3, true>(a, (hipStream_t)stream) : launch<1, true>(a, (hipStream_t)stream);
-    if (r != 0) return r;
-    ESTTS_CHECK_LAUNCH("estts_gru_fused_fwd");
     return 0;
 }
 
-extern "C" int estts_gru_fused_bwd(const estts_gru_fused_args* args, void* stream) {
-    ESTTS_CHECK_ARG(args != nullptr, "estts_gru_fused_bwd: null args");
-    const estts_gru_fused_args& a = *args;
+int check_bwd(const estts_gru_fused_args& a) {
     if (check_common(a, "estts_gru_fused_bwd") != 0) return -1;
     ESTTS_CHECK_ARG(a.dgh_next && a.dh && a.dgi && a.dgh && a.dhd, "estts_gru_fused_bwd: null gradient pointer");
     ESTTS_CHECK_ARG(a.lddghn >= 3 * a.H && a.lddgi >= 3 * a.H && a.lddgh >= 3 * a.H && a.lddh >= a.H && a.lddhd >= a.H, "estts_gru_fused_bwd: ld too small");
     ESTTS_CHECK_ARG((a.lddghn & 3) == 0 && ((uintptr_t)a.dgh_next & 15) == 0, "estts_gru_fused_bwd: dgh_next must be 16-byte aligned, ld a multiple of 4");
     ESTTS_CHECK_ARG(a.ldw >= ((3 * a.H + 63) / 64) * 64 && (a.ldw & 63) == 0, "estts_gru_fused_bwd: ldw must be 3 H rounded up to 64");
     ESTTS_CHECK_ARG(a.dgh != a.dgh_next, "estts_gru_fused_bwd: dgh must not be dgh_next (other workgroups still read it)");
-    const int r = a.precision == 3 ? launch<3, false>(a, (hipStream_t)stream) : launch<1, false>(a, (hipStream_t)stream);
-    if (r != 0) return r;
-    ESTTS_CHECK_LAUNCH("estts_gru_fused_bwd");
     return 0;
+}
+
+template <bool FWD>
+int run(const estts_gru_fused_args* args, const estts_gru_fused_args* second, void* stream, const char* who) {
+    ESTTS_CHECK_ARG(args != nullptr, "%s: null args", who);
+    const estts_gru_fused_args& a = *args;
+    if ((FWD ? check_fwd(a) : check_bwd(a)) != 0) return -1;
+    if (second) {
+        if ((FWD ? check_fwd(*second) : check_bwd(*second)) != 0) return -1;
+        ESTTS_CHECK_ARG(second->H == a.H && second->precision == a.precision, "%s: the two steps of a launch must have the same H and precision", who);
+    }
+    const int r = a.precision == 3 ? launch<3, FWD>(a, second, (hipStream_t)stream) : launch<1, FWD>(a, second, (hipStream_t)stream);
+    if (r != 0) return r;
+    ESTTS_CHECK_LAUNCH(who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int estts_gru_fused_fwd(const estts_gru_fused_args* args, void* stream) {
+    return run<true>(args, nullptr, stream, "estts_gru_fused_fwd");
+}
+
+extern "C" int estts_gru_fused_bwd(const estts_gru_fused_args* args, void* stream) {
+    return run<false>(args, nullptr, stream, "estts_gru_fused_bwd");
+}
+
+extern "C" int estts_gru_fused_fwd2(const estts_gru_fused_args* a, const estts_gru_fused_args* b, void* stream) {
+    ESTTS_CHECK_ARG(b != nullptr, "estts_gru_fused_fwd2: null args");
+    return run<true>(a, b, stream, "estts_gru_fused_fwd2");
+}
+
+extern "C" int estts_gru_fused_bwd2(const estts_gru_fused_args* a, const estts_gru_fused_args* b, void* stream) {
+    ESTTS_CHECK_ARG(b != nullptr, "estts_gru_fused_bwd2: null args");
+    return run<false>(a, b, stream, "estts_gru_fused_bwd2");
 }

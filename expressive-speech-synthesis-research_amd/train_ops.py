@@ -366,9 +366,10 @@ def _gru_fused_common(gi, gh, h_prev, lin, precision):
     return a
 
 
-def gru_fused_fwd(gi, gh, h_prev, lin, h_out, x_res=None, out=None, precision='bf16x3'):
+def gru_fused_fwd(gi, gh, h_prev, lin, h_out, x_res=None, out=None, precision='bf16x3', launch=True):
     """One GRU step forward in one launch: gh = h_prev (*) lin (W_hh packed for estts_gemm, its bias included), gates, h_out
-    (and out = h_out + x_res); see estts_gru_fused_fwd."""
+    (and out = h_out + x_res); see estts_gru_fused_fwd.  launch=False: only builds and returns the argument block (for
+    gru_fused_pair; the tensors must outlive the launch)."""
     a = _gru_fused_common(gi, gh, h_prev, lin, precision)
     if (lin.N, lin.K) != (3 * a.H, a.H) or lin.s1 is not None:
         raise ValueError('gru_fused_fwd: the weight must be W_hh [3H x H] without an output scale')
@@ -378,19 +379,36 @@ def gru_fused_fwd(gi, gh, h_prev, lin, h_out, x_res=None, out=None, precision='b
         a.x_res, a.ldx = x_res.data_ptr(), x_res.stride(0)
     if out is not None:
         a.out, a.ldo = out.data_ptr(), out.stride(0)
+    if not launch:
+        return a
     check(_lib.load().estts_gru_fused_fwd(a, _stream()), 'estts_gru_fused_fwd')
 
 
-def gru_fused_bwd(gi, gh, h_prev, dh, dgh_next, lin_bwd, dgi, dgh, dhd, precision='bf16x3'):
+def gru_fused_bwd(gi, gh, h_prev, dh, dgh_next, lin_bwd, dgi, dgh, dhd, precision='bf16x3', launch=True):
     """The hidden-state gradient reaching a step from the next one (dgh_next (*) lin_bwd + dhd) and the step's gate gradients in
-    one launch; see estts_gru_fused_bwd."""
+    one launch; see estts_gru_fused_bwd.  launch=False: only builds and returns the argument block (gru_fused_pair)."""
     a = _gru_fused_common(gi, gh, h_prev, lin_bwd, precision)
     if (lin_bwd.N, lin_bwd.K) != (a.H, 3 * a.H) or lin_bwd.s1 is not None or lin_bwd.b1 is not None:
         raise ValueError('gru_fused_bwd: the weight must be the transposed pack [H x 3H] of W_hh without scale or bias')
     a.dgh_next, a.lddghn, a.dh, a.lddh = dgh_next.data_ptr(), dgh_next.stride(0), dh.data_ptr(), dh.stride(0)
     a.dgi, a.lddgi, a.dgh, a.lddgh = dgi.data_ptr(), dgi.stride(0), dgh.data_ptr(), dgh.stride(0)
     a.dhd, a.lddhd = dhd.data_ptr(), dhd.stride(0)
+    if not launch:
+        return a
     check(_lib.load().estts_gru_fused_bwd(a, _stream()), 'estts_gru_fused_bwd')
+
+
+def gru_fused_pair(a, b, forward):
+    """Argument blocks of gru_fused_fwd / gru_fused_bwd (launch=False) as ONE launch: two independent steps of the same width;
+    either may be None (then the other runs alone)."""
+    lib = _lib.load()
+    if a is None or b is None:
+        one = a if b is None else b
+        fn, name = (lib.estts_gru_fused_fwd, 'estts_gru_fused_fwd') if forward else (lib.estts_gru_fused_bwd, 'estts_gru_fused_bwd')
+        check(fn(one, _stream()), name)
+        return
+    fn, name = (lib.estts_gru_fused_fwd2, 'estts_gru_fused_fwd2') if forward else (lib.estts_gru_fused_bwd2, 'estts_gru_fused_bwd2')
+    check(fn(a, b, _stream()), name)
 
 
 def wavernn_prep_bwd(dxin, da2, da3, da4, mel, mel_off, d_aux, dfir, fir_kmin, n_utt, frames, feat, d, hop, pad):

@@ -69,6 +69,9 @@ class WaveRNNTrainer:
         # a recurrent step as ONE launch (product + gates, estts_gru_fused_fwd / _bwd) instead of two; False: estts_gemm followed
         # by estts_gru_step_fwd / _bwd (for comparisons)
         self.fused_gru = True
+        # with one-launch steps: both layers' recurrences as ONE chain of launches (step t of one layer and step t -+ chunk of
+        # the other in the same launch) instead of two chains on two streams
+        self.one_chain = True
         self.use_graph = use_graph
         self.step = 0
         self.lr, self.beta1, self.beta2, self.eps = 1e-4, 0.9, 0.999, 1e-8      # torch.optim.Adam defaults, hp.voc_lr
@@ -332,14 +335,95 @@ class WaveRNNTrainer:
                      # 32 windows x 1000 steps: one chunk 57.6 ms per training step, 500: 47.8, 250: 42.8, 125: 44.1, 50: 46.3)
 
     def _chunks(self, T):
-        c = self.CHUNK or max(-(-T // 4), 1)
+        # one chain of launches for both layers: the hand-over is one product in the same stream, so shorter chunks pay
+        # (measured, 32 windows x 1000 steps: 25.0 ms per training step at 250, 23.3 at 125, 22.9 at 63, 23.3 at 32, 24.6 at 16)
+        c = self.CHUNK or max(-(-T // (16 if self.fused_gru and self.one_chain else 4)), 1)
         return [(c0, min(c0 + c, T)) for c0 in range(0, T, c)]
+
+    def _fwd_blocks(self, ws, gi, gh, H, hh, x_res, out, out_cols, t0, t1):
+        """Argument blocks of the one-launch forward steps t0 .. t1 - 1 of a layer."""
+        B, T, R = ws['B'], ws['T'], self.rnn_dims
+        gi3, gh3, H3 = gi.view(B, T, 3 * R), gh.view(B, T, 3 * R), H.view(B, T, R)
+        xr3, out3 = x_res.view(B, T, -1), out.view(B, T, -1)
+        return [T_.gru_fused_fwd(gi3[:, t], gh3[:, t], ws['h0'] if t == 0 else H3[:, t - 1], hh.lin.fwd, H3[:, t],
+                                 x_res=xr3[:, t, :out_cols], out=out3[:, t, :out_cols], precision=self.precision, launch=False)
+                for t in range(t0, t1)]
+
+    def _bwd_blocks(self, ws, gi, gh, H, hh, dout, dgi, dgh, dhd, t_hi, t_lo):
+        """The launches of the backward steps t_hi - 1 .. t_lo of a layer (see _gru_bwd): a callable for the plain kernel of the
+        window's last step, argument blocks for the one-launch steps."""
+        B, T, R = ws['B'], ws['T'], self.rnn_dims
+        gi3, gh3, H3 = gi.view(B, T, 3 * R), gh.view(B, T, 3 * R), H.view(B, T, R)
+        dgi3, dgh3, do3 = dgi.view(B, T, 3 * R), dgh.view(B, T, 3 * R), dout.view(B, T, -1)
+        blocks = []
+        if t_hi == T:
+            hp = ws['h0'] if T == 1 else H3[:, T - 2]
+            blocks.append(lambda: T_.gru_step_bwd(gi3[:, T - 1], gh3[:, T - 1], hp, do3[:, T - 1, :R], None, dgi3[:, T - 1],
+                                                  dgh3[:, T - 1], dhd))
+        for t in range(min(t_hi, T - 1), t_lo, -1):
+            blocks.append(T_.gru_fused_bwd(gi3[:, t - 1], gh3[:, t - 1], ws['h0'] if t == 1 else H3[:, t - 2], do3[:, t - 1, :R],
+                                           dgh3[:, t], hh.lin.bwd, dgi3[:, t - 1], dgh3[:, t - 1], dhd, precision=self.precision,
+                                           launch=False))
+        return blocks
+
+    @staticmethod
+    def _issue(first, second, forward):
+        """Two lists of launches side by side: entry i of both in one launch where both are one-launch GRU steps."""
+        for i in range(max(len(first), len(second))):
+            a = first[i] if i < len(first) else None
+            b = second[i] if i < len(second) else None
+            if callable(a):
+                a()
+                a = None
+            if callable(b):
+                b()
+                b = None
+            if a is not None or b is not None:
+                T_.gru_fused_pair(a, b, forward)
+
+    def _gru12_fwd_one_chain(self, ws):
+        """Both GRU layers as ONE chain of launches: rnn2 runs a chunk of steps behind rnn1 (its input gates come from one
+        product per chunk over rnn1's outputs), and step t of rnn1 shares its launch with step t - chunk of rnn2.  Two chains side
+        by side on two streams take about as long as one and a quarter; this takes one and one chunk."""
+        B, T, R, d = ws['B'], ws['T'], self.rnn_dims, self.aux_dims
+        x1 = ws['x1cat'].view(B, T, R + d)
+        g2 = ws['gi2'].view(B, T, 3 * R)
+        chunks = self._chunks(T)
+        for k in range(len(chunks) + 1):
+            one = self._fwd_blocks(ws, ws['gi1'], ws['gh1'], ws['H1'], self.hh1, ws['xI'], ws['x1cat'], R, *chunks[k]) if k < len(chunks) else []
+            two = self._fwd_blocks(ws, ws['gi2'], ws['gh2'], ws['H2'], self.hh2, ws['x1cat'], ws['x2cat'], R, *chunks[k - 1]) if k else []
+            self._issue(one, two, True)
+            if k < len(chunks):
+                c0, c1 = chunks[k]
+                ops.gemm(x1[0, c0:c1], self.ih2.lin.fwd, g2[0, c0:c1], precision=self.precision, split=False,
+                         batch=(B, T * (R + d), 0, T * 3 * R, 0))
+
+    def _gru21_bwd_one_chain(self, ws):
+        """The backward recurrences as one chain, from the last step down: rnn1 a chunk behind rnn2 (the gradient of rnn1's
+        outputs comes from one product per chunk over rnn2's input-gate gradients plus the residual path)."""
+        B, T, R, d = ws['B'], ws['T'], self.rnn_dims, self.aux_dims
+        dg2 = ws['dgi'].view(B, T, 3 * R)
+        dx1 = ws['dx1cat'].view(B, T, R + d)
+        res = ws['res2'].view(B, T, R + d)
+        chunks = list(reversed(self._chunks(T)))
+        for k in range(len(chunks) + 1):
+            two = self._bwd_blocks(ws, ws['gi2'], ws['gh2'], ws['H2'], self.hh2, ws['dx2cat'], ws['dgi'], ws['dgh'], ws['dhd'],
+                                   chunks[k][1], chunks[k][0]) if k < len(chunks) else []
+            one = self._bwd_blocks(ws, ws['gi1'], ws['gh1'], ws['H1'], self.hh1, ws['dx1cat'], ws['dgi1'], ws['dgh1'], ws['dhd1'],
+                                   chunks[k - 1][1], chunks[k - 1][0]) if k else []
+            self._issue(two, one, False)
+            if k < len(chunks):
+                c0, c1 = chunks[k]
+                ops.gemm(dg2[0, c0:c1], self.ih2.lin.bwd, dx1[0, c0:c1], precision=self.precision, split=False,
+                         residual=res[0, c0:c1], batch=(B, T * 3 * R, 0, T * (R + d), 0))
 
     def _gru12_fwd(self, ws):
         """Both GRU layers of the window as two chains that overlap: rnn2 only needs rnn1's outputs up to its own step, so
         after every CHUNK steps of rnn1 (this stream) a second stream computes rnn2's input gates for those steps (one product
         batched over the windows) and runs rnn2 over them while rnn1 goes on.  The chains are latency-bound (32 rows per
         product), so side by side they take little more than one of them."""
+        if self.fused_gru and self.one_chain:
+            return self._gru12_fwd_one_chain(ws)
         B, T, R, d = ws['B'], ws['T'], self.rnn_dims, self.aux_dims
         cur, sb = torch.cuda.current_stream(), ws['stream_b']
         x1 = ws['x1cat'].view(B, T, R + d)
@@ -358,6 +442,8 @@ class WaveRNNTrainer:
         """The backward recurrences the same way, from the last step down: rnn2 on this stream; after every CHUNK steps the
         second stream turns rnn2's input-gate gradients of those steps into the gradient of rnn1's output (product with
         W_ih2 plus the residual path, ws['res2']) and runs rnn1's backward recurrence over them."""
+        if self.fused_gru and self.one_chain:
+            return self._gru21_bwd_one_chain(ws)
         B, T, R, d = ws['B'], ws['T'], self.rnn_dims, self.aux_dims
         cur, sb = torch.cuda.current_stream(), ws['stream_b']
         dg2 = ws['dgi'].view(B, T, 3 * R)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 30
+#define ESTTS_ABI_VERSION 31
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -705,6 +705,10 @@ typedef struct estts_gru_fused_args {
 
 int estts_gru_fused_fwd(const estts_gru_fused_args* args, void* stream);
 int estts_gru_fused_bwd(const estts_gru_fused_args* args, void* stream);
+/* Two independent steps of the same width H and precision in one launch (the two layers of a WaveRNN window, one a chunk of
+ * steps behind the other: two recurrences then cost one chain of launches instead of two that run side by side). */
+int estts_gru_fused_fwd2(const estts_gru_fused_args* a, const estts_gru_fused_args* b, void* stream);
+int estts_gru_fused_bwd2(const estts_gru_fused_args* a, const estts_gru_fused_args* b, void* stream);
 
 /* Backward of estts_wavernn_prep for teacher-forced windows: every utterance has `frames` frames of `hop` samples and
  * row (u * frames + f) * hop + ph of the gradient matrices belongs to frame f, phase ph.

@@ -44,19 +44,21 @@ def check_grads(mine, ref, tol_all=0.35, tol_tight=3e-3):
 
 @pytest.mark.parametrize('mode', ['RAW', 'MOL'])
 @pytest.mark.parametrize('use_graph,chunk,fused', [(False, None, True), (True, None, True), (False, 7, True), (True, 7, True),
-                                                   (False, 7, False), (True, None, False)])
+                                                   (False, 7, False), (True, None, False), (True, 7, 'two chains')])
 def test_train_step_against_reference_golden_and_oracle(mode, use_graph, chunk, fused):
     """chunk: steps between hand-overs of the two overlapped GRU recurrences; 7 gives the window several (uneven) chunks, so
     the second stream's batched products and the carried hidden-state gradients cross chunk borders.  fused: a recurrent step
-    as one launch (product + gates) or as two."""
+    as one launch (product + gates; both layers in one chain of launches, or on two streams) or as two."""
     from estts.wavernn_training import WaveRNNTrainer
     g = np.load(os.path.join(GOLD, f'wavernn_train_{mode.lower()}_small.npz'))
     hp = small_hp(mode)
     w = weights.init_wavernn(hp, seed=int(g['seed']))
     model = WaveRNNTrainer.from_hparams(hp, use_graph=use_graph)
     model.CHUNK = chunk
-    model.fused_gru = fused
-    assert len(model._chunks(g['x'].shape[1])) == 4 if chunk is None else len(model._chunks(g['x'].shape[1])) > 4
+    model.fused_gru = bool(fused)
+    model.one_chain = fused is True                      # 'two chains': one-launch steps, the layers on two streams
+    n_chunks = len(model._chunks(g['x'].shape[1]))       # a quarter window by default, a sixteenth for the one-chain recurrences
+    assert n_chunks > 4 if (chunk is not None or fused) else n_chunks == 4
     model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
     sd0 = model.state_dict()
     for k, v in w.items():
