@@ -508,9 +508,10 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 dz = self._empty(M, conv.N)
                 if batch and self.fold_sums and conv.N <= T.SumSlots.MAX_C:
                     # this call's own sum(dy) and sum(dy * xhat) go to bn_bwd in their copies; it adds them to the gradients
-                    sl = T.colreduce(2, z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz, M=M, C=conv.N,
+                    sl = T.colreduce(2, z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], M=M, C=conv.N,
                                      scale=st[2], shift=st[3], defer=True)
-                    self._bn_input_grad(batch, dz, z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N, slots=sl)
+                    self._bn_input_grad(batch, g.view(M, conv.N), z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N, slots=sl,
+                                        act='relu')
                 else:
                     sums = self.store.zeros(2, conv.N)       # this call's own sums: bn_bwd reads them
                     T.colreduce(2, sums[0], sums[1], z=z, g=g.view(M, conv.N), act='relu', mean=st[0], rstd=st[1], dy_out=dz,

@@ -118,12 +118,17 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* dy, int lddy, 
 __global__ __launch_bounds__(256) void bn_bwd_slots_kernel(const float* dy, int lddy, const float* z, int ldz, const float* mean,
                                                            const float* rstd, const float* gamma, const float* slots,
                                                            long cp, float* dgamma, float* dbeta, float* dz, int lddz, int M,
-                                                           int C) {
+                                                           int C, int act, const float* scale, const float* shift) {
     const int chunk = threadIdx.x & 63;
     const int rl = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + chunk) * 4;
     if (c >= C) return;
     float4 db = make_float4(0.f, 0.f, 0.f, 0.f), dg = db;
+    // scale != NULL: dy is the gradient w.r.t. act(z scale + shift) and goes through the activation here, with the arithmetic of
+    // the reduction that built the sums (which then need not store its dy)
+    const bool through_act = scale != nullptr && act != ESTTS_ACT_NONE;
+    float4 sc = db, sh = db;
+    if (through_act) { sc = ld4(scale + c); sh = ld4(shift + c); }
     {
         float4 v0[16], v1[16];
 #pragma unroll
@@ -146,7 +151,13 @@ __global__ __launch_bounds__(256) void bn_bwd_slots_kernel(const float* dy, int 
     }
     const float inv_m = 1.0f / (float)M;
     const float4 mu = ld4(mean + c), rs = ld4(rstd + c), ga = ld4(gamma + c);
-    auto one = [&](const float4& g, const float4& x) {
+    auto one = [&](float4 g, const float4& x) {
+        if (through_act) {
+            g.x *= act_grad_from_output(apply_act(x.x * sc.x + sh.x, act), act);
+            g.y *= act_grad_from_output(apply_act(x.y * sc.y + sh.y, act), act);
+            g.z *= act_grad_from_output(apply_act(x.z * sc.z + sh.z, act), act);
+            g.w *= act_grad_from_output(apply_act(x.w * sc.w + sh.w, act), act);
+        }
         float4 r;
         r.x = ga.x * rs.x * (g.x - db.x * inv_m - (x.x - mu.x) * rs.x * dg.x * inv_m);
         r.y = ga.y * rs.y * (g.y - db.y * inv_m - (x.y - mu.y) * rs.y * dg.y * inv_m);
@@ -747,7 +758,9 @@ extern "C" int estts_bn_bwd(const float* dy, int32_t lddy, const float* z, int32
 
 extern "C" int estts_bn_bwd_slots(const float* dy, int32_t lddy, const float* z, int32_t ldz, const float* mean, const float* rstd,
                                   const float* gamma, const float* slots, int64_t slot_stride, float* dgamma, float* dbeta,
-                                  float* dz, int32_t lddz, int32_t M, int32_t C, void* stream) {
+                                  float* dz, int32_t lddz, int32_t M, int32_t C, int32_t act, const float* scale,
+                                  const float* shift, void* stream) {
+    ESTTS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "estts_bn_bwd_slots: scale and shift go together");
     ESTTS_CHECK_ARG(dy && z && mean && rstd && gamma && slots && dgamma && dbeta && dz && M > 0 && C > 0 && (C & 3) == 0 &&
                         (lddy & 3) == 0 && (ldz & 3) == 0 && (lddz & 3) == 0,
                     "estts_bn_bwd_slots: bad arguments");
@@ -757,7 +770,7 @@ extern "C" int estts_bn_bwd_slots(const float* dy, int32_t lddy, const float* z,
     const int cap = (1024 + gx - 1) / gx;
     if (ysplit > cap) ysplit = cap;
     hipLaunchKernelGGL(bn_bwd_slots_kernel, dim3(gx, ysplit), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma,
-                       slots, (long)slot_stride, dgamma, dbeta, dz, lddz, M, C);
+                       slots, (long)slot_stride, dgamma, dbeta, dz, lddz, M, C, act, scale, shift);
     ESTTS_CHECK_LAUNCH("estts_bn_bwd_slots");
     return 0;
 }

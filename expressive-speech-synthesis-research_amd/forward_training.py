@@ -459,12 +459,15 @@ class ForwardTransformerTrainer:
     def _bn_stats(self, z, norm, M, C, summed=None):
         return self._bn_train(z, norm, M, C, summed) if self._bn_batch else self._bn_eval(norm, C)
 
-    def _bn_input_grad(self, batch, dy, z, st, norm, sums, dz, M, C, slots=None):
+    def _bn_input_grad(self, batch, dy, z, st, norm, sums, dz, M, C, slots=None, act=None):
         """Gradient with respect to the normalised tensor given sum(dy) and sum(dy * xhat) in `sums` (beta, gamma order), or
         still spread over the copies at `slots` (then also added to `sums`, the parameter gradients): the batch-statistics
         form, or dy * scale when the layer ran on its moving statistics."""
         if batch:
-            T.bn_bwd(dy, z, st[0], st[1], norm.gamma, sums[1], sums[0], dz, M=M, C=C, slots=slots)
+            if act is not None:      # dy is still the gradient w.r.t. the activation output: bn_bwd takes it through (slots only)
+                T.bn_bwd(dy, z, st[0], st[1], norm.gamma, sums[1], sums[0], dz, M=M, C=C, slots=slots, act=act, scale=st[2], shift=st[3])
+            else:
+                T.bn_bwd(dy, z, st[0], st[1], norm.gamma, sums[1], sums[0], dz, M=M, C=C, slots=slots)
         else:
             T.affine_act(dy, dz, st[2], self.store.zeros(C), None, M=M, C=C)
 
@@ -504,9 +507,16 @@ class ForwardTransformerTrainer:
                 conv, norm, act = Cb.convs[i], Cb.norms[i], Cb.acts[i]
                 hin, z, st = saved[i]
                 dz = self._empty(M, conv.N)
-                sl = T.colreduce(2, norm.dbeta, norm.dgamma, z=z, g=g, act=act, mean=st[0], rstd=st[1], dy_out=dz, M=M, C=conv.N,
-                                 scale=st[2], shift=st[3], defer=batch and self.fold_sums and conv.N <= T.SumSlots.MAX_C)
-                self._bn_input_grad(batch, dz, z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N, slots=sl)
+                defer = batch and self.fold_sums and conv.N <= T.SumSlots.MAX_C
+                if defer and act is not None:
+                    # the reduction does not store g * act': bn_bwd recomputes it from the same operands (one store and one
+                    # load of the tensor less)
+                    sl = T.colreduce(2, z=z, g=g, act=act, mean=st[0], rstd=st[1], M=M, C=conv.N, scale=st[2], shift=st[3], defer=True)
+                    self._bn_input_grad(batch, g, z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N, slots=sl, act=act)
+                else:
+                    sl = T.colreduce(2, norm.dbeta, norm.dgamma, z=z, g=g, act=act, mean=st[0], rstd=st[1], dy_out=dz, M=M, C=conv.N,
+                                     scale=st[2], shift=st[3], defer=defer)
+                    self._bn_input_grad(batch, dz, z, st, norm, (norm.dbeta, norm.dgamma), dz, M, conv.N, slots=sl)
                 if i > 0:
                     g = self._empty(M, conv.lin.cin)
                     self._lin_bwd(hin, conv, dz, M, seg, dx=g)

@@ -262,16 +262,20 @@ def affine_act(z, out, scale=None, shift=None, act=None, residual=None, r_mod=0,
     return out
 
 
-def bn_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dz, M=None, C=None, slots=None):
+def bn_bwd(dy, z, mean, rstd, gamma, dgamma, dbeta, dz, M=None, C=None, slots=None, act=None, scale=None, shift=None):
     """slots = (pointer, stride) of deferred mode-2 sums: they are the dbeta / dgamma used, and their totals are added to the
-    dgamma / dbeta tensors (the parameter gradients)."""
+    dgamma / dbeta tensors (the parameter gradients).  With slots, act / scale / shift: dy is the gradient w.r.t.
+    act(z * scale + shift) and goes through the activation inside the launch (the reduction then needs no dy_out)."""
     M = z.shape[0] if M is None else M
     C = z.shape[1] if C is None else C
     if slots is not None:
         check(_lib.load().estts_bn_bwd_slots(dy.data_ptr(), dy.stride(0), z.data_ptr(), z.stride(0), mean.data_ptr(), rstd.data_ptr(),
                                              gamma.data_ptr(), slots[0], slots[1], dgamma.data_ptr(), dbeta.data_ptr(),
-                                             dz.data_ptr(), dz.stride(0), M, C, _stream()), 'estts_bn_bwd_slots')
+                                             dz.data_ptr(), dz.stride(0), M, C, ACT[act], _ptr(scale), _ptr(shift), _stream()),
+              'estts_bn_bwd_slots')
         return dz
+    if scale is not None:
+        raise ValueError('bn_bwd: the activation inside the launch needs slots=')
     check(_lib.load().estts_bn_bwd(dy.data_ptr(), dy.stride(0), z.data_ptr(), z.stride(0), mean.data_ptr(), rstd.data_ptr(),
                                    gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), dz.stride(0), M, C,
                                    _stream()), 'estts_bn_bwd')

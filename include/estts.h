@@ -581,10 +581,13 @@ int estts_bn_bwd(const float* dy, int32_t lddy, const float* z, int32_t ldz, con
 
 /* The same with dbeta / dgamma = the mode-2 sums still spread over 16 copies (estts_colreduce with defer; layout as for
  * estts_bn_finalize_slots, sum 0 = dbeta, sum 1 = dgamma).  The totals are also ADDED to dgamma [C] / dbeta [C] (the
- * parameter gradients).  The copies are left as they are: hand the region to a later estts_colreduce as `clear`. */
+ * parameter gradients).  The copies are left as they are: hand the region to a later estts_colreduce as `clear`.
+ * scale / shift != NULL: dy is the gradient w.r.t. act(z scale + shift) and is taken through the activation here (dy <- dy *
+ * act'), with the arithmetic of the estts_colreduce call that built the sums from the same operands -- that call then needs no
+ * dy_out, which saves a store and a load of the tensor. */
 int estts_bn_bwd_slots(const float* dy, int32_t lddy, const float* z, int32_t ldz, const float* mean, const float* rstd,
                        const float* gamma, const float* slots, int64_t slot_stride, float* dgamma, float* dbeta, float* dz,
-                       int32_t lddz, int32_t M, int32_t C, void* stream);
+                       int32_t lddz, int32_t M, int32_t C, int32_t act, const float* scale, const float* shift, void* stream);
 
 /* out[m, c] = x[m, c] * keep(seed, site, m, c) / (1 - rate): tf.keras.layers.Dropout in training mode with a
  * counter-based generator (the same call on a gradient is the backward pass).  May run in place. */

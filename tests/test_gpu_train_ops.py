@@ -333,6 +333,12 @@ def test_batchnorm_with_deferred_sums_matches_the_two_launch_path(T, sizes):
             sl = T.colreduce(2, g2[0], g2[1], z=z, g=dout, act='relu', mean=st[0], rstd=st[1], dy_out=dy, scale=st[2], shift=st[3],
                              defer=defer)
             T.bn_bwd(dy, z, st[0], st[1], gamma, g2[1], g2[0], dz, slots=sl)
+            if defer:       # the same from the raw gradient: bn_bwd takes it through the activation, the reduction stores no dy
+                g3 = torch.zeros(2, C, device='cuda')
+                dz3 = torch.empty(M, C, device='cuda')
+                sl = T.colreduce(2, z=z, g=dout, act='relu', mean=st[0], rstd=st[1], scale=st[2], shift=st[3], defer=True)
+                T.bn_bwd(dout, z, st[0], st[1], gamma, g3[1], g3[0], dz3, slots=sl, act='relu', scale=st[2], shift=st[3])
+                assert rel_err(dz3, dz) < 1e-6 and rel_err(g3, g2 - 0.5) < 1e-6, (rnd, M, C)
             stats.append((st.clone(), mm, mv, (g2 - (0.5 if defer else 0.0)).clone(), dz))
         a, b = stats
         # (float atomics: the order of the additions differs from launch to launch)

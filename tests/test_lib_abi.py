@@ -78,8 +78,10 @@ def test_deferred_sum_arguments_are_validated_before_any_launch():
 
     args = [fake, 512, fake, 64, 256, 1e-3, 0.99, 1.0] + [fake] * 9 + [None]     # stride 512 for 256 columns
     assert lib.estts_bn_finalize_slots(*args) != 0 and 'slot_stride' in err()
-    args = [fake, 256, fake, 256, fake, fake, fake, fake, 512, fake, fake, fake, 256, 64, 256, None]
+    args = [fake, 256, fake, 256, fake, fake, fake, fake, 512, fake, fake, fake, 256, 64, 256, 0, None, None, None]
     assert lib.estts_bn_bwd_slots(*args) != 0 and 'slot_stride' in err()
+    args[8], args[16] = 256, fake                                                # scale without shift
+    assert lib.estts_bn_bwd_slots(*args) != 0 and 'go together' in err()
 
     g = _lib.GemmArgs()
     g.A, g.lda, g.taps, g.c_per_tap, g.W_hi, g.W_lo, g.ldw = fake, 64, 1, 64, fake, fake, 64
