@@ -278,21 +278,104 @@ def roofline_from_trace(trace, kernel_table, rank):
             pmc = None
         if pmc:
             roofline['traffic'] = pmc['hbm_bytes']
-            roofline['traffic_source'] = pmc['source']
+            roofline['traffic_source'] = ('committed PMC pass (rocprofv3 --pmc on this command, same kernel sources by digest), '
+                                          'not measured in this run: ' + pmc['source'])
             roofline['algorithmic_bytes'] = dom['info']['bytes']
     except OSError:
         pass
     roofline['avg_us'] = avg * 1e6
     roofline['launches_per_step'] = dom['n']
-    roofline['share_of_step'] = dom['t'] / total_iso
+    # finish_roofline() turns this into share_of_step once the step itself has been timed
+    roofline['share_of_isolated_kernel_sum'] = dom['t'] / total_iso
     return roofline, len(rows)
 
 
-def train_bench(args, rank, world, dist):
+def finish_roofline(roofline, ms_per_step):
+    """share_of_step: the dominant kernel's launches (isolated average x count) over the measured step time."""
+    if roofline is not None:
+        roofline['share_of_step'] = roofline['avg_us'] * roofline['launches_per_step'] / (ms_per_step * 1e3)
+    return roofline
+
+
+def launches_of(fn):
+    """Kernels the library launches during fn() (estts_launch_count: every launch of every entry point, the training
+    kernels included; torch's own fills and copies are not the library's and are not counted)."""
+    from estts import _lib
+    lib = _lib.load()
+    n0 = lib.estts_launch_count()
+    out = fn()
+    return lib.estts_launch_count() - n0, out
+
+
+def timed_steps(step, steps, warmup, dist):
+    """`warmup` untimed and `steps` timed calls of step(), bracketed by barrier + device synchronisation on both sides;
+    returns (seconds of the slowest rank, last result)."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def exchange_report(model, dist, dp_ms, steps, warmup, step):
+    """Data-parallel runs: what the gradient exchange costs.  `allreduce_ms` is the bucketed all-reduce of the whole flat
+    gradient buffer on its own (communication stream, HIP events), `exposed_ms` the difference between the step with and
+    without the exchange (the same trainer, `exchange = False`: ranks then drift apart, which is fine for a timing),
+    `hidden_ms` the rest, i.e. what ran beside the backward pass."""
+    from estts import parallel
+    world = dist.get_world_size()
+    backend = dist.get_backend()
+    grad = model.store.grad
+    comm = torch.cuda.Stream()
+    best = float('inf')
+    for i in range(4):
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        parallel.allreduce_buckets(grad, model.bucket_elems, comm_stream=comm if backend == 'nccl' else None)
+        e1.record()
+        e1.synchronize()
+        if i:
+            best = min(best, e0.elapsed_time(e1))
+    model.exchange = False
+    dt, _ = timed_steps(step, steps, warmup, dist)
+    model.exchange = True
+    solo_ms = dt * 1e3 / steps
+    exposed = max(dp_ms - solo_ms, 0.0)
+    seen = [None] * world
+    dist.all_gather_object(seen, (dist.get_rank(), torch.cuda.current_device(), torch.cuda.get_device_name()))
+    nbytes = grad.numel() * 4
+    return {'backend': 'rccl' if backend == 'nccl' else backend, 'ranks_seen': len({r for r, _, _ in seen}),
+            'devices': sorted({f'{d}:{n}' for _, d, n in seen}), 'gradient_bytes': nbytes,
+            'buckets': len(parallel.bucket_ranges(grad.numel(), model.bucket_elems)),
+            'overlapped_with_backward': backend == 'nccl',
+            'allreduce_ms': best, 'allreduce_bus_gb_s': 2.0 * (world - 1) / world * nbytes / (best * 1e-3) / 1e9,
+            'step_ms_without_exchange': solo_ms, 'exposed_ms': exposed, 'hidden_ms': max(best - exposed, 0.0)}
+
+
+def train_measure(args, rank, world, dist, B, steps, warmup, cpu_leg):
     """BASELINE config 5: ForwardTransformer training step (forward with dropout / batch statistics, masked-MAE losses,
-    backward, bucketed gradient all-reduce over RCCL, Adam), `--batch` utterances per GPU (weak scaling)."""
+    backward, bucketed gradient all-reduce over RCCL beside the backward pass, Adam), B utterances per GPU (weak scaling,
+    global batch world * B).  Returns the bench line (rank 0; None elsewhere)."""
     from estts.forward_training import ForwardTransformerTrainer
-    B, N, T = args.batch, args.tokens, args.frames
+    N, T = args.tokens, args.frames
     cfg = configs.forward_config()
     w = weights.init_forward_transformer(cfg, seed=1234)                 # same seed: identical replicas on every rank
     tokens, durs = synthetic_utterance(cfg, B, N, T, seed=1234 + rank)
@@ -315,7 +398,7 @@ def train_bench(args, rank, world, dist):
     loss0 = float(out['loss'])
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and cpu_leg:
         from oracle import tts_train_torch as OTT
         torch.set_num_threads(min(os.cpu_count() or 1, 16))
         bs = min(B, 2)
@@ -326,52 +409,96 @@ def train_bench(args, rank, world, dist):
                'sample': f'1 training step (forward + autograd backward, no optimizer) on {bs} of the {B} utterances '
                          f'(N={N}, T={T}), PyTorch CPU float32 restatement (oracle/tts_train_torch.py)'}
 
-    roofline, launches = None, None
-    if rank == 0 or world > 1:
-        ops.start_trace()
-        traced = step()
-        trace = ops.stop_trace()
-        torch.cuda.synchronize()
-        roofline, launches = roofline_from_trace(trace, args.kernel_table, rank)
-        del traced, trace
+    # per-kernel timing (every rank goes through the same collectives, so every rank traces)
+    ops.start_trace()
+    launches, traced = launches_of(step)
+    trace = ops.stop_trace()
+    torch.cuda.synchronize()
+    roofline, _ = roofline_from_trace(trace, args.kernel_table, rank)
+    del traced, trace
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms = dt * 1e3 / args.steps
+    dt, out = timed_steps(step, steps, warmup, dist)
+    ms = dt * 1e3 / steps
+    exchange = exchange_report(model, dist, ms, max(steps // 2, 3), 1, step) if dist is not None else None
+    if rank != 0:
+        return None
+    flops = 3.0 * B * algorithmic_flops(N, T)           # forward + data gradient + weight gradient
+    line = {
+        'metric': 'mel-frames/sec (ForwardTransformer training step)', 'value': world * B * T / (dt / steps),
+        'unit': 'mel-frames/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': ms,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': f'ForwardTransformer train_step: forward (dropout 0.1, BatchNorm batch statistics) + backward + '
+                               f'gradient all-reduce + Adam, batch={B} per GPU, N={N}, T={T} (BASELINE config 5); '
+                               f'{args.precision} MFMA operands (backward products: {args.backward_precision or args.precision}), fp32 accumulate, fp32 master weights',
+                   'global_batch': world * B, 'parallelism': f'dp{world}', 'hip_graph': False,
+                   'launches_per_step': launches},
+        'steps_per_s': steps / dt, 'algorithmic_tflops': world * flops / (dt / steps) / 1e12,
+        'loss_first_step': loss0, 'loss_last_step': float(out['loss']),
+        'roofline': finish_roofline(roofline, ms), 'cpu_baseline': cpu,
+    }
+    if exchange is not None:
+        line['exchange'] = exchange
+    return line
+
+
+def train_bench(args, rank, world, dist):
+    line = train_measure(args, rank, world, dist, args.batch, args.steps, args.warmup, not args.no_cpu_baseline)
     if rank == 0:
-        flops = 3.0 * B * algorithmic_flops(N, T)           # forward + data gradient + weight gradient
-        line = {
-            'metric': 'mel-frames/sec (ForwardTransformer training step)', 'value': world * B * T / (dt / args.steps),
-            'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'ForwardTransformer train_step: forward (dropout 0.1, BatchNorm batch statistics) + backward + '
-                                   f'gradient all-reduce + Adam, batch={B} per GPU, N={N}, T={T} (BASELINE config 5); '
-                                   f'{args.precision} MFMA operands (backward products: {args.backward_precision or args.precision}), fp32 accumulate, fp32 master weights',
-                       'global_batch': world * B, 'parallelism': f'dp{world}', 'hip_graph': False,
-                       'launches_per_step': launches},
-            'steps_per_s': args.steps / dt, 'algorithmic_tflops': world * flops / (dt / args.steps) / 1e12,
-            'loss_first_step': loss0, 'loss_last_step': float(out['loss']),
-            'roofline': roofline, 'cpu_baseline': cpu,
-        }
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def exchange_bench(args, rank, world, dist):
+    """The exchange step of data-parallel training on its own: the bucketed sum of one flat float32 gradient buffer over all
+    ranks (parallel.allreduce_buckets; 19.18 M elements = the ForwardTransformer's 76.7 MB unless --elems says otherwise).
+    With a GPU the buffer lives in HBM and the transport is RCCL (or gloo when ESTTS_DIST_BACKEND=gloo); without one it is
+    host memory over gloo, which is how the CPU tests rehearse the N-rank launch."""
+    from estts import parallel
+    on_gpu = torch.cuda.is_available()
+    n = args.elems
+    flat = torch.full((n,), float(rank + 1), dtype=torch.float32, device='cuda' if on_gpu else 'cpu')
+    bucket = int(25 * (1 << 20) // 4)
+    comm = torch.cuda.Stream() if on_gpu and dist is not None and dist.get_backend() == 'nccl' else None
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    def step():
+        parallel.allreduce_buckets(flat, bucket, comm_stream=comm)
+
+    step()
+    sync()
+    expect = world * (world + 1) / 2.0
+    ok = bool((flat == expect).all())
+    flat.fill_(1.0 / world)           # stays 1 / world * world ... bounded whatever the step count
+    for _ in range(args.warmup):
+        step()
+        flat.mul_(1.0 / world)
+    sync()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device=flat.device if on_gpu and comm is not None else torch.device('cpu'))
+    if rank == 0:
+        nbytes = 4.0 * n
+        print(json.dumps({
+            'metric': 'gradient all-reduce bus bandwidth', 'value': 2.0 * (world - 1) / max(world, 1) * nbytes * args.steps / dt / 1e9,
+            'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt * 1e3 / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'bucketed all-reduce (sum) of one flat float32 gradient buffer of {n} elements over {world} ranks, '
+                                   f'{len(parallel.bucket_ranges(n, bucket))} bucket(s) of <= 25 MB',
+                       'backend': ('rccl' if dist.get_backend() == 'nccl' else dist.get_backend()) if dist is not None else None,
+                       'memory': 'hbm' if on_gpu else 'host', 'parallelism': f'dp{world}'},
+            'sum_correct': ok, 'roofline': None, 'cpu_baseline': None}))
+    if dist is not None:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit('all-reduce returned a wrong sum')
 
 
 def train_ar_bench(args, rank, world, dist):
@@ -650,6 +777,31 @@ def in_flight_pass(w, cfg, tok_d, dur_d, T, want_attn, args, mel_ref):
     return res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher's environment: starts N ranks of this same command as a child job
+    (python -m torch.distributed.run --standalone: the agent's own TCP store on a port it binds itself, one process per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE in the ranks' environment), relays rank 0's JSON line and fails unless that line reports
+    n_gpus == N.  A child process, never an exec: this process has not touched the GPU and goes on waiting."""
+    import subprocess
+    cmd = [sys.executable, '-u', '-m', 'torch.distributed.run', '--standalone', '--nnodes=1', '--nproc-per-node', str(n),
+           '--local-addr', '127.0.0.1', os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, min(16, (os.cpu_count() or 1)) // n)))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    for l in r.stdout.splitlines():
+        if not l.startswith('{'):
+            print(l, file=sys.stderr)
+    if r.returncode != 0 or not lines:
+        print(f'bench.py: the {n}-rank job failed (exit {r.returncode}, {len(lines)} JSON line(s))', file=sys.stderr)
+        raise SystemExit(r.returncode or 1)
+    line = json.loads(lines[-1])
+    print(lines[-1], flush=True)
+    if line.get('n_gpus') != n:
+        print(f"bench.py: asked for {n} ranks, the line reports n_gpus = {line.get('n_gpus')}", file=sys.stderr)
+        raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -668,7 +820,12 @@ def main():
     ap.add_argument('--no-roofline', action='store_true',
                     help='skip the per-kernel timing pass (clean kernel statistics under rocprofv3); roofline is then null')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel timing table to stderr')
-    ap.add_argument('--workload', default='forward', choices=['forward', 'gst', 'train', 'train_wavernn', 'train_ar', 'predict', 'config1'],
+    ap.add_argument('--train-batch', type=int, default=32,
+                    help='utterances per GPU of the data-parallel training block that a default run with --gpus N > 1 adds '
+                         '(BASELINE config 5: 32 per GPU, global 256 at N = 8); 0 skips the block')
+    ap.add_argument('--elems', type=int, default=19_178_529, help='--workload exchange: float32 elements of the gradient buffer')
+    ap.add_argument('--workload', default='forward',
+                    choices=['forward', 'gst', 'train', 'train_wavernn', 'train_ar', 'predict', 'config1', 'exchange'],
                     help="forward: ForwardTransformer (BASELINE config 2); gst: GST reference encoder + teacher-forced "
                          "AutoregressiveTransformer (config 3; use --batch 32); train: ForwardTransformer training step, "
                          "forward + backward + gradient all-reduce + Adam (config 5; use --batch 32)")
@@ -683,8 +840,18 @@ def main():
 
     if args.workload == 'config1':
         return config1_cpu_seconds(args)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args.gpus)            # before anything here has touched the GPU
     from estts import parallel
     rank, world, local_rank = parallel.env_ranks()
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)')
+    if args.workload == 'exchange':
+        dist = None
+        parallel.init_distributed(os.environ.get('ESTTS_DIST_BACKEND') or None)
+        if world > 1:
+            import torch.distributed as dist
+        return exchange_bench(args, rank, world, dist)
     # (ESTTS_DIST_BACKEND=gloo with more ranks than GPUs rehearses the multi-rank paths on a one-GPU box; with gloo the
     # ForwardTransformer trainer exchanges its gradients after the backward pass instead of overlapped with it, see
     # parallel.GradientOverlap.  The driver's runs have one GPU per rank and use RCCL.)
@@ -770,10 +937,10 @@ def main():
     # (the traced step's outputs must stay referenced while its launches are replayed: torch.cuda.graph() empties
     # the allocator cache on entry, which would unmap any buffer that has been freed in the meantime)
     ops.start_trace()
-    traced_out = step()
+    n_launches, traced_out = launches_of(step)
     trace = ops.stop_trace()
     torch.cuda.synchronize()
-    roofline, n_launches = roofline_from_trace(trace, args.kernel_table, rank)
+    roofline, _ = roofline_from_trace(trace, args.kernel_table, rank)
     del traced_out, trace
 
     # whole-forward timing
@@ -811,7 +978,13 @@ def main():
     ms = dt * 1e3 / args.steps
     value = world * B * T / (dt / args.steps)
 
+    train_line = None
+    if world > 1 and args.workload == 'forward' and args.train_batch > 0:
+        # the data-parallel training step of BASELINE config 5 on the same ranks (its own model and buffers)
+        train_line = train_measure(args, rank, world, dist, args.train_batch, 10, 3, False)
+
     if rank == 0:
+        finish_roofline(roofline, ms)
         line = {
             'metric': 'mel-frames/sec (fwd TransformerTTS)', 'value': value, 'unit': 'mel-frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
@@ -824,6 +997,12 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
+        if train_line is not None:
+            keep = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'steps_per_s', 'algorithmic_tflops', 'scaling',
+                    'loss_first_step', 'loss_last_step', 'exchange', 'roofline')
+            line['train'] = {k: train_line[k] for k in keep if k in train_line}
+            line['train'].update(workload=train_line['config']['workload'], global_batch=train_line['config']['global_batch'],
+                                 launches_per_step=train_line['config']['launches_per_step'])
         if world == 1 and args.workload == 'forward' and graph is not None and not args.no_in_flight:
             line['in_flight'] = in_flight_pass(w, cfg, tok_d, dur_d, T, want_attn, args, out['mel'])
         if world == 1 and not args.no_wavernn:

@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -146,6 +146,7 @@ class WavernnSampleArgs(C.Structure):
 SIGNATURES = {
     'estts_abi_version': (_i32, []),
     'estts_last_error': (C.c_char_p, []),
+    'estts_launch_count': (C.c_longlong, []),
     'estts_gemm': (_i32, [C.POINTER(GemmArgs), _vp]),
     'estts_gemm_noalloc': (_i32, [C.POINTER(GemmArgs), _vp]),
     'estts_attention': (_i32, [C.POINTER(AttentionArgs), _vp]),

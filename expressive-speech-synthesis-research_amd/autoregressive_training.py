@@ -231,6 +231,8 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         self.dec_names = [f'Decoder_DenseBlock{i + 1}_CrossAttention' if i < nd else f'Decoder_ConvBlock{i - nd + 1}_CrossAttention'
                           for i in range(len(cfg['decoder_num_heads']))]
         self.gst = _Gst(st, 'style_encoder', cfg) if self.system_type in ('speaker_style_text', 'style_text') else None
+        if self.gst is not None and (3 * self.gst.u > ops.GRU_FUSED_MAX_H or self.gst.u % 16):
+            self.fused_gru = False       # the one-launch backward step holds K = 3 * units <= 1536; larger cells: two launches
         self.prenet1 = _Layer(st, 'decoder_prenet.d1', act='relu')
         self.prenet2 = _Layer(st, 'decoder_prenet.d2', act='relu')
         self.stop = _Layer(st, 'decoder_postnet.stop_linear')
@@ -563,14 +565,19 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
         return self._stack_fwd(self.enc_blocks, cat0, B, N, key_mask, de, tape, enc_attn, self.enc_names), key_mask
 
     def train_step(self, tts_mel, tts_phonemes, tts_stop, tts_speaker=None, train_text_encoder=True, train_style_encoder=True,
-                   train_decoder=True, apply=True, use_style_loss=False):
+                   train_decoder=True, apply=True, use_style_loss=False, global_frames=None):
         """The TTS half of train_models_step (traning_steps.py:22-56).  use_style_loss: the style encoder runs a second time
         over the model's own post-net output and the mean squared distance of the two style embeddings joins the loss
         (traning_steps.py:41-49).
         tts_mel [B, T + 1, C] (start / end vectors included), tts_phonemes [B, N] int, tts_stop [B, T + 1] int,
         tts_speaker [B, 1, speaker_embed_dim] or None.  Returns the reference's model_out entries that exist after the TTS
         half: final_output, mel_linear, stop_prob, decoder_attention, text_encoder_attention, text_enc_output, tts_loss,
-        loss, losses, reduced_target."""
+        loss, losses, reduced_target.
+        global_frames (data-parallel runs): the padded number of target frames (T) of the GLOBAL batch, i.e. the largest over
+        all ranks.  The three losses divide by the padded element count, so a rank whose shard pads to fewer frames would
+        weigh its utterances more; with global_frames every rank divides by the global batch's count and the summed
+        gradient is that of the loss over the concatenated batch.  The returned losses are scaled the same way (their mean
+        over the ranks is the global loss)."""
         dev, C, r = self.device, self.mel_channels, self.r
         tokens = torch.as_tensor(tts_phonemes, device=dev).to(torch.int32).contiguous()
         B, N = tokens.shape
@@ -584,6 +591,7 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             raise ValueError('sequence exceeds the positional-encoding table')
         self._infer = None
         self._site = 0
+        T.SumSlots.step_begin(self.device, self)      # (clears sums a failed step may have left without a consumer)
         self._seed_now = (self.seed * 1000003 + self.iterations * 7919 + 12345 + self.rank * 0x9E3779B1) & 0xFFFFFFFF
         self._host_rng = np.random.default_rng(self._seed_now)
         st, de, dd = self.store, self.de, self.dd
@@ -642,10 +650,11 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             T.wgrad(tg2, dp1, self.prenet1.dk, M=Md, precision=self.backward_precision)
 
         # ---- decoder blocks (layers.py:357-376)
-        dec_tape = []
+        dec_tape, dec_tape_marks = [], []        # dec_tape_marks[i]: entries of dec_tape before block i
         n_blocks = len(self.dec_blocks)
         with self._submode(train_decoder):
             for i, (S, Cx, tail) in enumerate(self.dec_blocks):
+                dec_tape_marks.append(len(dec_tape))
                 cat2 = self._empty(Md, 2 * dd)
                 self._sarn_fwd(S, cat, B, Tq, dec_mask, cat2[:, :dd], dec_tape, causal=True)
                 x2 = self._empty(Md, dd)
@@ -689,17 +698,22 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
 
         final_l, mel_l, stop_l = head(final, C), head(mel, C), head(stop4, 3)
         labels = tar_stop.reshape(Ml).contiguous()
+        rank_share = 1.0
+        if global_frames is not None:
+            if int(global_frames) < mel_len:
+                raise ValueError(f'global_frames {global_frames} is shorter than this rank\'s batch ({mel_len} frames)')
+            rank_share = mel_len / float(global_frames)
         losses = torch.zeros(3, dtype=torch.float32, device=dev)
         ops.masked_mae(target2, final_l, losses[0:1])
         dstop_l = torch.zeros(Ml, 4, dtype=torch.float32, device=dev)
         T.scaled_xent(stop_l, labels, losses[1:2], dlogits=dstop_l[:, :3], index=2, scaling=self.stop_scaling,
-                      scale=self.loss_weights[1] / Ml)
+                      scale=self.loss_weights[1] * rank_share / Ml)
         ops.masked_mae(target2, mel_l, losses[2:3])
         if self.gate_log is not None:
             self.gate_log += [torch.sign(final_l - target2), torch.sign(mel_l - target2)]
         lw = self.loss_weights
         # (scaled_xent was given scale = weight / M for its gradient; its loss value carries the weight too)
-        loss_vals = torch.stack([losses[0], losses[1] / lw[1], losses[2]])
+        loss_vals = torch.stack([losses[0] * rank_share, losses[1] / lw[1], losses[2] * rank_share])
         tts_loss = loss_vals[0] * lw[0] + loss_vals[1] * lw[1] + loss_vals[2] * lw[2]
         if style_loss is not None:
             tts_loss = tts_loss + style_loss[0]
@@ -714,23 +728,34 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             return g.view(Mt, width)
 
         dfinal_l = self._empty(Ml, C)
-        T.masked_mae_bwd(target2, final_l, dfinal_l, lw[0])
+        T.masked_mae_bwd(target2, final_l, dfinal_l, lw[0] * rank_share)
         dmel_l = self._empty(Ml, C)
-        T.masked_mae_bwd(target2, mel_l, dmel_l, lw[2])
+        T.masked_mae_bwd(target2, mel_l, dmel_l, lw[2] * rank_share)
         dfinal = spread(dfinal_l, C)
         if style_loss is not None:             # the second style pass read the whole post-net output
             if dfinal is dfinal_l:
                 dfinal = dfinal_l.clone()
             T.axpby(style_tape[0](d_g2).view(Mt, C), dfinal, alpha=1.0, beta=1.0, M=Mt, D=C)
+        # the gradient buffer is in forward order (text encoder, style encoder, prenet, decoder blocks, projections, post-net):
+        # every finished stage hands its tail to the all-reduce on the communication stream, as in the ForwardTransformer
+        # trainer.  With the style loss the style encoder's gradients are complete only after its second backward pass
+        # (gst_tape below); its offset lies under everything that is reported before that.
+        overlap = self._new_overlap()
         dmel = post_tape[0](dfinal)
         T.axpby(spread(dmel_l, C), dmel, alpha=1.0, beta=1.0, M=Mt, D=C)
         self._lin_bwd(mel, self.stop, spread(dstop_l, 4), Mt, dx=dmel, accumulate=True)
         d_dec = self._empty(Md, dd)
         self._lin_bwd(dec_out, F, dmel.view(Md, r * C), Md, dx=d_dec)
+        overlap.ready(self._first_offset('final_proj_mel.'))
         g = d_dec
-        for bw in reversed(dec_tape):
+        marks = self._decoder_tape_marks(dec_tape_marks, len(dec_tape))
+        for j, bw in enumerate(reversed(dec_tape)):
             g = bw(g)
+            blk = marks.get(len(dec_tape) - 1 - j)
+            if blk is not None:
+                overlap.ready(self._first_offset(f'decoder.block{blk}.'))
         prenet_backward(g)
+        overlap.ready(self._first_offset('decoder_prenet.'))
         if self.gst is not None:           # the style embedding was tiled over the tokens: its gradient is the sum over them
             d_gst = torch.zeros(B, sd, dtype=torch.float32, device=dev)
             d_enc3 = d_enc.view(B, N, self.enc_dim)
@@ -739,13 +764,14 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
             if style_loss is not None:         # d style_loss / d (first embedding) = -d style_loss / d (second embedding)
                 T.axpby(d_g2, d_gst, alpha=-1.0, beta=1.0, M=B, D=sd)
             gst_tape[0](d_gst)
+            overlap.ready(self._first_offset('style_encoder.'))
         g = d_enc[:, :de].contiguous()
         for bw in reversed(enc_tape):
             g = bw(g)
-        overlap = parallel.GradientOverlap(self.store.grad, self.bucket_elems, self.pg, self._comm)
         overlap.finish()
         if apply:
             self._apply_gradients()
+        T.SumSlots.step_end(self.device)
         return {'final_output': final.view(B, Tt, C), 'mel_linear': mel.view(B, Tt, C), 'stop_prob': stop4.view(B, Tt, 4)[:, :, :3],
                 'decoder_attention': dec_attn, 'text_encoder_attention': enc_attn, 'text_enc_output': text_out.reshape(B, N, de),
                 'gst_output': None if gst_out is None else gst_out.view(B, 1, sd),
@@ -753,6 +779,12 @@ class AutoregressiveTransformerTrainer(ForwardTransformerTrainer):
                 'tts_loss': tts_loss, 'style_loss': 0 if style_loss is None else style_loss[0], 'loss': tts_loss,
                 'losses': {'output': loss_vals[0], 'stop_prob': loss_vals[1], 'mel_linear': loss_vals[2]},
                 'reduced_target': tar_mel}
+
+    @staticmethod
+    def _decoder_tape_marks(starts, n):
+        """{index of the first tape entry of decoder block i: i}: once the backward pass has run that entry, block i's
+        variables (and everything after them in the buffer) are final."""
+        return {s: i for i, s in enumerate(starts) if s < n}
 
     def encode(self, phonemes, reduced_mel, speaker=None):
         """call_encoder in training mode without gradients (train_models_step's separate batch for the mutual-information

@@ -100,6 +100,10 @@ _WAVERNN = {
     'voc_pad': 2,
     'voc_batch_size': 64,
     'voc_lr': 1e-4,
+    'voc_checkpoint_every': 25_000,    # WaveRNN/hparams.py:42-45 (training cadence)
+    'voc_gen_at_checkpoint': 5,
+    'voc_total_steps': 2_000_000,
+    'voc_model_id': 'test',
     'voc_seq_len': 1000,
     'voc_gen_batched': True,
     'voc_target': 11_000,

@@ -144,7 +144,7 @@ extern "C" int estts_alignment_lengths(const float* mels, int64_t ldm, int32_t T
                                        int32_t* mel_len, int32_t* phon_len, void* stream) {
     ESTTS_CHECK_ARG(mels && tokens && mel_len && phon_len && B > 0 && T > 0 && C > 0 && N > 0 && ldm >= C,
                     "estts_alignment_lengths: bad arguments");
-    hipLaunchKernelGGL(alignment_lengths_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mels, (long)ldm, T, C, tokens, N, mel_len,
+    ESTTS_LAUNCH(alignment_lengths_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mels, (long)ldm, T, C, tokens, N, mel_len,
                        phon_len);
     ESTTS_CHECK_LAUNCH("estts_alignment_lengths");
     return 0;
@@ -155,7 +155,7 @@ extern "C" int estts_alignment_stats(const float* attn, int32_t B, int32_t H, in
     ESTTS_CHECK_ARG(attn && mel_len && phon_len && score && colsum && B > 0 && H > 0 && Lq > 0 && Lk > 0,
                     "estts_alignment_stats: bad arguments");
     ESTTS_CHECK_ARG(B <= 65535, "estts_alignment_stats: B = %d exceeds 65535", B);
-    hipLaunchKernelGGL(alignment_stats_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, attn, H, Lq, Lk, mel_len, phon_len, score,
+    ESTTS_LAUNCH(alignment_stats_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, attn, H, Lq, Lk, mel_len, phon_len, score,
                        colsum);
     ESTTS_CHECK_LAUNCH("estts_alignment_stats");
     return 0;
@@ -168,7 +168,7 @@ extern "C" int estts_alignment_peaks(const float* attn, int32_t B, int32_t H, in
                         Lk > 0,
                     "estts_alignment_peaks: bad arguments");
     ESTTS_CHECK_ARG(B <= 65535, "estts_alignment_peaks: B = %d exceeds 65535", B);
-    hipLaunchKernelGGL(alignment_peaks_kernel, dim3((Lq + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, attn, H, Lq, Lk, mel_len,
+    ESTTS_LAUNCH(alignment_peaks_kernel, dim3((Lq + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, attn, H, Lq, Lk, mel_len,
                        phon_len, score, weighted, peak_idx, peak_val, peak_ties, best_head);
     ESTTS_CHECK_LAUNCH("estts_alignment_peaks");
     return 0;

@@ -637,13 +637,13 @@ int launch_wide(const estts_attention_args& a, hipStream_t st) {
     dim3 grid((unsigned)((long)((a.Lq + 63) / 64) * a.H * a.B));
     if (a.attn && a.Lk <= 128) {
         if (a.precision == 3)
-            hipLaunchKernelGGL((attention_wide_kernel<DH, 2, 4>), grid, dim3(256), 0, st, a);
+            ESTTS_LAUNCH((attention_wide_kernel<DH, 2, 4>), grid, dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL((attention_wide_kernel<DH, 1, 4>), grid, dim3(256), 0, st, a);
+            ESTTS_LAUNCH((attention_wide_kernel<DH, 1, 4>), grid, dim3(256), 0, st, a);
     } else if (a.precision == 3)
-        hipLaunchKernelGGL((attention_wide_kernel<DH, 2>), grid, dim3(256), 0, st, a);
+        ESTTS_LAUNCH((attention_wide_kernel<DH, 2>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((attention_wide_kernel<DH, 1>), grid, dim3(256), 0, st, a);
+        ESTTS_LAUNCH((attention_wide_kernel<DH, 1>), grid, dim3(256), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_attention");
     return 0;
 }
@@ -652,9 +652,9 @@ template <int DH, int MAXT, int NW = 4>
 int launch_t(const estts_attention_args& a, hipStream_t st) {
     dim3 grid((a.Lq + 15) / 16, a.H, a.B);
     if (a.precision == 3)
-        hipLaunchKernelGGL((attention_kernel<DH, 2, MAXT, NW>), grid, dim3(NW * 64), 0, st, a);
+        ESTTS_LAUNCH((attention_kernel<DH, 2, MAXT, NW>), grid, dim3(NW * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((attention_kernel<DH, 1, MAXT, NW>), grid, dim3(NW * 64), 0, st, a);
+        ESTTS_LAUNCH((attention_kernel<DH, 1, MAXT, NW>), grid, dim3(NW * 64), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_attention");
     return 0;
 }

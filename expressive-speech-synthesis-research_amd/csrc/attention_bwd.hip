@@ -470,15 +470,15 @@ void launch_side(const estts_attention_bwd_args& a, hipStream_t st) {
     const long wide = (long)((L_own + 63) / 64) * BH;
     if (wide >= 192) {   // enough 64-row workgroups to fill the chip
         if (a.precision == 3)
-            hipLaunchKernelGGL((attention_bwd_wide_kernel<DH, 2, OWN_Q>), dim3((unsigned)wide), dim3(256), 0, st, a);
+            ESTTS_LAUNCH((attention_bwd_wide_kernel<DH, 2, OWN_Q>), dim3((unsigned)wide), dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL((attention_bwd_wide_kernel<DH, 1, OWN_Q>), dim3((unsigned)wide), dim3(256), 0, st, a);
+            ESTTS_LAUNCH((attention_bwd_wide_kernel<DH, 1, OWN_Q>), dim3((unsigned)wide), dim3(256), 0, st, a);
     } else {
         const dim3 grid((unsigned)((long)((L_own + 15) / 16) * BH));
         if (a.precision == 3)
-            hipLaunchKernelGGL((attention_bwd_kernel<DH, 2, OWN_Q>), grid, dim3(256), 0, st, a);
+            ESTTS_LAUNCH((attention_bwd_kernel<DH, 2, OWN_Q>), grid, dim3(256), 0, st, a);
         else
-            hipLaunchKernelGGL((attention_bwd_kernel<DH, 1, OWN_Q>), grid, dim3(256), 0, st, a);
+            ESTTS_LAUNCH((attention_bwd_kernel<DH, 1, OWN_Q>), grid, dim3(256), 0, st, a);
     }
 }
 
@@ -508,7 +508,7 @@ extern "C" int estts_attention_bwd(const estts_attention_bwd_args* args, void* s
                     "estts_attention_bwd: pointers not 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long rows = (long)a.B * a.Lq;
-    hipLaunchKernelGGL(attention_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
+    ESTTS_LAUNCH(attention_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
     switch (a.depth) {
         case 32: return launch<32>(a, st);
         case 64: return launch<64>(a, st);

@@ -120,14 +120,14 @@ extern "C" int estts_gemm_f32(const float* A, int64_t lda, const float* W, int64
     ESTTS_CHECK_ARG(ldw >= K && ldc >= N, "estts_gemm_f32: ldw < K or ldc < N");
     dim3 grid((N + FT - 1) / FT, (M + FT - 1) / FT);
     ESTTS_CHECK_ARG(grid.y <= 65535, "estts_gemm_f32: too many rows");
-    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, (long)lda, W, (long)ldw, C, (long)ldc, M, N, K);
+    ESTTS_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, A, (long)lda, W, (long)ldw, C, (long)ldc, M, N, K);
     ESTTS_CHECK_LAUNCH("estts_gemm_f32");
     return 0;
 }
 
 extern "C" int estts_spec_magnitude(const float* reim, int64_t ld, int32_t nb, float* mag, int64_t ldm, int32_t M, void* stream) {
     ESTTS_CHECK_ARG(reim && mag && M > 0 && nb > 0 && ld >= 2 * (int64_t)nb && ldm >= nb, "estts_spec_magnitude: bad arguments");
-    hipLaunchKernelGGL(spec_magnitude_kernel, dim3(ew_blocks((long)M * nb)), dim3(256), 0, (hipStream_t)stream, reim, (long)ld, nb, mag,
+    ESTTS_LAUNCH(spec_magnitude_kernel, dim3(ew_blocks((long)M * nb)), dim3(256), 0, (hipStream_t)stream, reim, (long)ld, nb, mag,
                        (long)ldm, M);
     ESTTS_CHECK_LAUNCH("estts_spec_magnitude");
     return 0;
@@ -138,7 +138,7 @@ extern "C" int estts_mel_normalize(const float* x, int64_t ldx, float* out, int6
     ESTTS_CHECK_ARG(x && out && M > 0 && C > 0 && ldx >= C && ldo >= C, "estts_mel_normalize: bad arguments");
     ESTTS_CHECK_ARG(mode == 0 || mode == 1, "estts_mel_normalize: mode must be 0 (dB) or 1 (log)");
     ESTTS_CHECK_ARG(mode == 1 || min_level_db < 0.0f, "estts_mel_normalize: min_level_db must be negative");
-    hipLaunchKernelGGL(mel_normalize_kernel, dim3(ew_blocks((long)M * C)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, out, (long)ldo,
+    ESTTS_LAUNCH(mel_normalize_kernel, dim3(ew_blocks((long)M * C)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, out, (long)ldo,
                        M, C, mode, ref_level_db, min_level_db, scale, shift);
     ESTTS_CHECK_LAUNCH("estts_mel_normalize");
     return 0;

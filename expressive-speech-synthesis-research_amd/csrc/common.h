@@ -24,6 +24,15 @@ void estts_set_error(const char* fmt, ...);
         }                                       \
     } while (0)
 
+// every kernel launch of the library goes through this macro, which counts it (estts_launch_count(): the benchmark's
+// launches-per-step figure)
+extern long long g_estts_launches;
+#define ESTTS_LAUNCH(...)                                                       \
+    do {                                                                         \
+        __atomic_fetch_add(&g_estts_launches, 1LL, __ATOMIC_RELAXED);            \
+        hipLaunchKernelGGL(__VA_ARGS__);                                         \
+    } while (0)
+
 #define ESTTS_CHECK_LAUNCH(name)                                                 \
     do {                                                                         \
         hipError_t e__ = hipGetLastError();                                      \

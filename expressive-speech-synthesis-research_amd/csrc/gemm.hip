@@ -704,12 +704,26 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
 
 // ------------------------------------------------------------------------------------------------------
 thread_local const char* g_entry = "estts_gemm";   // entry point named in the split-K size error
+// estts_gemm_noalloc: tickets to clear on the launch stream in front of a launch that really splits (null otherwise)
+thread_local void* g_clear_tickets = nullptr;
+thread_local size_t g_clear_bytes = 0;
 
 bool splitk_fits(const estts_gemm_args& a, dim3 grid, long tile_elems) {
     const long need = (long)grid.z * grid.x * grid.y * tile_elems * sizeof(float);
     if (!a.ws || !a.counters || need > a.ws_bytes || (long)grid.x * grid.y > a.n_counters) {
         estts_set_error("%s: split-K of this launch needs %ld scratch bytes and %ld tickets, the caller's buffer holds %ld and %d",
                         g_entry, need, (long)grid.x * grid.y, (long)a.ws_bytes, a.n_counters);
+        return false;
+    }
+    return true;
+}
+
+// the static tickets must be zero when a splitting kernel starts; a finished launch leaves them zero, an aborted one may not
+bool clear_static_tickets(hipStream_t st) {
+    if (!g_clear_tickets) return true;
+    const hipError_t e = hipMemsetAsync(g_clear_tickets, 0, g_clear_bytes, st);
+    if (e != hipSuccess) {
+        estts_set_error("%s: clearing the tickets failed: %s", g_entry, hipGetErrorString(e));
         return false;
     }
     return true;
@@ -727,9 +741,9 @@ int operand_kind(const estts_gemm_args& a) {
 template <int NW, int KIND>
 int launch_small_nw(const estts_gemm_args& a, dim3 grid, hipStream_t st) {
     if (a.precision == 3)
-        hipLaunchKernelGGL((gemm_small_kernel<3, NW, KIND>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
+        ESTTS_LAUNCH((gemm_small_kernel<3, NW, KIND>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
     else
-        hipLaunchKernelGGL((gemm_small_kernel<1, NW, KIND>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
+        ESTTS_LAUNCH((gemm_small_kernel<1, NW, KIND>), grid, dim3(NW * 64), 0, st, a, (int)grid.z);
     ESTTS_CHECK_LAUNCH("estts_gemm");
     return 0;
 }
@@ -737,6 +751,7 @@ int launch_small_nw(const estts_gemm_args& a, dim3 grid, hipStream_t st) {
 int launch_small(const estts_gemm_args& a, int splitk, int nw, hipStream_t st) {
     dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, splitk);
     if (splitk > 1 && !splitk_fits(a, grid, 1024)) return -1;
+    if (splitk > 1 && !clear_static_tickets(st)) return -2;
     if (nw == 0) {
         // measured on MI355X: 8 waves pay from about 12 K-steps up, but only while the launch has fewer workgroups than
         // the chip has CUs (beyond that 4-wave workgroups fill the SIMDs better: 832 x 1536 x 512 runs 19 vs 22 us);
@@ -758,10 +773,11 @@ template <int BM, int BN, int WM, int WN>
 int launch(const estts_gemm_args& a, int splitk, hipStream_t st) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splitk);
     if (splitk > 1 && !splitk_fits(a, grid, BM * BN)) return -1;
+    if (splitk > 1 && !clear_static_tickets(st)) return -2;
     if (a.precision == 3)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, a, splitk);
+        ESTTS_LAUNCH((gemm_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, a, splitk);
     else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, st, a, splitk);
+        ESTTS_LAUNCH((gemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, st, a, splitk);
     ESTTS_CHECK_LAUNCH("estts_gemm");
     return 0;
 }
@@ -770,9 +786,9 @@ template <int TM, int TN, int OCC, int KIND>
 int launch_big_d(const estts_gemm_args& a, hipStream_t st) {
     dim3 grid((a.N + 64 * TN - 1) / (64 * TN), (a.M + 64 * TM - 1) / (64 * TM), a.batch > 1 ? a.batch : 1);
     if (a.precision == 3)
-        hipLaunchKernelGGL((gemm_big_kernel<3, TM, TN, OCC, KIND>), grid, dim3(256), 0, st, a);
+        ESTTS_LAUNCH((gemm_big_kernel<3, TM, TN, OCC, KIND>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((gemm_big_kernel<1, TM, TN, OCC, KIND>), grid, dim3(256), 0, st, a);
+        ESTTS_LAUNCH((gemm_big_kernel<1, TM, TN, OCC, KIND>), grid, dim3(256), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_gemm");
     return 0;
 }
@@ -940,13 +956,23 @@ namespace {
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};   // device address of `scratch` on each GPU (every GPU holds its own copy)
 
-// Device address of this GPU's copy of `scratch`, looked up once per device with that device current.
-int scratch_of_current_device(unsigned char** out) {
+// Device address of this GPU's copy of `scratch`, looked up once per device with that device current.  The stream must
+// belong to the current device: another GPU's stream would be handed this GPU's array.
+int scratch_of_current_device(unsigned char** out, hipStream_t stream) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
         estts_set_error("estts_gemm_noalloc: hipGetDevice failed or device index %d out of range: %s", dev, hipGetErrorString(e));
         return -2;
+    }
+    if (stream) {
+        hipDevice_t sdev = -1;
+        e = hipStreamGetDevice(stream, &sdev);
+        if (e == hipSuccess && (int)sdev != dev) {
+            estts_set_error("estts_gemm_noalloc: the stream belongs to device %d but device %d is current; make the stream's device "
+                            "current before the call", (int)sdev, dev);
+            return -1;
+        }
     }
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
@@ -966,21 +992,19 @@ int scratch_of_current_device(unsigned char** out) {
 extern "C" int estts_gemm_noalloc(const estts_gemm_args* args, void* stream) {
     ESTTS_CHECK_ARG(args != nullptr, "estts_gemm_noalloc: null args");
     unsigned char* ptr = nullptr;
-    const int rc = scratch_of_current_device(&ptr);
+    const int rc = scratch_of_current_device(&ptr, (hipStream_t)stream);
     if (rc != 0) return rc;
     estts_gemm_args a = *args;
     a.counters = reinterpret_cast<int32_t*>(ptr);
     a.n_counters = NOALLOC_TICKETS;
     a.ws = reinterpret_cast<float*>(ptr + NOALLOC_TICKETS * 4);
     a.ws_bytes = NOALLOC_SLAB_BYTES;
-    // the tickets must be zero when the kernel starts; a finished launch leaves them zero, an aborted one may not
-    const hipError_t e = hipMemsetAsync(ptr, 0, NOALLOC_TICKETS * 4, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        estts_set_error("estts_gemm_noalloc: clearing the tickets failed: %s", hipGetErrorString(e));
-        return -2;
-    }
+    // (the tickets are cleared on the stream only in front of a launch that splits: see clear_static_tickets)
     g_entry = "estts_gemm_noalloc";
+    g_clear_tickets = ptr;
+    g_clear_bytes = NOALLOC_TICKETS * 4;
     const int r = estts_gemm(&a, stream);
+    g_clear_tickets = nullptr;
     g_entry = "estts_gemm";
     return r;
 }

@@ -479,7 +479,7 @@ int launch_conv_s(const estts_gemm_args& a, dim3 grid, int S, int rows_staged, i
         auto kern = gemm_oneshot_conv_kernel<NSPLIT, T, 8, s_, LNCH>;                                                      \
         static bool raised[64] = {};       /* per GPU: the attribute belongs to the device's copy of the kernel */         \
         if (!allow_large_lds(reinterpret_cast<const void*>(kern), raised)) return -2;                                      \
-        hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, rows_staged, lda_s);                                         \
+        ESTTS_LAUNCH(kern, grid, dim3(512), smem, st, a, rows_staged, lda_s);                                         \
     } break;
     switch (S) {
         ESTTS_ONESHOT_CASE(1) ESTTS_ONESHOT_CASE(2) ESTTS_ONESHOT_CASE(3)
@@ -494,7 +494,7 @@ int launch_conv_s(const estts_gemm_args& a, dim3 grid, int S, int rows_staged, i
 template <int NSPLIT, int KIND, int T, int NW>
 int launch_s(const estts_gemm_args& a, dim3 grid, int S, hipStream_t st) {
 #define ESTTS_ONESHOT_CASE(s_) \
-    case s_: hipLaunchKernelGGL((gemm_oneshot_kernel<NSPLIT, KIND, T, NW, s_>), grid, dim3(NW * 64), 0, st, a); break;
+    case s_: ESTTS_LAUNCH((gemm_oneshot_kernel<NSPLIT, KIND, T, NW, s_>), grid, dim3(NW * 64), 0, st, a); break;
     switch (S) {
         ESTTS_ONESHOT_CASE(1) ESTTS_ONESHOT_CASE(2) ESTTS_ONESHOT_CASE(3)
         ESTTS_ONESHOT_CASE(4) ESTTS_ONESHOT_CASE(5) ESTTS_ONESHOT_CASE(6)

@@ -402,10 +402,10 @@ int launch_wgrad_conv(const estts_gemm_args& ga, const estts_wgrad_args& a, hipS
     ESTTS_CHECK_ARG(total < (1L << 30), "estts_gemm_wgrad: too many workgroups");
     dim3 grid((unsigned)((total + 7) / 8 * 8));
     if (a.precision == 3)
-        hipLaunchKernelGGL((wgrad_conv_kernel<3, TAPS>), grid, dim3(256), 0, st, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
+        ESTTS_LAUNCH((wgrad_conv_kernel<3, TAPS>), grid, dim3(256), 0, st, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
                            ctiles, ntiles, splits);
     else
-        hipLaunchKernelGGL((wgrad_conv_kernel<1, TAPS>), grid, dim3(256), 0, st, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
+        ESTTS_LAUNCH((wgrad_conv_kernel<1, TAPS>), grid, dim3(256), 0, st, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
                            ctiles, ntiles, splits);
     ESTTS_CHECK_LAUNCH("estts_gemm_wgrad");
     return 0;
@@ -469,10 +469,10 @@ extern "C" int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream) {
     ESTTS_CHECK_ARG(total < (1L << 30), "estts_gemm_wgrad: too many workgroups");
     dim3 grid((unsigned)((total + 7) / 8 * 8));
     if (a.precision == 3)
-        hipLaunchKernelGGL((wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
+        ESTTS_LAUNCH((wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
                            ktiles, ntiles, splits);
     else
-        hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
+        ESTTS_LAUNCH((wgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
                            ktiles, ntiles, splits);
     ESTTS_CHECK_LAUNCH("estts_gemm_wgrad");
     return 0;

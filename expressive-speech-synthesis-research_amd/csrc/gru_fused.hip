@@ -191,8 +191,8 @@ int launch(const estts_gru_fused_args& a, const estts_gru_fused_args* second, hi
     dim3 grid(a.H / 16, ((a.M > b.M ? a.M : b.M) + 15) / 16, second ? 2 : 1);
 #define ESTTS_GRU_CASE(SV)                                                                                        \
     case SV:                                                                                                      \
-        if (FWD) hipLaunchKernelGGL((gru_fused_fwd_kernel<NSPLIT, SV>), grid, dim3(NW * 64), 0, st, a, b);      \
-        else hipLaunchKernelGGL((gru_fused_bwd_kernel<NSPLIT, SV>), grid, dim3(NW * 64), 0, st, a, b);          \
+        if (FWD) ESTTS_LAUNCH((gru_fused_fwd_kernel<NSPLIT, SV>), grid, dim3(NW * 64), 0, st, a, b);      \
+        else ESTTS_LAUNCH((gru_fused_bwd_kernel<NSPLIT, SV>), grid, dim3(NW * 64), 0, st, a, b);          \
         break;
     switch (s) {
         ESTTS_GRU_CASE(1)
@@ -202,8 +202,8 @@ int launch(const estts_gru_fused_args& a, const estts_gru_fused_args* second, hi
         ESTTS_GRU_CASE(6)
         default:
             if (s == 5) {
-                if (FWD) hipLaunchKernelGGL((gru_fused_fwd_kernel<NSPLIT, 6>), grid, dim3(NW * 64), 0, st, a, b);
-                else hipLaunchKernelGGL((gru_fused_bwd_kernel<NSPLIT, 6>), grid, dim3(NW * 64), 0, st, a, b);
+                if (FWD) ESTTS_LAUNCH((gru_fused_fwd_kernel<NSPLIT, 6>), grid, dim3(NW * 64), 0, st, a, b);
+                else ESTTS_LAUNCH((gru_fused_bwd_kernel<NSPLIT, 6>), grid, dim3(NW * 64), 0, st, a, b);
                 break;
             }
             estts_set_error("estts_gru_fused: H = %d is beyond one launch (H <= 1536 forward, 3 H <= 1536 backward)", a.H);

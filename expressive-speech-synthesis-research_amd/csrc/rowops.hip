@@ -15,6 +15,8 @@ void estts_set_error(const char* fmt, ...) {
 
 extern "C" const char* estts_last_error(void) { return g_err; }
 extern "C" int estts_abi_version(void) { return ESTTS_ABI_VERSION; }
+long long g_estts_launches = 0;
+extern "C" long long estts_launch_count(void) { return __atomic_load_n(&g_estts_launches, __ATOMIC_RELAXED); }
 
 namespace {
 
@@ -221,10 +223,10 @@ bool launch_rownorm_fast(const estts_rownorm_args& a, hipStream_t st) {
     const dim3 grid((a.M + 4 * RPW - 1) / (4 * RPW));
     const int key = (a.ga ? 4 : 0) | (a.x ? 2 : 0) | (a.gb ? 1 : 0);
     switch (key) {
-        case 7: hipLaunchKernelGGL((rownorm_fast_kernel<NCH, true, true, true, RPW>), grid, dim3(256), 0, st, a); return true;
-        case 3: hipLaunchKernelGGL((rownorm_fast_kernel<NCH, false, true, true, RPW>), grid, dim3(256), 0, st, a); return true;
-        case 6: hipLaunchKernelGGL((rownorm_fast_kernel<NCH, true, true, false, RPW>), grid, dim3(256), 0, st, a); return true;
-        case 4: hipLaunchKernelGGL((rownorm_fast_kernel<NCH, true, false, false, RPW>), grid, dim3(256), 0, st, a); return true;
+        case 7: ESTTS_LAUNCH((rownorm_fast_kernel<NCH, true, true, true, RPW>), grid, dim3(256), 0, st, a); return true;
+        case 3: ESTTS_LAUNCH((rownorm_fast_kernel<NCH, false, true, true, RPW>), grid, dim3(256), 0, st, a); return true;
+        case 6: ESTTS_LAUNCH((rownorm_fast_kernel<NCH, true, true, false, RPW>), grid, dim3(256), 0, st, a); return true;
+        case 4: ESTTS_LAUNCH((rownorm_fast_kernel<NCH, true, false, false, RPW>), grid, dim3(256), 0, st, a); return true;
         default: return false;
     }
 }
@@ -373,7 +375,7 @@ extern "C" int estts_embed_posenc(const int32_t* tokens, const float* emb, const
     ESTTS_CHECK_ARG(B > 0 && N > 0 && D > 0 && (D & 3) == 0 && (ldo & 3) == 0 && ldo >= D, "estts_embed_posenc: bad shape");
     const long total = (long)B * N * (D >> 2);
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(embed_posenc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tokens, emb, pe, pos_scalar,
+    ESTTS_LAUNCH(embed_posenc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, tokens, emb, pe, pos_scalar,
                        out, ldo, key_mask, B * N, N, D, scale, pe_stride);
     ESTTS_CHECK_LAUNCH("estts_embed_posenc");
     return 0;
@@ -398,14 +400,14 @@ extern "C" int estts_rownorm(const estts_rownorm_args* args, void* stream) {
         if (a.D == 256) done = many ? launch_rownorm_fast<1, 2>(a, (hipStream_t)stream) : launch_rownorm_fast<1, 1>(a, (hipStream_t)stream);
         else if (a.D == 512) done = many ? launch_rownorm_fast<2, 2>(a, (hipStream_t)stream) : launch_rownorm_fast<2, 1>(a, (hipStream_t)stream);
     }
-    if (!done) hipLaunchKernelGGL(rownorm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (!done) ESTTS_LAUNCH(rownorm_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_rownorm");
     return 0;
 }
 
 extern "C" int estts_durations_cumsum(const float* dur, int32_t* cum, int32_t* totals, int32_t B, int32_t N, void* stream) {
     ESTTS_CHECK_ARG(dur && cum && totals && B > 0 && N > 0, "estts_durations_cumsum: bad arguments");
-    hipLaunchKernelGGL(durations_cumsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dur, cum, totals, N);
+    ESTTS_LAUNCH(durations_cumsum_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, dur, cum, totals, N);
     ESTTS_CHECK_LAUNCH("estts_durations_cumsum");
     return 0;
 }
@@ -415,7 +417,7 @@ extern "C" int estts_expand(const float* x, int32_t ldx, const int32_t* cum, flo
     ESTTS_CHECK_ARG(x && cum && out && B > 0 && N > 0 && T > 0 && D > 0, "estts_expand: bad arguments");
     ESTTS_CHECK_ARG((D & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= D && ldo >= D, "estts_expand: D / ld must be multiples of 4");
     const long frames = (long)B * T;
-    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, cum,
+    ESTTS_LAUNCH(expand_kernel, dim3((unsigned)((frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, cum,
                        out, ldo, frame_mask, B, N, T, D);
     ESTTS_CHECK_LAUNCH("estts_expand");
     return 0;
@@ -431,7 +433,7 @@ extern "C" int estts_conv2d_c1(const float* x, const float* w, const float* scal
     const long total = (long)B * Ho * Wo * (Cout >> 2);
     ESTTS_CHECK_ARG(total < (1L << 31) - (1L << 21), "estts_conv2d_c1: too many outputs");
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv2d_c1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, scale, bias, out, B, H, W, Ho,
+    ESTTS_LAUNCH(conv2d_c1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, scale, bias, out, B, H, W, Ho,
                        Wo, Cout, stride, pad_t, pad_l);
     ESTTS_CHECK_LAUNCH("estts_conv2d_c1");
     return 0;
@@ -439,7 +441,7 @@ extern "C" int estts_conv2d_c1(const float* x, const float* w, const float* scal
 
 extern "C" int estts_row_zero_mask(const float* x, int32_t ldx, float* mask, int32_t M, int32_t D, void* stream) {
     ESTTS_CHECK_ARG(x && mask && M > 0 && D > 0 && ldx >= D, "estts_row_zero_mask: bad arguments");
-    hipLaunchKernelGGL(row_zero_mask_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, mask, M, D);
+    ESTTS_LAUNCH(row_zero_mask_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, mask, M, D);
     ESTTS_CHECK_LAUNCH("estts_row_zero_mask");
     return 0;
 }
@@ -448,7 +450,7 @@ extern "C" int estts_masked_mae(const float* target, int32_t ldt, const float* p
                                 int32_t C, void* stream) {
     ESTTS_CHECK_ARG(target && pred && out && M > 0 && C > 0 && ldt >= C && ldp >= C, "estts_masked_mae: bad arguments");
     const int wgs = (M + 3) / 4;
-    hipLaunchKernelGGL(masked_mae_kernel, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, target, ldt, pred, ldp, out, M, C);
+    ESTTS_LAUNCH(masked_mae_kernel, dim3(wgs < 256 ? wgs : 256), dim3(256), 0, (hipStream_t)stream, target, ldt, pred, ldp, out, M, C);
     ESTTS_CHECK_LAUNCH("estts_masked_mae");
     return 0;
 }

@@ -720,7 +720,7 @@ extern "C" int estts_pack_weight(const float* src, int32_t ld_src, int32_t K, in
     const int cols = mode == 0 ? K : taps * N;
     const int rp = (rows + 63) / 64 * 64, cp = (cols + 63) / 64 * 64;
     const long total = (long)(rp / 16) * (cp / 32) * 64;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, ld_src, K, N, taps,
+    ESTTS_LAUNCH(pack_weight_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, src, ld_src, K, N, taps,
                        mode, hi, lo, rows, cols, cp / 32, total);
     ESTTS_CHECK_LAUNCH("estts_pack_weight");
     return 0;
@@ -728,7 +728,7 @@ extern "C" int estts_pack_weight(const float* src, int32_t ld_src, int32_t K, in
 
 extern "C" int estts_pack_weights(const estts_pack_job* jobs, int32_t n_jobs, int64_t total_units, void* stream) {
     ESTTS_CHECK_ARG(jobs && n_jobs > 0 && total_units > 0, "estts_pack_weights: bad arguments");
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total_units)), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs, (long)total_units);
+    ESTTS_LAUNCH(pack_weights_kernel, dim3(ew_grid(total_units)), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs, (long)total_units);
     ESTTS_CHECK_LAUNCH("estts_pack_weights");
     return 0;
 }
@@ -739,7 +739,7 @@ extern "C" int estts_affine_act(const float* z, int32_t ldz, const float* scale,
     ESTTS_CHECK_ARG(z && out && M > 0 && C > 0 && (C & 3) == 0 && (ldz & 3) == 0 && (ldo & 3) == 0 && (!R || (ldr & 3) == 0),
                     "estts_affine_act: bad arguments (C and ld must be multiples of 4)");
     ESTTS_CHECK_ARG((scale == nullptr) == (shift == nullptr), "estts_affine_act: scale and shift go together");
-    hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid((long)M * (C >> 2))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale,
+    ESTTS_LAUNCH(affine_act_kernel, dim3(ew_grid((long)M * (C >> 2))), dim3(256), 0, (hipStream_t)stream, z, ldz, scale,
                        shift, act, R, ldr, r_mod, out, ldo, M, C);
     ESTTS_CHECK_LAUNCH("estts_affine_act");
     return 0;
@@ -750,7 +750,7 @@ extern "C" int estts_bn_bwd(const float* dy, int32_t lddy, const float* z, int32
                             int32_t C, void* stream) {
     ESTTS_CHECK_ARG(dy && z && mean && rstd && gamma && dgamma && dbeta && dz, "estts_bn_bwd: null pointer");
     ESTTS_CHECK_ARG(M > 0 && C > 0 && (C & 3) == 0 && (lddy & 3) == 0 && (ldz & 3) == 0 && (lddz & 3) == 0, "estts_bn_bwd: bad shape");
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3(ew_grid((long)M * (C >> 2))), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz,
+    ESTTS_LAUNCH(bn_bwd_kernel, dim3(ew_grid((long)M * (C >> 2))), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz,
                        mean, rstd, gamma, dgamma, dbeta, dz, lddz, M, C);
     ESTTS_CHECK_LAUNCH("estts_bn_bwd");
     return 0;
@@ -769,7 +769,7 @@ extern "C" int estts_bn_bwd_slots(const float* dy, int32_t lddy, const float* z,
     int ysplit = (M + 15) / 16;          // at least 16 rows per workgroup, about 1024 workgroups
     const int cap = (1024 + gx - 1) / gx;
     if (ysplit > cap) ysplit = cap;
-    hipLaunchKernelGGL(bn_bwd_slots_kernel, dim3(gx, ysplit), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma,
+    ESTTS_LAUNCH(bn_bwd_slots_kernel, dim3(gx, ysplit), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz, mean, rstd, gamma,
                        slots, (long)slot_stride, dgamma, dbeta, dz, lddz, M, C, act, scale, shift);
     ESTTS_CHECK_LAUNCH("estts_bn_bwd_slots");
     return 0;
@@ -779,7 +779,7 @@ extern "C" int estts_dropout(const float* x, int32_t ldx, float* out, int32_t ld
                              uint32_t seed, uint32_t site, void* stream) {
     ESTTS_CHECK_ARG(x && out && M > 0 && D > 0 && (D & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "estts_dropout: bad shape");
     ESTTS_CHECK_ARG(rate >= 0.0f && rate < 1.0f, "estts_dropout: rate must be in [0, 1)");
-    hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid((long)M * (D >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, M,
+    ESTTS_LAUNCH(dropout_kernel, dim3(ew_grid((long)M * (D >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, M,
                        D, rate, seed, site);
     ESTTS_CHECK_LAUNCH("estts_dropout");
     return 0;
@@ -788,7 +788,7 @@ extern "C" int estts_dropout(const float* x, int32_t ldx, float* out, int32_t ld
 extern "C" int estts_axpby(const float* x, int32_t ldx, float alpha, float* out, int32_t ldo, float beta, int32_t M, int32_t D,
                            void* stream) {
     ESTTS_CHECK_ARG(x && out && M > 0 && D > 0 && (D & 3) == 0 && (ldx & 3) == 0 && (ldo & 3) == 0, "estts_axpby: bad shape");
-    hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid((long)M * (D >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, out,
+    ESTTS_LAUNCH(axpby_kernel, dim3(ew_grid((long)M * (D >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, out,
                        ldo, beta, M, D);
     ESTTS_CHECK_LAUNCH("estts_axpby");
     return 0;
@@ -854,7 +854,7 @@ extern "C" int estts_im2col(const float* x, float* out, int32_t ldo, int32_t B, 
                     "estts_im2col: bad arguments");
     ESTTS_CHECK_ARG((Ho - 1) * stride + kh - pad_t <= H + kh - 1 && (Wo - 1) * stride + kw - pad_l <= W + kw - 1,
                     "estts_im2col: output size does not fit the padded input");
-    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid((long)B * Ho * Wo * ldo)), dim3(256), 0, (hipStream_t)stream, x, out, ldo, B, H,
+    ESTTS_LAUNCH(im2col_kernel, dim3(ew_grid((long)B * Ho * Wo * ldo)), dim3(256), 0, (hipStream_t)stream, x, out, ldo, B, H,
                        W, C, Ho, Wo, kh, kw, stride, pad_t, pad_l);
     ESTTS_CHECK_LAUNCH("estts_im2col");
     return 0;
@@ -865,7 +865,7 @@ extern "C" int estts_col2im(const float* dp, int32_t ldp, float* dx, int32_t B, 
     ESTTS_CHECK_ARG(dp && dx && B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && kh > 0 && kw > 0 && stride > 0 &&
                         pad_t >= 0 && pad_l >= 0 && ldp >= kh * kw * C,
                     "estts_col2im: bad arguments");
-    hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dp, ldp, dx, B, H, W,
+    ESTTS_LAUNCH(col2im_kernel, dim3(ew_grid((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dp, ldp, dx, B, H, W,
                        C, Ho, Wo, kh, kw, stride, pad_t, pad_l);
     ESTTS_CHECK_LAUNCH("estts_col2im");
     return 0;
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(MI_THREADS) void mse_kernel(const float* __restrict
 
 extern "C" int estts_mse(const float* a, const float* b, int32_t n, float* loss, float* da, float scale, void* stream) {
     ESTTS_CHECK_ARG(a && b && loss && da && n > 0, "estts_mse: bad arguments");
-    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, a, b, n, loss, da, scale);
+    ESTTS_LAUNCH(mse_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, a, b, n, loss, da, scale);
     ESTTS_CHECK_LAUNCH("estts_mse");
     return 0;
 }
@@ -1017,7 +1017,7 @@ extern "C" int estts_mine_divergence(const float* joint, const float* marginal, 
                                      float* d_joint, float* d_marginal, float gscale, void* stream) {
     ESTTS_CHECK_ARG(joint && marginal && prev_exp && next_exp && mi && d_joint && d_marginal && n > 0, "estts_mine_divergence: bad arguments");
     ESTTS_CHECK_ARG(div_type == 0 || (div_type == 1 && betas && n_beta > 0), "estts_mine_divergence: divergence 0 (KL) or 1 (Renyi with betas)");
-    hipLaunchKernelGGL(mine_divergence_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, joint, marginal, n, div_type, betas,
+    ESTTS_LAUNCH(mine_divergence_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, joint, marginal, n, div_type, betas,
                        n_beta, smoothing, prev_exp, next_exp, mi, d_joint, d_marginal, gscale);
     ESTTS_CHECK_LAUNCH("estts_mine_divergence");
     return 0;
@@ -1026,7 +1026,7 @@ extern "C" int estts_mine_divergence(const float* joint, const float* marginal, 
 extern "C" int estts_club_terms(const float* mu, const float* log_var, const float* y, const float* y_shuffled, int32_t B, int32_t D,
                                 float* out, float* d_mu, float* d_log_var, float gscale, void* stream) {
     ESTTS_CHECK_ARG(mu && log_var && y && y_shuffled && out && d_mu && d_log_var && B > 0 && D > 0, "estts_club_terms: bad arguments");
-    hipLaunchKernelGGL(club_terms_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, mu, log_var, y, y_shuffled, B, D, out,
+    ESTTS_LAUNCH(club_terms_kernel, dim3(1), dim3(MI_THREADS), 0, (hipStream_t)stream, mu, log_var, y, y_shuffled, B, D, out,
                        d_mu, d_log_var, gscale);
     ESTTS_CHECK_LAUNCH("estts_club_terms");
     return 0;
@@ -1036,7 +1036,7 @@ extern "C" int estts_head_scale(float* x, int32_t ldx, const float* scale, int32
                                 void* stream) {
     ESTTS_CHECK_ARG(x && scale && B > 0 && L > 0 && H > 0 && depth > 0 && (depth & 3) == 0 && (ldx & 3) == 0 && ldx >= H * depth,
                     "estts_head_scale: bad arguments");
-    hipLaunchKernelGGL(head_scale_kernel, dim3(ew_grid((long)B * L * (H * depth >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx,
+    ESTTS_LAUNCH(head_scale_kernel, dim3(ew_grid((long)B * L * (H * depth >> 2))), dim3(256), 0, (hipStream_t)stream, x, ldx,
                        scale, B * L, L, H, depth);
     ESTTS_CHECK_LAUNCH("estts_head_scale");
     return 0;
@@ -1045,7 +1045,7 @@ extern "C" int estts_head_scale(float* x, int32_t ldx, const float* scale, int32
 extern "C" int estts_embed_bwd(const int32_t* tokens, const float* dx, int32_t lddx, float* demb, int32_t B, int32_t N, int32_t D,
                                float scale, void* stream) {
     ESTTS_CHECK_ARG(tokens && dx && demb && B > 0 && N > 0 && D > 0 && (D & 3) == 0 && (lddx & 3) == 0, "estts_embed_bwd: bad arguments");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(ew_grid((long)B * N * (D >> 2))), dim3(256), 0, (hipStream_t)stream, tokens, dx,
+    ESTTS_LAUNCH(embed_bwd_kernel, dim3(ew_grid((long)B * N * (D >> 2))), dim3(256), 0, (hipStream_t)stream, tokens, dx,
                        lddx, demb, B * N, D, scale);
     ESTTS_CHECK_LAUNCH("estts_embed_bwd");
     return 0;
@@ -1056,7 +1056,7 @@ extern "C" int estts_expand_bwd(const float* dout, int32_t lddo, const int32_t* 
     ESTTS_CHECK_ARG(dout && cum && dx && B > 0 && N > 0 && T > 0 && D > 0 && (D & 3) == 0 && (lddo & 3) == 0 && (lddx & 3) == 0,
                     "estts_expand_bwd: bad arguments");
     const long toks = (long)B * N;
-    hipLaunchKernelGGL(expand_bwd_kernel, dim3((unsigned)((toks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, lddo, cum, dx,
+    ESTTS_LAUNCH(expand_bwd_kernel, dim3((unsigned)((toks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout, lddo, cum, dx,
                        lddx, B, N, T, D);
     ESTTS_CHECK_LAUNCH("estts_expand_bwd");
     return 0;
@@ -1065,7 +1065,7 @@ extern "C" int estts_expand_bwd(const float* dout, int32_t lddo, const int32_t* 
 extern "C" int estts_masked_mae_bwd(const float* target, int32_t ldt, const float* pred, int32_t ldp, float* dpred, int32_t lddp,
                                     int32_t M, int32_t C, float scale, void* stream) {
     ESTTS_CHECK_ARG(target && pred && dpred && M > 0 && C > 0 && ldt >= C && ldp >= C && lddp >= C, "estts_masked_mae_bwd: bad arguments");
-    hipLaunchKernelGGL(masked_mae_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, target, ldt, pred, ldp, dpred,
+    ESTTS_LAUNCH(masked_mae_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, target, ldt, pred, ldp, dpred,
                        lddp, M, C, scale);
     ESTTS_CHECK_LAUNCH("estts_masked_mae_bwd");
     return 0;
@@ -1075,7 +1075,7 @@ extern "C" int estts_adam(float* p, const float* grad, float* m, float* v, int64
                           float eps, float grad_scale, void* stream) {
     ESTTS_CHECK_ARG(p && grad && m && v && n > 0 && (n & 3) == 0, "estts_adam: n must be a positive multiple of 4");
     ESTTS_CHECK_ARG((((uintptr_t)p | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "estts_adam: buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (long)(n / 4), lr_t,
+    ESTTS_LAUNCH(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (long)(n / 4), lr_t,
                        beta1, beta2, eps, grad_scale);
     ESTTS_CHECK_LAUNCH("estts_adam");
     return 0;
@@ -1111,7 +1111,7 @@ extern "C" int estts_colreduce(const estts_colreduce_args* args, void* stream) {
         int ys = (a.M + 15) / 16;
         const int cap_d = (target + gx - 1) / gx;
         if (ys > cap_d) ys = cap_d;
-        hipLaunchKernelGGL(colreduce_kernel, dim3(gx, ys), dim3(256), 0, (hipStream_t)stream, k);
+        ESTTS_LAUNCH(colreduce_kernel, dim3(gx, ys), dim3(256), 0, (hipStream_t)stream, k);
         ESTTS_CHECK_LAUNCH("estts_colreduce");
         return 0;
     }
@@ -1122,10 +1122,10 @@ extern "C" int estts_colreduce(const estts_colreduce_args* args, void* stream) {
     if (ysplit > cap) ysplit = cap;
     if (ysplit <= 32) k.ws = nullptr;
     dim3 grid(gx, ysplit);
-    hipLaunchKernelGGL(colreduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
+    ESTTS_LAUNCH(colreduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, k);
     if (k.ws) {
         ESTTS_CHECK_LAUNCH("estts_colreduce");
-        hipLaunchKernelGGL(colreduce_finish_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, k.ws, cp, a.C, a.out0,
+        ESTTS_LAUNCH(colreduce_finish_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, k.ws, cp, a.C, a.out0,
                            a.mode != 1 ? a.out1 : nullptr);
     }
     ESTTS_CHECK_LAUNCH("estts_colreduce");
@@ -1138,7 +1138,7 @@ extern "C" int estts_bn_finalize(const float* s0, const float* s1, const float* 
                                  void* stream) {
     ESTTS_CHECK_ARG(s0 && s1 && z0 && gamma && beta && mean && rstd && scale && shift && M > 0 && C > 0, "estts_bn_finalize: bad arguments");
     ESTTS_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "estts_bn_finalize: moving statistics go together");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s0, s1, z0, M, C, eps, momentum,
+    ESTTS_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, s0, s1, z0, M, C, eps, momentum,
                        moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, (float*)nullptr, 0L,
                        (float*)nullptr);
     ESTTS_CHECK_LAUNCH("estts_bn_finalize");
@@ -1152,7 +1152,7 @@ extern "C" int estts_bn_finalize_slots(float* slots, int64_t slot_stride, const 
     ESTTS_CHECK_ARG(slots && z0 && gamma && beta && mean && rstd && scale && shift && M > 0 && C > 0, "estts_bn_finalize_slots: bad arguments");
     ESTTS_CHECK_ARG(slot_stride == ((int64_t)(C + 255) / 256) * 256, "estts_bn_finalize_slots: slot_stride must be C rounded up to 256");
     ESTTS_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr), "estts_bn_finalize_slots: moving statistics go together");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, slots, slots, z0, M, C, eps,
+    ESTTS_LAUNCH(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, slots, slots, z0, M, C, eps,
                        momentum, moving_var_scale, gamma, beta, moving_mean, moving_var, mean, rstd, scale, shift, slots,
                        (long)slot_stride, about_next);
     ESTTS_CHECK_LAUNCH("estts_bn_finalize_slots");
@@ -1177,12 +1177,12 @@ extern "C" int estts_rownorm_bwd(const estts_rownorm_bwd_args* args, void* strea
     if (grid > cap) grid = cap;
     estts_rownorm_bwd_args k = a;
     if (k.ws && (k.ws_bytes < (int64_t)ROWNORM_SLOTS * 6 * 1024 * 4 || grid <= 32)) k.ws = nullptr;
-    if (nch == 1) hipLaunchKernelGGL(rownorm_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
-    else if (nch == 2) hipLaunchKernelGGL(rownorm_bwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
-    else hipLaunchKernelGGL(rownorm_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    if (nch == 1) ESTTS_LAUNCH(rownorm_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    else if (nch == 2) ESTTS_LAUNCH(rownorm_bwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
+    else ESTTS_LAUNCH(rownorm_bwd_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, k);
     if (k.ws) {
         ESTTS_CHECK_LAUNCH("estts_rownorm_bwd");
-        hipLaunchKernelGGL(rownorm_bwd_finish_kernel, dim3((f.D + 255) / 256, 6), dim3(256), 0, (hipStream_t)stream, k);
+        ESTTS_LAUNCH(rownorm_bwd_finish_kernel, dim3((f.D + 255) / 256, 6), dim3(256), 0, (hipStream_t)stream, k);
     }
     ESTTS_CHECK_LAUNCH("estts_rownorm_bwd");
     return 0;

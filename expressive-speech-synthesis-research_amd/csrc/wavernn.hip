@@ -240,7 +240,7 @@ extern "C" int estts_wavernn_prep(const estts_wavernn_prep_args* args, void* str
                     "estts_wavernn_prep: leading dimension too small");
     ESTTS_CHECK_ARG(a.pad - a.fir_kmin - (a.ntaps - 1) >= 0 && a.pad + a.fir_kmin >= 0,
                     "estts_wavernn_prep: filter reaches outside the padded mel");
-    hipLaunchKernelGGL(wavernn_prep_kernel, dim3(a.n_seq), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_LAUNCH(wavernn_prep_kernel, dim3(a.n_seq), dim3(256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_wavernn_prep");
     return 0;
 }
@@ -254,7 +254,7 @@ extern "C" int estts_gru_gates(const float* gi, int32_t ldgi, const float* gh, i
     ESTTS_CHECK_ARG(((ldgi | ldgh | ldh | ldo | (x_res ? ldx : 0)) & 3) == 0, "estts_gru_gates: ld not multiple of 4");
     const long total = (long)M * (H >> 2);
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(gru_gates_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gi, ldgi, gh, ldgh, h, ldh, x_res,
+    ESTTS_LAUNCH(gru_gates_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gi, ldgi, gh, ldgh, h, ldh, x_res,
                        ldx, out, ldo, M, H);
     ESTTS_CHECK_LAUNCH("estts_gru_gates");
     return 0;
@@ -278,7 +278,7 @@ extern "C" int estts_wavernn_sample(const estts_wavernn_sample_args* args, void*
                         8 + c.feat + c.d <= 128 && c.aux_kpitch > c.aux_ks && c.aux_ks >= 0,
                         "estts_wavernn_sample: bad conditioning block (see estts_wavernn_cond)");
     }
-    hipLaunchKernelGGL(wavernn_sample_kernel, dim3((a.n_seq + 3) / 4), dim3(a.with_cond ? 512 : 256), 0, (hipStream_t)stream, a);
+    ESTTS_LAUNCH(wavernn_sample_kernel, dim3((a.n_seq + 3) / 4), dim3(a.with_cond ? 512 : 256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_wavernn_sample");
     return 0;
 }
@@ -341,7 +341,7 @@ extern "C" int estts_wavernn_unfold(const estts_wavernn_unfold_args* args, void*
     ESTTS_CHECK_ARG(a.n_utt > 0 && a.n_utt <= 65535 && a.target > 0 && a.overlap >= 4 && a.max_len > 0 && a.mu >= 0 && a.fade_tail >= 0 &&
                     a.ld_wave >= a.target + 2 * a.overlap, "estts_wavernn_unfold: bad sizes (utterances %d, target %d, overlap %d, row %d)",
                     a.n_utt, a.target, a.overlap, a.ld_wave);
-    hipLaunchKernelGGL(wavernn_unfold_kernel, dim3((a.max_len + 255) / 256, a.n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_LAUNCH(wavernn_unfold_kernel, dim3((a.max_len + 255) / 256, a.n_utt), dim3(256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_wavernn_unfold");
     return 0;
 }

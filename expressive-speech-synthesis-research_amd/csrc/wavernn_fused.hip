@@ -412,7 +412,7 @@ template <int MODE, int NT, int MB = 2>
 int launch_layer(const estts_wavernn_layer_args& a, hipStream_t st) {
     const int per = 16 * (MODE ? 1 : NT);
     const int grid = ((a.n_seq + 64 * MB - 1) / (64 * MB)) * ((a.n_units + per - 1) / per);
-    hipLaunchKernelGGL((wavernn_layer_kernel<MODE, NT, MB>), dim3(grid), dim3(512), 0, st, a);
+    ESTTS_LAUNCH((wavernn_layer_kernel<MODE, NT, MB>), dim3(grid), dim3(512), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_wavernn_layer");
     return 0;
 }
@@ -463,7 +463,7 @@ extern "C" int estts_wavernn_cond(const estts_wavernn_cond_args* args, void* str
     ESTTS_CHECK_ARG(8 + a.feat + a.d <= 128, "estts_wavernn_cond: the step input must fit 128 columns");
     ESTTS_CHECK_ARG(a.aux_kpitch > a.aux_ks && a.aux_ks >= 0, "estts_wavernn_cond: aux K-step outside the panels");
     const long threads = (long)(((a.n_seq + 15) >> 4) << 4) * (15 + 3 * (a.d >> 3));
-    hipLaunchKernelGGL(wavernn_cond_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_LAUNCH(wavernn_cond_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_wavernn_cond");
     return 0;
 }

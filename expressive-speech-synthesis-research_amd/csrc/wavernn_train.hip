@@ -247,7 +247,7 @@ extern "C" int estts_gru_step_fwd(const float* gi, int32_t ldgi, const float* gh
     ESTTS_CHECK_ARG(ldgi >= 3 * H && ldgh >= 3 * H && ldhp >= H && ldho >= H && (!out || ldo >= H) && (!x_res || ldx >= H),
                     "estts_gru_step_fwd: ld too small");
     ESTTS_CHECK_ARG(((ldgi | ldgh | ldhp | ldho | (out ? ldo : 0) | (x_res ? ldx : 0)) & 3) == 0, "estts_gru_step_fwd: ld not multiple of 4");
-    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(grid_for((long)M * (H >> 2))), dim3(256), 0, (hipStream_t)stream, gi, ldgi, gh, ldgh,
+    ESTTS_LAUNCH(gru_step_fwd_kernel, dim3(grid_for((long)M * (H >> 2))), dim3(256), 0, (hipStream_t)stream, gi, ldgi, gh, ldgh,
                        h_prev, ldhp, h_out, ldho, x_res, ldx, out, ldo, M, H);
     ESTTS_CHECK_LAUNCH("estts_gru_step_fwd");
     return 0;
@@ -262,7 +262,7 @@ extern "C" int estts_gru_step_bwd(const float* gi, int32_t ldgi, const float* gh
                     "estts_gru_step_bwd: ld too small");
     ESTTS_CHECK_ARG(((ldgi | ldgh | ldhp | lddh | lddgi | lddgh | lddhp | (dh_rec ? lddhr : 0)) & 3) == 0, "estts_gru_step_bwd: ld not multiple of 4");
     ESTTS_CHECK_ARG(!dh_rec || lddhr >= H, "estts_gru_step_bwd: ld too small");
-    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(grid_for((long)M * (H >> 2))), dim3(256), 0, (hipStream_t)stream, gi, ldgi, gh, ldgh,
+    ESTTS_LAUNCH(gru_step_bwd_kernel, dim3(grid_for((long)M * (H >> 2))), dim3(256), 0, (hipStream_t)stream, gi, ldgi, gh, ldgh,
                        h_prev, ldhp, dh, lddh, dh_rec, lddhr, dgi, lddgi, dgh, lddgh, dh_prev, lddhp, M, H);
     ESTTS_CHECK_LAUNCH("estts_gru_step_bwd");
     return 0;
@@ -276,7 +276,7 @@ extern "C" int estts_wavernn_prep_bwd(const estts_wavernn_prep_bwd_args* args, v
                     "estts_wavernn_prep_bwd: bad shape");
     ESTTS_CHECK_ARG(a.pad - a.fir_kmin - (a.ntaps - 1) >= 0 && a.pad + a.fir_kmin >= 0, "estts_wavernn_prep_bwd: pad too small for the filter");
     ESTTS_CHECK_ARG(a.ld_dxin >= 1 + a.feat + a.d && a.ld_da2 >= a.d && a.ld_da3 >= a.d && a.ld_da4 >= a.d, "estts_wavernn_prep_bwd: ld too small");
-    hipLaunchKernelGGL(wavernn_prep_bwd_kernel, dim3(a.n_utt * a.frames), dim3(256), 0, (hipStream_t)stream, a);
+    ESTTS_LAUNCH(wavernn_prep_bwd_kernel, dim3(a.n_utt * a.frames), dim3(256), 0, (hipStream_t)stream, a);
     ESTTS_CHECK_LAUNCH("estts_wavernn_prep_bwd");
     return 0;
 }
@@ -284,7 +284,7 @@ extern "C" int estts_wavernn_prep_bwd(const estts_wavernn_prep_bwd_args* args, v
 extern "C" int estts_softmax_xent(const float* logits, int32_t ld, const int32_t* labels, float* loss, float* dlogits, int32_t lddl,
                                   int32_t M, int32_t C, float scale, void* stream) {
     ESTTS_CHECK_ARG(logits && labels && loss && dlogits && M > 0 && C > 0 && ld >= C && lddl >= C, "estts_softmax_xent: bad arguments");
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss, dlogits,
+    ESTTS_LAUNCH(softmax_xent_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss, dlogits,
                        lddl, M, C, scale, 0, 0, 1.0f);
     ESTTS_CHECK_LAUNCH("estts_softmax_xent");
     return 0;
@@ -293,7 +293,7 @@ extern "C" int estts_softmax_xent(const float* logits, int32_t ld, const int32_t
 extern "C" int estts_scaled_xent(const float* logits, int32_t ld, const int32_t* labels, float* loss, float* dlogits, int32_t lddl,
                                  int32_t M, int32_t C, int32_t index, float scaling, float scale, void* stream) {
     ESTTS_CHECK_ARG(logits && labels && loss && M > 0 && C > 0 && ld >= C && (!dlogits || lddl >= C), "estts_scaled_xent: bad arguments");
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss, dlogits,
+    ESTTS_LAUNCH(softmax_xent_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, loss, dlogits,
                        lddl, M, C, scale, 1, index, scaling);
     ESTTS_CHECK_LAUNCH("estts_scaled_xent");
     return 0;
@@ -303,7 +303,7 @@ extern "C" int estts_mol_loss(const float* y_hat, int32_t ld, const float* y, fl
                               int32_t nr_mix, int32_t num_classes, float log_scale_min, float scale, void* stream) {
     ESTTS_CHECK_ARG(y_hat && y && loss && d && M > 0, "estts_mol_loss: bad arguments");
     ESTTS_CHECK_ARG(nr_mix > 0 && nr_mix <= 16 && ld >= 3 * nr_mix && ldd >= 3 * nr_mix && num_classes > 1, "estts_mol_loss: nr_mix must be 1..16");
-    hipLaunchKernelGGL(mol_loss_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, y_hat, ld, y, loss, d, ldd, M, nr_mix,
+    ESTTS_LAUNCH(mol_loss_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, y_hat, ld, y, loss, d, ldd, M, nr_mix,
                        1.0f / (float)(num_classes - 1), logf((float)(num_classes - 1) * 0.5f), log_scale_min, scale);
     ESTTS_CHECK_LAUNCH("estts_mol_loss");
     return 0;

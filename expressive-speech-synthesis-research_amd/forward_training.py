@@ -256,6 +256,7 @@ class ForwardTransformerTrainer:
         # reduction pass plus a launch that adds its 16 copies up (for comparisons)
         self.fold_sums = True
         self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        self.exchange = True       # False: the step skips its gradient exchange (timing what the exchange costs)
 
     def __init__(self, weights, config, device='cuda', precision='bf16x3', seed=0, process_group=None, bucket_mb=25):
         self._init_common(config, device, precision, seed, process_group, bucket_mb)
@@ -310,6 +311,13 @@ class ForwardTransformerTrainer:
 
     def _empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def _new_overlap(self):
+        overlap = parallel.GradientOverlap(self.store.grad, self.bucket_elems, self.pg, self._comm)
+        if not self.exchange:
+            overlap.active = False
+        self._last_overlap = overlap          # (tests look at the collectives it issued)
+        return overlap
 
     def _first_offset(self, prefix):
         """Lowest offset in the flat parameter / gradient buffer of the variables whose names start with `prefix`."""
@@ -657,6 +665,7 @@ class ForwardTransformerTrainer:
             mel_w, dur_w = mel_w * Tm / Tg, dur_w * N / Ng
         self._infer = None
         self._site = 0
+        T.SumSlots.step_begin(self.device, self)      # (clears sums a failed step may have left without a consumer)
         # (the rank enters the seed: replicas draw different dropout masks and head drops for their shards)
         self._seed_now = (self.seed * 1000003 + self.iterations * 7919 + 12345 + self.rank * 0x9E3779B1) & 0xFFFFFFFF
         self._host_rng = np.random.default_rng(self._seed_now)
@@ -763,7 +772,7 @@ class ForwardTransformerTrainer:
         T.masked_mae_bwd(td.view(Me, 1), dur.view(Me, 1), ddur.view(Me, 1), dur_w)
         # the gradient buffer is in forward order: every finished stage hands its tail to the all-reduce, which runs on
         # the communication stream beside the rest of the backward pass
-        overlap = parallel.GradientOverlap(self.store.grad, self.bucket_elems, self.pg, self._comm)
+        overlap = self._new_overlap()
         g = post_tape[0](dmel)
         d_dec = self._empty(Md, dd)
         self._lin_bwd(dec_out, self.out, g, Md, dx=d_dec)
@@ -794,6 +803,7 @@ class ForwardTransformerTrainer:
                 overlap.ready(self._first_offset(f'encoder.block{(idx - 1) // 2}.'))
         overlap.finish()
         self._apply_gradients()
+        T.SumSlots.step_end(self.device)
         if global_lengths is not None:
             losses = losses * torch.tensor([Tm / global_lengths[0], N / global_lengths[1]], dtype=torch.float32, device=self.device)
         loss = losses[0] * self.loss_weights[0] + losses[1] * self.loss_weights[1]

@@ -93,6 +93,7 @@ class _Head:
         self.iterations = 0
         self.last_draws = None
         self._pending = None
+        self._pending_opt = None
 
     @property
     def step(self):
@@ -115,6 +116,9 @@ class _Head:
         if self._pending is not None:
             self.load_weights(self._pending)
             self._pending = None
+        if self._pending_opt is not None:
+            self.load_optimizer_state(self._pending_opt)
+            self._pending_opt = None
         self._linears = []
         for s in stacks:
             self._linears += s.bind(st)
@@ -154,6 +158,35 @@ class _Head:
                 dst[:v.shape[0]].copy_(v)
         if getattr(self, '_linears', None):
             self._pack_plan.run()
+
+    def optimizer_state(self):
+        """Adam's state for a checkpoint (the reference checkpoints every head with its optimizer,
+        train_autoregressive.py:119-131): moments in the flat store's order, the step count, and the state of the generator
+        behind the head's random pairings, so that a resumed run draws what the uninterrupted one would have."""
+        if self.store is None:
+            raise RuntimeError('the head has no variables before its first call')
+        st = self.store
+        rng = np.frombuffer(repr(self._rng.bit_generator.state).encode(), dtype=np.uint8)
+        return {'__adam_m__': st.m.cpu().numpy(), '__adam_v__': st.v.cpu().numpy(),
+                '__iterations__': np.asarray(self.iterations, np.int64), '__rng__': rng}
+
+    def load_optimizer_state(self, state):
+        """Before the first call (the variables are built lazily from the first batch's widths) the state is kept until they
+        exist, like load_weights()."""
+        if self.store is None:
+            self._pending_opt = dict(state)
+            self.iterations = int(state['__iterations__'])
+            return
+        st = self.store
+        m, v = np.asarray(state['__adam_m__'], np.float32), np.asarray(state['__adam_v__'], np.float32)
+        if m.shape != tuple(st.m.shape) or v.shape != tuple(st.v.shape):
+            raise ValueError(f'optimizer state of {m.shape[0]} elements does not fit this head ({st.m.shape[0]})')
+        st.m.copy_(torch.from_numpy(m))
+        st.v.copy_(torch.from_numpy(v))
+        self.iterations = int(state['__iterations__'])
+        if '__rng__' in state:
+            import ast
+            self._rng.bit_generator.state = ast.literal_eval(bytes(np.asarray(state['__rng__'], np.uint8)).decode())
 
     def _apply(self):
         st = self.store

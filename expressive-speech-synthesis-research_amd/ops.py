@@ -465,6 +465,9 @@ def gru_gates(gi, gh, h, out, x_res=None, M=None, H=None):
     return out
 
 
+GRU_FUSED_MAX_H = 1536          # estts_gru_fused_fwd: H <= 1536; estts_gru_fused_bwd: 3 H <= 1536 (48 K-steps of 32 per launch)
+
+
 def gru_step(gi, gh, h_prev, lin, h_out, precision='bf16x3', site=None):
     """One GRU step in one launch (estts_gru_fused_fwd): gh = h_prev (*) lin (W_hh [3H x H] with its bias; stored), gates in the
     order r, z, n, h_out = the new state.  h_out must be another buffer than h_prev (other workgroups still read it)."""
@@ -479,6 +482,10 @@ def gru_step(gi, gh, h_prev, lin, h_out, precision='bf16x3', site=None):
     a.precision = PRECISION[precision]
     if (lin.N, lin.K) != (3 * a.H, a.H) or lin.s1 is not None:
         raise ValueError('gru_step: the weight must be W_hh [3H x H] without an output scale')
+    if a.H > GRU_FUSED_MAX_H or a.H % 16:
+        # beyond what one launch holds (a workgroup keeps a whole K = H row block in flight): the product, then the gates
+        gemm(h_prev, lin, gh, precision=precision)
+        return gru_gates(gi, gh, h_prev, h_out)
     check(_lib.load().estts_gru_fused_fwd(a, _stream()), 'estts_gru_fused_fwd')
     _record('gru_step', {'M': a.M, 'H': a.H, 'flops': 6.0 * a.M * a.H * a.H, 'bytes': 4.0 * a.M * a.H * 9 + 12.0 * a.H * a.H},
             _lib.load().estts_gru_fused_fwd, a, keep=(gi, gh, h_prev, lin, h_out))

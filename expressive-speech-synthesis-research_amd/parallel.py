@@ -110,7 +110,8 @@ class GradientOverlap:
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         # gloo stages device buffers through host threads of its own; collectives issued while kernels are still queued
         # stalled two ranks sharing one GPU, so with gloo on device memory the whole exchange waits for finish()
-        self.defer = self.active and flat.is_cuda and dist.get_backend(group) != 'nccl'
+        self.defer = (self.active and flat.is_cuda and dist.get_backend(group) != 'nccl'
+                      and os.environ.get('ESTTS_GLOO_OVERLAP', '0') != '1')     # (diagnostic switch: overlap over gloo anyway)
         self.final = False
         self.hi = flat.numel()
         self.works = []

@@ -171,24 +171,50 @@ class SumSlots:
         return cls._per_device[key]
 
     @classmethod
+    def step_begin(cls, device, owner):
+        """Called by a trainer at the start of train_step: if the previous step on this device did not reach step_end (an
+        exception between a producer and its consumer), sums may sit in the regions with nobody left to clear them, so all
+        regions are zeroed before the new step adds to them."""
+        s = cls.on(device)
+        if getattr(s, 'open_step', None) is not None:
+            s.buf.zero_()
+            s.used, s.turn = [0, 0], 0
+        s.open_step = owner
+
+    @classmethod
+    def step_end(cls, device):
+        cls.on(device).open_step = None
+
+    @classmethod
     def reset_all(cls):
         """Zero every region (after launches that left sums nobody consumed, e.g. a producer replayed on its own for timing)."""
         for s in cls._per_device.values():
             s.buf.zero_()
             s.used, s.turn = [0, 0], 0
+            s.open_step = None
 
     @staticmethod
     def stride(C):
         return (C + 255) // 256 * 256
 
+    @staticmethod
+    def _not_under_capture():
+        # the turn / used bookkeeping lives in Python: it advances when a launch is issued, not when a captured graph is
+        # replayed, so a replayed sequence with an odd number of deferred reductions would add into a region nobody cleared
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('SumSlots: deferred column sums cannot be recorded into a hipGraph (their clear / turn bookkeeping '
+                               'is host-side); capture with fold_sums = False or keep these launches outside the graph')
+
     def forward_region(self, C):
         """(pointer, stride) of the zeroed region a producer of forward moments for C columns writes."""
+        self._not_under_capture()
         if C > self.MAX_C:
             raise ValueError(f'SumSlots: at most {self.MAX_C} columns')
         return self.buf[2].data_ptr(), self.stride(C)
 
     def backward_region(self, C):
         """(pointer, stride, clear pointer, clear floats) for the next deferred mode-2 reduction over C columns."""
+        self._not_under_capture()
         if C > self.MAX_C:
             raise ValueError(f'SumSlots: at most {self.MAX_C} columns')
         i, o = self.turn, 1 - self.turn

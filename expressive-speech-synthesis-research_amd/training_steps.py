@@ -11,10 +11,12 @@ import torch
 def train_models_step(tts_mel, tts_phonemes, tts_stop, tts_speaker,
                       mine_mel, mine_phonemes, mine_stop, mine_speaker,
                       tts_model, mine_model, mi_holder,
-                      train_text_encoder=True, train_style_encoder=True, train_decoder=True, use_style_loss=False):
+                      train_text_encoder=True, train_style_encoder=True, train_decoder=True, use_style_loss=False,
+                      global_frames=None):
+    """global_frames (not in the reference, which is single-GPU): see AutoregressiveTransformerTrainer.train_step."""
     model_out = tts_model.train_step(tts_mel, tts_phonemes, tts_stop, tts_speaker, train_text_encoder=train_text_encoder,
                                      train_style_encoder=train_style_encoder, train_decoder=train_decoder,
-                                     use_style_loss=use_style_loss)
+                                     use_style_loss=use_style_loss, global_frames=global_frames)
     tts_loss = model_out['tts_loss']
     # the mutual-information term enters the total as a number: mi_holder['mi_loss'] was computed by the heads in the previous
     # step, outside this step's tape, so it moves the reported loss and no gradient (traning_steps.py:52-55)

@@ -16,6 +16,7 @@ per-phase filter (see wavernn.composite_upsample_filter): its gradient is reduce
 three small kernels is a few hundred multiply-adds on the host.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -68,10 +69,12 @@ class WaveRNNTrainer:
         self.precision = precision
         # a recurrent step as ONE launch (product + gates, estts_gru_fused_fwd / _bwd) instead of two; False: estts_gemm followed
         # by estts_gru_step_fwd / _bwd (for comparisons)
-        self.fused_gru = True
+        # (the one-launch backward step holds K = 3 * rnn_dims in flight: up to 1536, i.e. rnn_dims <= 512 -- the shipped
+        # size; larger layers take the two-launch steps, which have no such limit)
+        self.fused_gru = 3 * rnn_dims <= ops.GRU_FUSED_MAX_H and rnn_dims % 16 == 0
         # with one-launch steps: both layers' recurrences as ONE chain of launches (step t of one layer and step t -+ chunk of
         # the other in the same launch) instead of two chains on two streams
-        self.one_chain = True
+        self.one_chain = self.fused_gru
         self.use_graph = use_graph
         self.step = 0
         self.lr, self.beta1, self.beta2, self.eps = 1e-4, 0.9, 0.999, 1e-8      # torch.optim.Adam defaults, hp.voc_lr
@@ -228,6 +231,30 @@ class WaveRNNTrainer:
 
     def load(self, path):
         self.load_state_dict(torch.load(path, map_location='cpu', weights_only=True))
+
+    def broadcast_running_statistics(self, src=0):
+        """BatchNorm running statistics are per replica during data-parallel training; before a checkpoint every rank takes
+        rank `src`'s."""
+        if self.world > 1:
+            torch.distributed.broadcast(self.store.state, src=src, group=self.pg)
+
+    def restore(self, path):
+        """fatchord_version.py:396-402: a new session writes its initial weights, an old one is loaded."""
+        if not os.path.exists(path):
+            print('\nNew WaveRNN Training Session...\n')
+            self.save(path)
+        else:
+            print(f'\nLoading Weights: "{path}"\n')
+            self.load(path)
+
+    def checkpoint(self, path):
+        """fatchord_version.py:385-387."""
+        self.save(os.path.join(path, f'checkpoint_{self.get_step() // 1000}k_steps.pyt'))
+
+    def log(self, path, msg):
+        """fatchord_version.py:392-394."""
+        with open(path, 'a') as f:
+            print(msg, file=f)
 
     # ------------------------------------------------------------------ workspace and captured loops
     def _workspace(self, B, Tf):
@@ -589,6 +616,7 @@ class WaveRNNTrainer:
         ws = self._workspace(B, Tf)
         M, Mr, R, F, d, pr = ws['M'], ws['Mr'], self.rnn_dims, self.fc_dims, self.aux_dims, self.precision
         self._load_batch(ws, x, mels)
+        T_.SumSlots.step_begin(self.device, self)     # (clears sums a failed step may have left without a consumer)
         st = self.store
         st.grad.zero_()
         ws['loss'].zero_()
@@ -628,6 +656,7 @@ class WaveRNNTrainer:
         for n, g in zip(self._up_names, ups):
             st.g[n].copy_(torch.from_numpy(g.astype(np.float32)))
         self._apply_gradients()
+        T_.SumSlots.step_end(self.device)
         return ws['loss'][0]
 
     def _gru_param_grads(self, ws, x_in, H, ih, hh, dgi, dgh):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 31
+#define ESTTS_ABI_VERSION 32
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -38,6 +38,9 @@ extern "C" {
 
 int estts_abi_version(void);
 const char* estts_last_error(void);
+/* Number of kernels this library has launched in the calling process so far (every entry point counts its launches).
+ * No counterpart in the reference: it is what a benchmark divides by its step count to report launches per step. */
+long long estts_launch_count(void);
 
 /* ------------------------------------------------------------------------------------------
  * Fused dense / 1-D convolution on the matrix cores.
@@ -145,9 +148,12 @@ int estts_gemm(const estts_gemm_args* args, void* stream);
  * that forbid hipMalloc).  No counterpart in the reference.  args->ws / ws_bytes / counters / n_counters are ignored: the
  * split-K slabs and tickets live in a static device array inside the library (4 MiB of slabs + 4096 tickets per GPU, held
  * until the process ends).  A launch whose split needs more is rejected with an error naming both sizes (tune = 0 never
- * splits beyond 32 tiles, i.e. 1 MiB).  The call allocates nothing (one hipMemsetAsync of the tickets, then the launch);
- * the first call on a device looks the array's address up.  Every call on one GPU shares that GPU's array: calls that may
- * overlap on one GPU (different streams) race and must use estts_gemm with workspaces of their own instead. */
+ * splits beyond 32 tiles, i.e. 1 MiB).  The call allocates nothing: the launch, preceded by one hipMemsetAsync of the
+ * tickets only when the launch really splits K.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress): make that call outside stream capture; later calls may be captured.  `stream` must belong to the
+ * current device (a stream of another GPU is rejected: it would be handed this GPU's array).  Every call on one GPU
+ * shares that GPU's array: calls that may overlap on one GPU (different streams) race and must use estts_gemm with
+ * workspaces of their own instead. */
 int estts_gemm_noalloc(const estts_gemm_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------

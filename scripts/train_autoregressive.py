@@ -8,14 +8,17 @@ train_models_step: one update of the autoregressive model and, with use_mine, on
 head (MINE / CLUB per mine_type and mine_pair_types).  Samples are .npz files with arrays mel (T, C), phonemes (N,) and,
 for the speaker systems, speaker (speaker_embed_dim,); the start / end vectors and the stop labels are added here as the
 reference's preprocessor does (TransformerTTS/preprocessing/data_handling.py).  One process per GPU under
-torch.distributed.run: every rank takes its own batches, gradients are summed over RCCL inside train_step and the losses
-are normalised per rank.  Checkpoints: ckpt-<step>.npz (variables, Adam moments) and mine<i>-<step>.npz per head."""
+torch.distributed.run: every rank takes its own batches, gradients are summed over RCCL inside train_step (beside the
+backward pass) and the losses are divided by the global batch's padded size.  The mutual-information heads are per rank.
+Checkpoints: ckpt-<step>.npz (variables, Adam moments) and mine<i>-<step>.npz per head (variables, Adam moments, step
+count, the running terms of mi_holder); a restart restores both."""
 import argparse
 import glob
 import os
 import sys
 
 import numpy as np
+import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import estts  # noqa: E402,F401
@@ -91,13 +94,39 @@ def build_heads(cfg):
     return heads
 
 
-def checkpoint(cm, model, heads, rank):
+def checkpoint(cm, model, heads, rank, mi_holder):
+    """ckpt-<step>.npz for the model; mine<i>-<model step>.npz for head i: variables, Adam moments and step count, the state of
+    its pairing generator, and the running terms of mi_holder (the smoothed exponentials and the last mutual-information
+    value, which the next step's reported loss contains).  The heads are per rank (their gradients are not exchanged);
+    rank 0's are the ones saved and every rank resumes from them."""
     model.broadcast_moving_statistics(src=0)
     if rank == 0:
         cm.save_weights(str(cm.weights_dir / f'ckpt-{model.step}.npz'), model.weights(), model.step, model.optimizer_state())
         for i, h in enumerate(heads):
             if h.store is not None:
-                cm.save_weights(str(cm.weights_dir / f'mine{i}-{h.step}.npz'), h.weights(), h.step)
+                state = h.optimizer_state()
+                state['__exp_terms__'] = np.asarray(torch.as_tensor(mi_holder['exp_terms']).detach().cpu().numpy(), np.float32)
+                state['__mi_loss__'] = np.asarray(float(mi_holder['mi_loss']), np.float64)
+                cm.save_weights(str(cm.weights_dir / f'mine{i}-{model.step}.npz'), h.weights(), h.step, state)
+
+
+def restore_heads(cm, heads, mi_holder, model_step, verbose):
+    """train_autoregressive.py:119-131: every head comes back from its own newest checkpoint (not newer than the model's),
+    with its optimizer; mi_holder's running terms come back with it."""
+    for i, h in enumerate(heads):
+        files = [(int(p.rsplit('-', 1)[1][:-4]), p) for p in glob.glob(str(cm.weights_dir / f'mine{i}-*.npz'))]
+        files = sorted(f for f in files if f[0] <= model_step)
+        if not files:
+            continue
+        w, _, opt = cm.read_weights(files[-1][1], with_optimizer=True)
+        h.load_weights(w)
+        if '__adam_m__' in opt:
+            h.load_optimizer_state(opt)
+        if '__exp_terms__' in opt:
+            mi_holder['exp_terms'] = np.asarray(opt['__exp_terms__'], np.float32)
+            mi_holder['mi_loss'] = float(opt['__mi_loss__'])
+        if verbose:
+            print(f'restored head {i} ({h.name}:{h.pair_type}) from {files[-1][1]} at head step {h.step}')
 
 
 def main():
@@ -135,7 +164,10 @@ def main():
     mi_holder = {'use_mine': bool(cfg.get('use_mine')), 'mine_sep_call': sep, 'mi_loss': 0.0,
                  'exp_terms': np.zeros((n_beta, 2), np.float32), 'weight_factor': float(cfg.get('mine_weight_factor', 0.0)),
                  'smoothing_factor': float(cfg.get('mine_smoothing_factor', 1.0))}
+    restore_heads(cm, heads, mi_holder, model.step, rank == 0)
     max_steps = args.max_steps or cfg['max_steps']
+    # ragged ranks: every rank divides its losses by the global batch's padded frame count (train_step(global_frames=...))
+    frames_buf = torch.zeros(1, dtype=torch.int64, device='cuda') if world > 1 else None
     losses = []
     while model.step < max_steps:
         mel, phonemes, stop, spk = next(batches)
@@ -146,15 +178,20 @@ def main():
                             learning_rate=float(piecewise_linear_schedule(model.step, cfg['learning_rate_tts_schedule'])),
                             reduction_factor=reduction_schedule(model.step, cfg['reduction_factor_schedule']),
                             drop_n_heads=reduction_schedule(model.step, cfg['head_drop_schedule']))
+        global_frames = None
+        if world > 1:
+            frames_buf.fill_(mel.shape[1] - 1)
+            torch.distributed.all_reduce(frames_buf, op=torch.distributed.ReduceOp.MAX)
+            global_frames = int(frames_buf.item())
         out = train_models_step(mel, phonemes, stop, spk, m_mel, m_ph, m_stop, m_spk, model, heads, mi_holder,
                                 cfg.get('train_text_encoder', True), cfg.get('train_style_encoder', True),
-                                cfg.get('train_decoder', True), cfg.get('use_style_loss', False))
+                                cfg.get('train_decoder', True), cfg.get('use_style_loss', False), global_frames=global_frames)
         losses.append(float(out['loss']))
         if rank == 0 and model.step % 10 == 0:
             print(f'step {model.step} r {model.r} loss {losses[-1]:.4f} (avg of last 100: {np.mean(losses[-100:]):.4f})', flush=True)
         if model.step % cfg.get('weights_save_frequency', 1000) == 0:
-            checkpoint(cm, model, heads, rank)
-    checkpoint(cm, model, heads, rank)
+            checkpoint(cm, model, heads, rank, mi_holder)
+    checkpoint(cm, model, heads, rank, mi_holder)
     parallel.barrier()
 
 

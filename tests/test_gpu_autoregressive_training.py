@@ -256,3 +256,63 @@ def test_weights_round_trip_and_adam_step():
     assert abs(float(val2['tts_loss']) - float(val['tts_loss'])) < 1e-4
     model.train_step(mel, tokens, stop, spk)
     assert abs(float(model.val_step(tokens, mel, stop, spk)['tts_loss']) - float(val['tts_loss'])) > 1e-6   # rebuilt after a step
+
+
+def test_global_frames_makes_ragged_shards_equal_the_concatenated_batch():
+    """Data-parallel normalisation: two shards that pad to different frame counts, each given global_frames, sum to `world`
+    times the gradient of the concatenated batch (the optimizer divides by world).  Every sub-network runs in inference mode
+    (no dropout, BatchNormalization on its moving statistics) and the system has no style encoder, so an utterance's
+    gradient does not depend on what else is in its batch or on its padding."""
+    from estts.autoregressive_training import AutoregressiveTransformerTrainer
+    cfg = small_cfg('speaker_text', 0.0)
+    w = weights.init_autoregressive_transformer(cfg, seed=5)
+    shards = [batch(cfg, 2, 11, 18, seed=1), batch(cfg, 2, 11, 26, seed=2)]
+    Tg = max(s[1].shape[1] for s in shards) - 1
+
+    def padded(mel, stop):
+        B, T1 = stop.shape
+        m = np.zeros((B, Tg + 1, mel.shape[2]), np.float32)
+        s = np.zeros((B, Tg + 1), np.int32)
+        m[:, :T1], s[:, :T1] = mel, stop
+        return m, s
+
+    def grad_of(tokens, mel, stop, spk, **kw):
+        m = AutoregressiveTransformerTrainer(w, cfg)
+        m._compile(stop_scaling=8.0, optimizer={'learning_rate': 1e-3})
+        m.set_constants(reduction_factor=1)
+        out = m.train_step(mel, tokens, stop, spk, train_text_encoder=False, train_style_encoder=False, train_decoder=False,
+                           apply=False, **kw)
+        return m.store.grad.double().cpu(), float(out['loss'])
+
+    parts = [grad_of(*s, global_frames=Tg) for s in shards]
+    cat = [np.concatenate([s[0] for s in shards])]
+    pm = [padded(s[1], s[2]) for s in shards]
+    cat += [np.concatenate([p[0] for p in pm]), np.concatenate([p[1] for p in pm]), np.concatenate([s[3] for s in shards])]
+    whole, loss = grad_of(*cat)
+    summed = parts[0][0] + parts[1][0]
+    scale = float(whole.norm()) * 2
+    assert float((summed - 2 * whole).norm()) < 2e-3 * scale, (float((summed - 2 * whole).norm()), scale)
+    assert abs((parts[0][1] + parts[1][1]) / 2 - loss) < 1e-4 * abs(loss)
+    # without global_frames the short shard weighs its utterances more: the same comparison must fail clearly
+    plain = grad_of(*shards[0])[0] + parts[1][0]
+    assert float((plain - 2 * whole).norm()) > 2e-2 * scale
+
+
+def test_gru_cell_wider_than_one_launch_takes_the_two_launch_steps(monkeypatch):
+    """The one-launch backward step of the reference encoder's GRU holds K = 3 * units <= 1536 in flight.  With the limit
+    lowered under this model's cell (3 * 32 = 96) the trainer must choose the two-launch steps on its own and still match the
+    oracle; the inference encoder must give the same style embedding on either path."""
+    from estts import ops
+    from estts.autoregressive_transformer import ReferenceEncoderGST
+    monkeypatch.setattr(ops, 'GRU_FUSED_MAX_H', 64)
+    model, _, _ = check_step('style_text', 1)
+    assert model.fused_gru is False
+    cfg = small_cfg('style_text', 0.0)
+    w = weights.init_autoregressive_transformer(cfg, seed=5)
+    x = torch.from_numpy(np.random.default_rng(2).normal(size=(3, 45, 80)).astype(np.float32)).cuda()
+    enc = ReferenceEncoderGST(w, 'style_encoder', cfg, torch.device('cuda'))
+    monkeypatch.setattr(ops, 'GRU_FUSED_MAX_H', 16)
+    two, _ = enc.run(x, 'bf16x3')
+    monkeypatch.setattr(ops, 'GRU_FUSED_MAX_H', 1536)
+    one, _ = enc.run(x, 'bf16x3')
+    assert float((two - one).abs().max()) < 2e-6

@@ -308,6 +308,38 @@ def test_batchnorm_training_forward_backward(T, M, C, act):
     assert rel_err(dz, zt.grad) < 5e-5
 
 
+def test_deferred_sums_refuse_graph_capture_and_recover_from_an_unfinished_step(T):
+    """The regions' turn / clear bookkeeping is host-side: recording a deferred reduction into a hipGraph must raise instead
+    of replaying into a region nobody cleared; and a step that ended between a producer and its consumer must not pollute
+    the next one (step_begin clears what the unfinished step left)."""
+    rng = np.random.default_rng(3)
+    M, C = 300, 128
+    z = dev(rng.normal(size=(M, C)))
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with pytest.raises(RuntimeError, match='hipGraph'):
+        with torch.cuda.graph(g, stream=s):
+            T.colreduce(0, z=z, shift=z[0], defer=True)
+    torch.cuda.synchronize()
+    T.SumSlots.reset_all()
+    slots = T.SumSlots.on('cuda')
+    owner = object()
+    T.SumSlots.step_begin('cuda', owner)
+    T.colreduce(0, z=z, shift=None, defer=True)             # a producer whose consumer never runs (the step "fails" here)
+    assert float(slots.buf[2].abs().max()) > 0.0
+    T.SumSlots.step_begin('cuda', owner)                    # the next step starts: leftovers are cleared
+    assert float(slots.buf.abs().max()) == 0.0
+    gamma, beta = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+    st = torch.empty(4, C, device='cuda')
+    sl = T.colreduce(0, z=z, shift=None, defer=True)
+    T.bn_finalize(None, None, torch.zeros(C, device='cuda'), M, C, gamma, beta, None, None, *st, slots=sl)
+    T.SumSlots.step_end('cuda')
+    assert rel_err(st[0], z.double().mean(0)) < 1e-5        # the mean of THIS step's tensor only
+    T.SumSlots.step_begin('cuda', owner)                    # a finished step leaves nothing to clear
+    T.SumSlots.step_end('cuda')
+
+
 @pytest.mark.parametrize('sizes', [[(1000, 512), (700, 80), (5000, 1024), (77, 256)]])
 def test_batchnorm_with_deferred_sums_matches_the_two_launch_path(T, sizes):
     """colreduce(defer=True) -> bn_finalize(slots=) / bn_bwd(slots=) against the path that adds the copies up in a launch of its

@@ -114,3 +114,25 @@ def test_training_reduces_loss_and_checkpoint_loads_into_generation_model():
     long_mel = rng.uniform(0, 1, size=(1, hp['num_mels'], 30)).astype(np.float32)
     out = gen.generate(torch.from_numpy(long_mel), True, hp['voc_target'], hp['voc_overlap'], True, seed=1)
     assert np.isfinite(out).all() and len(out) > 0
+
+
+def test_recurrent_layers_wider_than_one_launch_take_the_two_launch_steps():
+    """The one-launch recurrent step holds K = 3 * rnn_dims <= 1536 in flight (rnn_dims <= 512); a wider layer must choose the
+    two-launch steps by itself and still match the float64 oracle."""
+    from estts.wavernn_training import WaveRNNTrainer
+    hp = dict(small_hp('RAW'), voc_rnn_dims=528, voc_fc_dims=528)
+    w = weights.init_wavernn(hp, seed=11)
+    model = WaveRNNTrainer.from_hparams(hp, use_graph=False)
+    assert model.fused_gru is False and model.one_chain is False
+    assert WaveRNNTrainer.from_hparams(dict(hp, voc_rnn_dims=512, voc_fc_dims=512)).fused_gru is True
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+    rng = np.random.default_rng(2)
+    B, hops = 2, 3
+    L = hops * hp['hop_length']
+    labels = rng.integers(0, 2 ** hp['bits'], size=(B, L + 1))
+    x = (2 * labels[:, :L] / (2 ** hp['bits'] - 1.) - 1.).astype(np.float32)
+    mels = rng.uniform(0, 1, size=(B, hp['num_mels'], hops + 2 * hp['voc_pad'])).astype(np.float32)
+    ref = OT.train_step(w, hp, x, labels[:, 1:], mels)
+    loss = float(model.train_step(x, labels[:, 1:], mels, lr=1e-4))
+    assert abs(loss - ref['loss']) < 3e-5 * max(1.0, abs(ref['loss']))
+    check_grads(model.gradients(), ref['grads'])

@@ -79,3 +79,28 @@ def test_shard_by_cost_is_deterministic_and_complete():
     g = torch.ones(5)
     parallel.allreduce_buckets(g, 2)                      # not distributed: untouched
     assert torch.equal(g, torch.ones(5))
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks (one child job under torch.distributed.run)
+    and print ONE line with n_gpus == 2.  On a host without a GPU the workload that can run is the gradient exchange on host
+    memory over gloo (the hot path itself has no CPU implementation); the launch path is the same for every workload."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['ESTTS_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'exchange', '--elems', '300000',
+                        '--steps', '3', '--warmup', '1'], capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['sum_correct'] is True and line['config']['backend'] == 'gloo'
+    assert line['steps'] == 3 and line['value'] > 0
+    # a launcher that starts another number of ranks than --gpus says is an error, not a silently different run
+    env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'exchange', '--elems', '1000',
+                        '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=120, env=env2, cwd=root)
+    assert r.returncode != 0 and '--gpus 2' in (r.stderr + r.stdout)

@@ -75,3 +75,44 @@ def test_noalloc_rejects_oversize_split():
     msg = lib.estts_last_error().decode()
     assert rc != 0 and 'estts_gemm_noalloc' in msg and 'scratch bytes' in msg, msg
     torch.cuda.synchronize()
+
+
+def test_noalloc_allocates_nothing_and_runs_under_stream_capture():
+    """What the name promises: no device memory is allocated by the calls (free memory and torch's reservation unchanged),
+    and a call can be recorded into a hipGraph once the scratch address has been looked up (the first call on a device
+    does that, outside any capture); the replayed graph gives the same bits as the workspace entry."""
+    lib = _lib.load()
+    x, lin, _ = _case(24, 64, 2048, 1, seed=7)              # few tiles: the automatic choice splits K
+    x2, lin2, _ = _case(300, 256, 512, 1, seed=8)           # many tiles: no split, so no ticket clear either
+    outs = [torch.full((24, 64), float('nan'), device=DEV), torch.full((300, 256), float('nan'), device=DEV)]
+    refs = [torch.empty_like(o) for o in outs]
+    ws, cnt = ops.new_gemm_workspace(DEV, 4 << 20)
+    st = torch.cuda.current_stream().cuda_stream
+    for (xx, ll), ref in zip(((x, lin), (x2, lin2)), refs):
+        a = _args(xx, ll, ref, 0)
+        a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
+        _lib.check(lib.estts_gemm(a, st), 'estts_gemm')
+    _lib.check(lib.estts_gemm_noalloc(_args(x, lin, outs[0], 0), st), 'estts_gemm_noalloc')     # address looked up here
+    torch.cuda.synchronize()
+    outs[0].fill_(float('nan'))
+    torch.cuda.synchronize()
+    free0, reserved0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
+    n0 = lib.estts_launch_count()
+    for (xx, ll), out in zip(((x, lin), (x2, lin2)), outs):
+        _lib.check(lib.estts_gemm_noalloc(_args(xx, ll, out, 0), st), 'estts_gemm_noalloc')
+    torch.cuda.synchronize()
+    assert lib.estts_launch_count() - n0 == 2
+    assert torch.cuda.mem_get_info()[0] == free0 and torch.cuda.memory_reserved() == reserved0
+    assert torch.equal(outs[0], refs[0]) and torch.equal(outs[1], refs[1])
+    for o in outs:
+        o.fill_(float('nan'))
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=s):
+        for (xx, ll), out in zip(((x, lin), (x2, lin2)), outs):
+            _lib.check(lib.estts_gemm_noalloc(_args(xx, ll, out, 0), torch.cuda.current_stream().cuda_stream), 'estts_gemm_noalloc')
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], refs[0]) and torch.equal(outs[1], refs[1])
