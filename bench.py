@@ -842,6 +842,31 @@ def main():
         return config1_cpu_seconds(args)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return launch_ranks(args.gpus)            # before anything here has touched the GPU
+    if os.environ.get('ESTTS_WATCHDOG_S'):      # a rank that stalls dumps every thread's stack and exits instead of hanging
+        import faulthandler
+        import threading
+        limit = int(os.environ['ESTTS_WATCHDOG_S'])
+        faulthandler.dump_traceback_later(limit, exit=True, file=sys.stderr)
+
+        def native_threads():
+            # shortly before the dump: what every native thread of this rank is doing (name, scheduler state, kernel wait
+            # channel) and which of the pending collectives have completed
+            time.sleep(max(limit - 5, 1))
+            from estts import parallel as par
+            rows = []
+            for tid in sorted(os.listdir('/proc/self/task'), key=int):
+                try:
+                    comm = open(f'/proc/self/task/{tid}/comm').read().strip()
+                    state = open(f'/proc/self/task/{tid}/stat').read().rsplit(')', 1)[1].split()[0]
+                    wchan = open(f'/proc/self/task/{tid}/wchan').read().strip()
+                    rows.append(f'{tid}:{comm}:{state}:{wchan}')
+                except OSError:
+                    pass
+            ov = getattr(par.GradientOverlap, 'last', None)
+            done = None if ov is None else [bool(w.is_completed()) for w in ov.works]
+            print(f"[watchdog rank {os.environ.get('RANK')}] collectives issued {None if ov is None else ov.calls} completed {done}\n"
+                  f"[watchdog rank {os.environ.get('RANK')}] threads " + ' '.join(rows), file=sys.stderr, flush=True)
+        threading.Thread(target=native_threads, daemon=True).start()
     from estts import parallel
     rank, world, local_rank = parallel.env_ranks()
     if world != args.gpus:

@@ -136,6 +136,7 @@ class AutoregressiveTransformer:
         self.r = self.max_r
         self.drop_n_heads = 0
         self.stop_prob_index = 2
+        self.fuse_step_norms = True       # incremental decoding: row norms inside the one-row products that consume them
         self.decoder_prenet_dropout = 0.0
         # DecoderPrenet's dropout is active at inference too (layers.py:394-402).  Masks come from the counter-based
         # generator keyed by (seed, site, decoder position, channel); the seed advances once per decoder call.
@@ -405,26 +406,49 @@ class AutoregressiveTransformer:
         lin_r = self._final_proj(r)
         sqrt_d = math.sqrt(np.float32(d))
 
+        y2 = torch.empty(1, d, **f32)
+        # A row-wise normalisation is folded into the one-row product that consumes it (gemm(ln=...): every column tile
+        # recomputes the norm of the single row and tile 0 writes it out for the later residual uses), which takes three
+        # launches per block off the step.  `pending` describes the normalisation whose result xc[:, :d] the next consumer
+        # needs: None when the buffer already holds it.
+        fuse = pr == 'bf16x3' and d % 8 == 0 and d <= 512 and self.fuse_step_norms
+
         def step(i):
             frame = frames[r - 1 + i * r:r + i * r]
             ops.row_zero_mask(frame, dec_mask[0, i:i + 1])
             ops.gemm(frame, self.prenet1, p1, precision=pr, dropout=(rate, seed, 0, i))
             ops.gemm(p1, self.prenet2, xc[:, :d], alpha=sqrt_d, residual=self.pe_dec[i * r:i * r + 1], precision=pr,
                      dropout=(rate, seed, 1, i))
+            pending = None
             for b, (sa, ca, ff) in enumerate(blocks):
                 row = qkv[b][i:i + 1]
-                ops.gemm(xc[:, :d], sa.qkv, row, precision=pr)
+                ops.gemm(xc[:, :d], sa.qkv, row, precision=pr, ln=pending)
+                pending = None
                 ops.attention(row[:, :d], qkv[b][:i + 1, d:2 * d], qkv[b][:i + 1, 2 * d:], xc[:, d:], 1, sa.heads, 1, i + 1,
                               d // sa.heads, key_mask=dec_mask[:, :i + 1], precision=pr)
                 ops.gemm(xc, sa.out, y, precision=pr)
-                ops.rownorm(y, xc2[:, :d], ln_a=sa.ln, residual=xc[:, :d], ln_b=sa.last_ln)
-                ops.gemm(xc2[:, :d], ca.wq, q, precision=pr)
+                if fuse:
+                    ops.gemm(xc2[:, :d], ca.wq, q, precision=pr,
+                             ln=dict(y=y, x=xc[:, :d], ln_a=sa.ln, ln_b=sa.last_ln, out=xc2[:, :d]))
+                else:
+                    ops.rownorm(y, xc2[:, :d], ln_a=sa.ln, residual=xc[:, :d], ln_b=sa.last_ln)
+                    ops.gemm(xc2[:, :d], ca.wq, q, precision=pr)
                 ops.attention(q, kv_enc[b][:, :d], kv_enc[b][:, d:], xc2[:, d:], 1, ca.heads, 1, N, d // ca.heads,
                               key_mask=enc_mask, attn=attn[b][i, :ca.heads * N].view(1, ca.heads, 1, N), precision=pr)
                 ops.gemm(xc2, ca.out, y, precision=pr)
                 if isinstance(ff, FFNLayer):
-                    ops.rownorm(y, x2, residual=xc2[:, :d], ln_b=ca.ln)
-                    ff.run(x2, hid, y, xc[:, :d], pr)
+                    first = ff.d12 if ff.fold else ff.d1
+                    if fuse:
+                        # FFNResNorm on LN(y + x): x2 = LN(y + xc2) inside the first product, which writes y2 (or hid);
+                        # its own LN(relu(LN(y2)) + x2) is left to the next consumer of xc[:, :d]
+                        ops.gemm(x2, first, y2 if ff.fold else hid, precision=pr, site='ffn',
+                                 ln=dict(y=y, x=xc2[:, :d], ln_b=ca.ln, out=x2))
+                        if not ff.fold:
+                            ops.gemm(hid, ff.d2, y2, precision=pr, site='ffn')
+                        pending = dict(y=y2, x=x2, ln_a=ff.ln, act='relu', ln_b=ff.last_ln, out=xc[:, :d])
+                    else:
+                        ops.rownorm(y, x2, residual=xc2[:, :d], ln_b=ca.ln)
+                        ff.run(x2, hid, y, xc[:, :d], pr)
                 else:
                     hist, dense = conv_hist[b], conv_dense[b]
                     k = ff.layers[0].taps
@@ -436,7 +460,7 @@ class AutoregressiveTransformer:
                     ops.gemm(self._windows(hist[last], i, 1, k, dense[last].K // k), dense[last], xc[:, :d], residual=src_row,
                              precision=pr)
             mel_rows = post_hist[0][kp - 1 + i * r:kp - 1 + (i + 1) * r]          # FinalProj writes the r new mel frames here
-            ops.gemm(xc[:, :d], lin_r, mel_rows.view(1, r * C), precision=pr)
+            ops.gemm(xc[:, :d], lin_r, mel_rows.view(1, r * C), precision=pr, ln=pending)
             ops.gemm(mel_rows, self.stop_linear, stop[i * r:(i + 1) * r], precision=pr)
             for li, lin in enumerate(post_dense[:-1]):
                 ops.gemm(self._windows(post_hist[li], i * r, r, kp, lin.K // kp), lin,

@@ -865,7 +865,9 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         }
     }
     if (a.ln_y) {   // LayerNorm prologue: only the kernel that stages a tile's source rows can compute them on the way in
-        ESTTS_CHECK_ARG(a.ln_ga && a.ln_ba && a.ln_out && (!a.ln_gb == !a.ln_bb), "estts_gemm: LayerNorm prologue needs ln_ga, ln_ba, ln_out (and ln_gb with ln_bb)");
+        ESTTS_CHECK_ARG(a.ln_out && (!a.ln_ga == !a.ln_ba) && (!a.ln_gb == !a.ln_bb) && (a.ln_ga || a.ln_gb) &&
+                        (a.ln_ga || a.ln_act == ESTTS_ACT_NONE),
+                        "estts_gemm: LayerNorm prologue needs ln_out and at least one of (ln_ga, ln_ba) / (ln_gb, ln_bb); ln_act only with the first");
         ESTTS_CHECK_ARG(a.ln_out != a.ln_y && a.ln_out != a.ln_x, "estts_gemm: ln_out must not alias ln_y / ln_x (other workgroups still read those rows)");
         ESTTS_CHECK_ARG(a.C != a.ln_y && a.C != a.ln_x && a.C != a.ln_out && a.R != a.ln_out,
                         "estts_gemm: C must not alias an operand of the LayerNorm prologue, and R must not be ln_out (written by this launch)");
@@ -876,8 +878,8 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
                         "estts_gemm: LayerNorm prologue operands must be 16-byte aligned with row strides >= c_per_tap, multiples of 4");
         const long t32 = (long)((a.M + 31) / 32) * ((a.N + 31) / 32);
         const int r = estts_launch_gemm_oneshot_conv(a, operand_kind(a), tile == 11 || (tile != 12 && t32 < 128), st);
-        ESTTS_CHECK_ARG(r != 1, "estts_gemm: this launch cannot take a LayerNorm prologue (1-D convolution with 2..8 taps, c_per_tap <= 512 and a "
-                                "multiple of 8, K <= 1536, precision 3): run estts_rownorm first");
+        ESTTS_CHECK_ARG(r != 1, "estts_gemm: this launch cannot take a LayerNorm prologue (dense layer or 1-D convolution with up to 8 taps, "
+                                "c_per_tap <= 512 and a multiple of 8, K <= 1536, precision 3): run estts_rownorm first");
         return r;
     }
     if (tile == 9 || tile == 10) {   // explicit one-shot kernel: 16 x 16 / 32 x 32 tiles

@@ -276,8 +276,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
             cc[i] = min(c, C - 4);
             // (no load under a condition -- it would become a branch with a wait of its own, one round trip each: an absent
             // operand is read from a present one and ignored)
-            ga[i] = *reinterpret_cast<const float4*>(p.ln_ga + cc[i]);
-            ba[i] = *reinterpret_cast<const float4*>(p.ln_ba + cc[i]);
+            ga[i] = *reinterpret_cast<const float4*>((p.ln_ga ? p.ln_ga : p.ln_gb) + cc[i]);
+            ba[i] = *reinterpret_cast<const float4*>((p.ln_ba ? p.ln_ba : p.ln_bb) + cc[i]);
             gb[i] = *reinterpret_cast<const float4*>((p.ln_gb ? p.ln_gb : p.ln_ga) + cc[i]);
             bb[i] = *reinterpret_cast<const float4*>((p.ln_bb ? p.ln_bb : p.ln_ba) + cc[i]);
         }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
                     y[r][i].w = (y[r][i].w - mean[r]) * inv[r] * g[i].w + b[i].w;
                 }
         };
-        layer_norm(ga, ba);
+        if (p.ln_ga) layer_norm(ga, ba);      // (absent: the rows are LNb(ln_y + ln_x); the launcher then requires ln_act = none)
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
@@ -518,7 +518,9 @@ int launch_k(const estts_gemm_args& a, int kind, dim3 grid, int S, hipStream_t s
 }  // namespace
 
 int estts_launch_gemm_oneshot_conv(const estts_gemm_args& a, int kind, int tile16, hipStream_t st) {
-    if (kind != 2 || (a.K & 7) || (a.c_per_tap & 7) || a.batch > 1) return 1;
+    // (a dense layer is the one-tap case of the same kernel; it comes here only for the LayerNorm prologue, which needs the
+    // staged rows -- without one, gemm_oneshot_kernel's direct fragment loads are the faster way to read A)
+    if (!(kind == 2 || (kind == 1 && a.ln_y)) || (a.K & 7) || (a.c_per_tap & 7) || a.batch > 1) return 1;
     const int nks = (a.K + 31) / 32;
     const int S = (nks + 7) / 8;
     if (S > 6) return 1;
@@ -533,7 +535,8 @@ int estts_launch_gemm_oneshot_conv(const estts_gemm_args& a, int kind, int tile1
     if (grid.y > 65535) return 1;
     const int lnch = a.ln_y ? (a.c_per_tap <= 256 ? 1 : 2) : 0;
     if (lnch && (a.c_per_tap > 512 || a.taps > 8 || a.precision != 3 || (!tile16 && lnch == 2 && S > 3) ||
-                 (a.ln_act != ESTTS_ACT_NONE && a.ln_act != ESTTS_ACT_RELU))) return 1;   // (the last: 256 registers and spills)
+                 (a.ln_act != ESTTS_ACT_NONE && a.ln_act != ESTTS_ACT_RELU) ||
+                 (!a.ln_ga && a.ln_act != ESTTS_ACT_NONE))) return 1;   // (S > 3 there: 256 registers and spills)
 #define ESTTS_CONV_GO(t_)                                                                                               \
     (lnch == 0 ? (a.precision == 3 ? launch_conv_s<3, t_, 0>(a, grid, S, rows_staged, lda_s, smem, st)                  \
                                    : launch_conv_s<1, t_, 0>(a, grid, S, rows_staged, lda_s, smem, st))                 \

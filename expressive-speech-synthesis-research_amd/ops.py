@@ -229,8 +229,15 @@ def new_gemm_workspace(device, nbytes=4 << 20):
 def can_fuse_ln(lin, M, N_out=None, precision='bf16x3', site=None, act=None):
     """True when gemm(..., ln=...) can compute its input rows as a LayerNorm combination on the way in (estts_gemm_args.ln_y):
     a 1-D convolution of 2..8 taps over at most 1024 rows, c_per_tap <= 512, K <= 1536, split-bf16 operands, no activation or
-    ReLU between the two norms, and not while a step program is being recorded.  Callers fall back to rownorm() + gemm()."""
-    if _program is not None or precision_at(precision, site) != 'bf16x3' or act not in (None, 'relu'):
+    ReLU between the two norms, and not while a step program is being recorded (a decoding step convolves a window of history
+    rows of which only the last is new: there is nothing to recompute the older ones from); or a dense layer over at most 16
+    rows with K <= 512 (the one-row products of incremental decoding: every column tile recomputes the norm of its rows,
+    which costs nothing when there is one).  Callers fall back to rownorm() + gemm()."""
+    if precision_at(precision, site) != 'bf16x3' or act not in (None, 'relu'):
+        return False
+    if lin.taps == 1:
+        return M <= 16 and lin.K % 8 == 0 and lin.K <= 512
+    if _program is not None:
         return False
     C = lin.c_per_tap
     if not (2 <= lin.taps <= 8 and C % 8 == 0 and C <= 512 and lin.K % 8 == 0 and lin.K <= 1536 and M <= 1024):
@@ -295,7 +302,10 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
         if xr is not None:
             _check_f32(xr, 'ln.x')
             a.ln_x, a.ln_ldx = xr.data_ptr(), xr.stride(0)
-        a.ln_ga, a.ln_ba = ln['ln_a'][0].data_ptr(), ln['ln_a'][1].data_ptr()
+        if ln.get('ln_a') is not None:
+            a.ln_ga, a.ln_ba = ln['ln_a'][0].data_ptr(), ln['ln_a'][1].data_ptr()
+        elif ln.get('ln_b') is None or ln.get('act') not in (None, 'linear', 'none'):
+            raise ValueError('gemm: ln= needs ln_a or ln_b, and an activation only with ln_a')
         if ln.get('ln_b') is not None:
             a.ln_gb, a.ln_bb = ln['ln_b'][0].data_ptr(), ln['ln_b'][1].data_ptr()
         a.ln_act, a.ln_eps = ACT[ln.get('act')], ln.get('eps', 1e-6)

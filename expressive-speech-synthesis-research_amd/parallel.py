@@ -116,6 +116,7 @@ class GradientOverlap:
         self.hi = flat.numel()
         self.works = []
         self.calls = []          # (lo, hi) of every collective issued, for tests
+        GradientOverlap.last = self      # (diagnostics: a watchdog can ask which collectives are still pending)
 
     def ready(self, lo):
         lo = max(0, min(int(lo), self.hi))

@@ -122,12 +122,16 @@ typedef struct estts_gemm_args {
     int32_t batch;
     int64_t batch_stride_a, batch_stride_w, batch_stride_c, batch_stride_v;
     /* LayerNorm prologue (ln_y != NULL): the A operand is not read from A but computed per source row, over c_per_tap
-     * columns, as  a = LNb( act_ln( LNa(ln_y[row]) ) + ln_x[row] )  -- LNa = (ln_ga, ln_ba), LNb = (ln_gb, ln_bb) or none,
-     * ln_x or none, act_ln one of ESTTS_ACT_* -- i.e. estts_rownorm fused into the convolution that consumes it
-     * (SelfAttentionResNorm's LN(LN(y) + x) in front of CNNResNorm's first Conv1D, TransformerTTS/model/layers.py:163-168 and
-     * :35-40).  Every row is also written once to ln_out (float32, ln_ldo floats per row), which must not alias ln_y / ln_x.
-     * Only 1-D convolutions (taps 2..8) over few rows with c_per_tap <= 512 can take it (the kernel that stages a tile's
-     * source rows in LDS): estts_gemm fails with an error otherwise and the caller runs estts_rownorm itself. */
+     * columns, as  a = LNb( act_ln( LNa(ln_y[row]) ) + ln_x[row] )  -- LNa = (ln_ga, ln_ba) or none (then act_ln must be
+     * none: a = LNb(ln_y + ln_x), CrossAttentionResnorm, layers.py:270-274), LNb = (ln_gb, ln_bb) or none (at least one of
+     * the two), ln_x or none, act_ln one of ESTTS_ACT_NONE / _RELU -- i.e. estts_rownorm fused into the layer that consumes
+     * it (SelfAttentionResNorm's LN(LN(y) + x) in front of CNNResNorm's first Conv1D, TransformerTTS/model/layers.py:163-168
+     * and :35-40; FFNResNorm's LN(relu(LN(y)) + x) in front of the next block's query / key / value projection, :65-71).
+     * Every row is also written once to ln_out (float32, ln_ldo floats per row), which must not alias ln_y / ln_x.
+     * Dense layers and 1-D convolutions (up to 8 taps) over few rows with c_per_tap <= 512 can take it (the kernel that
+     * stages a tile's source rows in LDS; every column tile recomputes the norms of its rows, so it pays where the rows are
+     * few -- the one-row products of incremental decoding -- or the column tiles are): estts_gemm fails with an error
+     * otherwise and the caller runs estts_rownorm itself. */
     const float* ln_y; const float* ln_x;
     const float* ln_ga; const float* ln_ba; const float* ln_gb; const float* ln_bb;
     float* ln_out;

@@ -162,6 +162,37 @@ def test_incremental_predict_matches_full_redecode(system_type, r, conv_blocks):
     assert np.abs(a['mel'].cpu().numpy() - b['mel'].cpu().numpy()).max() < 2e-4
 
 
+@pytest.mark.parametrize('system_type,r,dense,fold', [('style_text', 2, 2, True), ('speaker_text', 1, 2, False), ('text', 3, 1, True)])
+def test_step_norms_folded_into_their_consumers_change_nothing(system_type, r, dense, fold):
+    """Incremental decoding with the row norms computed inside the one-row products that consume them (the default) against
+    the same steps with every norm as a launch of its own: same kernels downstream of the rows, so the mels agree to 1e-5; the
+    folded form issues three launches per dense block fewer."""
+    from estts import _lib
+    cfg = small_cfg(system_type, dense=dense)
+    w = weights.init_autoregressive_transformer(cfg, seed=23)
+    w['decoder_postnet.stop_linear.bias'] = np.array([5.0, 0.0, -5.0], np.float32)        # the stop class never wins
+    rng = np.random.default_rng(9)
+    tokens = rng.integers(1, cfg['vocab_size'], size=12)
+    spk = rng.normal(size=(1, cfg['speaker_embed_dim'])).astype(np.float32) if 'speaker' in system_type else None
+    ref_mel = rng.normal(size=(40, 80)).astype(np.float32) if 'style' in system_type else None
+    outs, launches = [], []
+    lib = _lib.load()
+    for fused in (True, False):
+        model = AutoregressiveTransformer(w, cfg, fold_ffn=fold)
+        model.set_constants(reduction_factor=r)
+        model.fuse_step_norms = fused
+        n0 = lib.estts_launch_count()
+        outs.append(model.predict(tokens, ref_mel, spk, max_length=8 * r, encode=False, verbose=False))
+        launches.append(lib.estts_launch_count() - n0)
+    a, b = outs
+    assert a['mel'].shape == b['mel'].shape == (9 * r, 80)
+    assert np.abs(a['mel'].cpu().numpy() - b['mel'].cpu().numpy()).max() < 1e-5
+    for name in a['decoder_attention']:
+        assert np.abs(a['decoder_attention'][name].cpu().numpy() - b['decoder_attention'][name].cpu().numpy()).max() < 1e-5
+    # 9 steps; three norms per dense block (the last block's third norm moves into the final projection), one per conv block
+    assert launches[1] - launches[0] == 9 * (3 * dense + (2 - dense)), launches
+
+
 def test_grouped_stop_checks_give_the_same_utterance():
     """predict(stop_check_every=k): the stop decision is read back once per k decoder steps; the utterance ends at the same step
     whatever k is, also when that step falls inside a group or is the very first one."""

@@ -221,13 +221,46 @@ def test_gemm_layernorm_prologue(B, T, cin, taps, lpad, N, form):
     assert torch.isnan(rows[:, cin:]).all() and torch.isnan(out[:, N:]).all()
     assert (rows[:, :cin] - rows_ref).abs().max().item() < 2e-5 * max(1.0, rows_ref.abs().max().item())
     assert ((out[:, :N] - out_ref).abs().max() / out_ref.abs().max()).item() < 2e-5
-    # what cannot take the prologue says so (dense layer), and aliasing is refused
+    # what cannot take the prologue says so (rows wider than 512), and aliasing is refused; a dense layer is offered the
+    # prologue only for a handful of rows (every column tile recomputes the norms)
     dense = PackedLinear(_rand(N, cin, seed=29).numpy(), device=DEV)
-    assert not ops.can_fuse_ln(dense, M)
+    assert not ops.can_fuse_ln(dense, M) and ops.can_fuse_ln(dense, 16)
+    wide = PackedLinear(_rand(N, 1024, seed=30).numpy(), device=DEV)
+    wide_rows = torch.empty(M, 1024, device=DEV)
     with pytest.raises(RuntimeError, match='LayerNorm prologue'):
-        ops.gemm(rows[:, :cin], dense, out[:, :N], ln=dict(y=yd, ln_a=ln_a, out=rows[:, :cin]))
+        ops.gemm(wide_rows, wide, out[:, :N],
+                 ln=dict(y=torch.zeros(M, 1024, device=DEV), ln_a=(torch.ones(1024, device=DEV), torch.zeros(1024, device=DEV)),
+                         out=wide_rows))
     with pytest.raises(ValueError, match='alias'):
         ops.gemm(rows[:, :cin], lin, yd, seg_len=T, ln=dict(y=yd, ln_a=ln_a, out=rows[:, :cin]))
+
+
+@pytest.mark.parametrize('M,K,N', [(1, 256, 768), (1, 256, 800), (3, 128, 40), (16, 512, 256), (7, 264, 72)])
+@pytest.mark.parametrize('form', ['double', 'relu_double', 'second_only'])
+def test_dense_layernorm_prologue_for_few_rows(M, K, N, form):
+    # the one-row products of incremental decoding: LN(LN(y) + x) (SelfAttentionResNorm), LN(relu(LN(y)) + x) (FFNResNorm) and
+    # LN(y + x) (CrossAttentionResnorm) computed inside the dense layer that consumes them, against estts_rownorm + the same
+    # layer; the rows are also written out once
+    y, x = _rand(M, K + 4, seed=31), _rand(M, K, seed=32)
+    ln_a = (_rand(K, seed=33).abs().to(DEV) + 0.5, _rand(K, seed=34).to(DEV))
+    ln_b = (_rand(K, seed=35).abs().to(DEV) + 0.5, _rand(K, seed=36).to(DEV))
+    lin = PackedLinear(_rand(N, K, seed=37, scale=1 / math.sqrt(K)).numpy(), bias=_rand(N, seed=38).numpy(), device=DEV)
+    yd, xd = y.to(DEV)[:, :K], x.to(DEV)
+    kw = {'double': dict(ln_a=ln_a, ln_b=ln_b, act=None), 'relu_double': dict(ln_a=ln_a, ln_b=ln_b, act='relu'),
+          'second_only': dict(ln_a=None, ln_b=ln_b, act=None)}[form]
+    assert ops.can_fuse_ln(lin, M)
+    rows_ref = torch.empty(M, K, device=DEV)
+    ops.rownorm(yd, rows_ref, ln_a=kw['ln_a'], act=kw['act'], residual=xd, ln_b=kw['ln_b'])
+    out_ref = torch.empty(M, N, device=DEV)
+    ops.gemm(rows_ref, lin, out_ref, precision='bf16x3')
+    rows = torch.full((M, K + 8), float('nan'), device=DEV)
+    out = torch.full((M, N + 4), float('nan'), device=DEV)
+    ops.gemm(rows[:, :K], lin, out[:, :N], precision='bf16x3', ln=dict(y=yd, x=xd, out=rows[:, :K], **kw))
+    assert torch.isnan(rows[:, K:]).all() and torch.isnan(out[:, N:]).all()
+    assert (rows[:, :K] - rows_ref).abs().max().item() < 2e-5 * max(1.0, rows_ref.abs().max().item())
+    assert ((out[:, :N] - out_ref).abs().max() / out_ref.abs().max()).item() < 2e-5
+    with pytest.raises(ValueError, match='ln_a or ln_b'):
+        ops.gemm(rows[:, :K], lin, out[:, :N], ln=dict(y=yd, x=xd, out=rows[:, :K], ln_a=None, ln_b=ln_b, act='relu'))
 
 
 def test_gemm_posenc_residual_shared_rows():
