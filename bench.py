@@ -678,14 +678,41 @@ def predict_bench(args, rank, world, dist):
             dt = (time.perf_counter() - t0) / args.steps
             res[f'r{r}_{"incremental" if cached else "full_redecode"}'] = {'frames': int(out['mel'].shape[0]), 's_per_utterance': dt,
                                                                            'mel_frames_per_s': out['mel'].shape[0] / dt}
+    # launches and weight bytes of one decoder step (r = 10): the step is a chain of one-row products, so what it can be priced
+    # against is the stream of its weights (bf16 hi + lo = 4 bytes per weight: decoder blocks, prenet, projections, post-net)
+    model.set_constants(reduction_factor=10)
+    n_launch, out = launches_of(lambda: model.predict(tokens, ref_mel, None, max_length=T - 10, encode=False, verbose=False))
+    steps_r10 = out['mel'].shape[0] // 10
+    n_enc, _ = launches_of(lambda: model.predict(tokens, ref_mel, None, max_length=10, encode=False, verbose=False))   # encoder + 2 steps
+    per_step = (n_launch - n_enc) / max(steps_r10 - 2, 1)
+    wbytes = 4.0 * sum(int(np.prod(np.shape(v))) for k, v in w.items()
+                       if k.startswith(('decoder.', 'decoder_prenet.', 'decoder_postnet.')) and k.endswith('.kernel'))
+    wbytes += 4.0 * cfg['decoder_model_dimension'] * 10 * cfg['mel_channels']          # FinalProj restricted to r * 80 columns
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # the reference's own loop (the whole decoder again at every step) in float32 NumPy, bounded to the first 100 frames:
+        # its cost per frame grows with the length, so the rate of a full 600-frame utterance is lower still
+        from oracle import tts_numpy as O
+        t0 = time.perf_counter()
+        o = O.autoregressive_predict(w, cfg, tokens, ref_mel, None, r=10, max_length=90, dtype=np.float32)
+        t_cpu = time.perf_counter() - t0
+        cpu = {'value': o['mel'].shape[0] / t_cpu, 'unit': 'mel-frames/s', 'cores': min(os.cpu_count() or 1, 16), 'kind': 'port',
+               'sample': f"the first {o['mel'].shape[0]} frames of the same utterance (N={N}, r=10), float32 NumPy restatement of the "
+                         f"reference's re-decode-everything loop (oracle/tts_numpy.py autoregressive_predict; BLAS threads as the host gives)"}
     if rank == 0:
         best = res['r10_incremental']
+        us_step = best['s_per_utterance'] * 1e6 / steps_r10
+        roofline = {'bound': 'hbm', 'achieved': wbytes / (us_step * 1e-6) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                    'kernel': 'decoder step (chain of one-row products; bytes = the step\'s weights, bf16 hi + lo)', 'traffic': None,
+                    'algorithmic_bytes': wbytes, 'launches_per_step': per_step, 'us_per_step': us_step,
+                    'note': 'latency-bound: every launch of the chain depends on the one before it'}
+        roofline['frac'] = roofline['achieved'] / roofline['peak']
         print(json.dumps({'metric': 'mel-frames/sec (AutoregressiveTransformer.predict, one utterance)', 'value': best['mel_frames_per_s'],
                           'unit': 'mel-frames/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': 1, 'ms_per_step': best['s_per_utterance'] * 1e3,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
                           'config': {'workload': f'AR predict, style_text, N={N}, {T} frames, reduction factor 10 (value) and 1; '
                                                  f'{args.precision} MFMA operands'},
-                          'variants': res, 'roofline': None, 'cpu_baseline': None}))
+                          'variants': res, 'roofline': roofline, 'cpu_baseline': cpu}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -800,6 +827,30 @@ def launch_ranks(n):
     if line.get('n_gpus') != n:
         print(f"bench.py: asked for {n} ranks, the line reports n_gpus = {line.get('n_gpus')}", file=sys.stderr)
         raise SystemExit(1)
+
+
+def serving_pass(w, cfg, tokens, args):
+    """The same lever through the product entry point: ForwardTransformer.predict_many (what scripts/synthesize_sentences.py
+    --text-file calls) on 64 copies of the benchmark sentence, durations PREDICTED (the duration predictor's bias is raised so
+    that they sum to about the benchmark's 600 frames; one small device-to-host read per sentence decides the frame count),
+    lanes replaying the graphs of the shapes they have met.  Includes the copy of every result out of the graph buffers."""
+    w2 = dict(w)
+    w2['dur_pred.linear.bias'] = np.asarray(w['dur_pred.linear.bias'], np.float32) + 5.0
+    model = ForwardTransformer(w2, cfg, precision=args.precision)
+    sentences = [tokens[0]] * 64
+    points = []
+    for k in (1, 2, 4):
+        model.predict_many(sentences[:3 * k], encode=False, in_flight=k)          # first visit, capture, replay
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = model.predict_many(sentences, encode=False, in_flight=k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        frames = sum(int(o['mel'].shape[0]) for o in outs)
+        points.append({'in_flight': k, 'sentences': len(outs), 'frames_per_sentence': frames / len(outs),
+                       'ms_per_sentence': dt * 1e3 / len(outs), 'value': frames / dt, 'unit': 'mel-frames/s'})
+    return {'note': 'ForwardTransformer.predict_many, predicted durations, results copied out of the lanes\' graph buffers',
+            'points': points}
 
 
 def main():
@@ -1030,6 +1081,7 @@ def main():
                                  launches_per_step=train_line['config']['launches_per_step'])
         if world == 1 and args.workload == 'forward' and graph is not None and not args.no_in_flight:
             line['in_flight'] = in_flight_pass(w, cfg, tok_d, dur_d, T, want_attn, args, out['mel'])
+            line['serving'] = serving_pass(w, cfg, tokens, args)
         if world == 1 and not args.no_wavernn:
             line['wavernn'] = wavernn_pass(args.precision, cpu_leg=not args.no_cpu_baseline, kernel_table=args.kernel_table)
             if args.workload == 'forward' and B == 1:

@@ -3,6 +3,7 @@
 torch is used for device memory and the current stream only; no torch op
 computes anything on the hot path.
 """
+import contextlib
 import ctypes
 import math
 import os
@@ -221,6 +222,21 @@ def gemm_workspace(device):
     return ws
 
 
+_ws_override = None
+
+
+@contextlib.contextmanager
+def private_workspace(ws):
+    """Every gemm() issued inside the block uses the split-K scratch `ws` (new_gemm_workspace()) instead of the device's shared
+    one: for launch sequences that run beside others on a stream of their own."""
+    global _ws_override
+    prev, _ws_override = _ws_override, ws
+    try:
+        yield ws
+    finally:
+        _ws_override = prev
+
+
 def new_gemm_workspace(device, nbytes=4 << 20):
     """A private split-K scratch for gemm(workspace=...)."""
     return (torch.empty(nbytes // 4, dtype=torch.float32, device=device), torch.zeros(_N_COUNTERS, dtype=torch.int32, device=device))
@@ -312,7 +328,7 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     if stats is not None:
         a.stat_slots, a.stat_shift = stats[0], _ptr(stats[1])
     if split:
-        ws, cnt = gemm_workspace(x.device) if workspace is None else workspace
+        ws, cnt = workspace if workspace is not None else (_ws_override if _ws_override is not None else gemm_workspace(x.device))
         a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
     if lin.taps == 1 and x.shape[1] < lin.K:
         raise ValueError(f'gemm: x has {x.shape[1]} columns, weight expects K={lin.K}')

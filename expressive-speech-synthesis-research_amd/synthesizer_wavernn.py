@@ -27,3 +27,11 @@ class Synthesize:
         """mel: [1, feat, T] in the reference's [0, 1] normalisation (host or device) -> float64 waveform."""
         hp = self.hp
         return self.voc_model.generate(mel, batch_pred, hp['voc_target'], hp['voc_overlap'], hp['mu_law'])
+
+    def generate_many(self, mels, batch_pred=True):
+        """Several utterances in ONE batched generation (every fold of every utterance is one sequence of the step kernels;
+        the reference vocodes them one after the other, synthesize_sentences_speaker.py:56-75).  mels: list of [feat, T] or
+        [1, feat, T] mels in [0, 1] (host or device) -> list of float64 waveforms."""
+        hp = self.hp
+        flat = [m[0] if getattr(m, 'ndim', 2) == 3 else m for m in mels]
+        return self.voc_model.generate_batch(flat, batch_pred, hp['voc_target'], hp['voc_overlap'], hp['mu_law'])

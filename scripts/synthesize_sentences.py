@@ -28,11 +28,45 @@ from estts.config_manager import ConfigManager  # noqa: E402
 from estts.synthesizer_wavernn import Synthesize  # noqa: E402
 
 
+def synthesize_file(args, model):
+    """The reference's loop over sentences (synthesize_sentences_speaker.py:56-75) with the sentences overlapped: the forward
+    model keeps --in-flight of them on the GPU at once, and WaveRNN takes every fold of every utterance as one batch."""
+    if args.model != 'forward':
+        raise SystemExit('--text-file runs the forward model (the autoregressive model synthesises one sentence per call)')
+    with open(args.text_file) as f:
+        texts = [line.strip() for line in f if line.strip()]
+    hp = configs.wavernn_hparams()
+    vocoder = Synthesize(args.vocoder_weights, hp)
+    model.predict_many(texts[:args.in_flight], in_flight=args.in_flight)          # library load, workspaces, first-visit shapes
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = model.predict_many(texts, in_flight=args.in_flight)
+    torch.cuda.synchronize()
+    t_tts = time.perf_counter() - t0
+    frames = sum(int(o['mel'].shape[0]) for o in outs)
+    keep = [i for i, o in enumerate(outs) if o['mel'].shape[0] >= 21]            # (WaveRNN's closing fade covers 20 hops)
+    t0 = time.perf_counter()
+    wavs = vocoder.generate_many([((outs[i]['mel'].t() + 4.) / 8.) for i in keep]) if keep else []
+    torch.cuda.synchronize()
+    t_voc = time.perf_counter() - t0
+    stem = args.out[:-4] if args.out.endswith('.npy') else args.out
+    for i, wav in zip(keep, wavs):
+        np.save(f'{stem}_{i}.npy', wav)
+    audio = sum(len(w) for w in wavs) / hp['sample_rate']
+    print(f'{len(texts)} sentences, {args.in_flight} in flight: {frames} mel frames in {t_tts * 1e3:.1f} ms '
+          f'({frames / t_tts:.0f} mel-frames/s, {t_tts / len(texts) * 1e3:.3f} ms per sentence); '
+          f'{len(wavs)} utterances vocoded in one batch: {audio:.2f} s of audio in {t_voc:.2f} s -> {stem}_<i>.npy')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', required=True)
     ap.add_argument('--model', default='forward', choices=['forward', 'autoregressive'])
-    ap.add_argument('--text', required=True)
+    ap.add_argument('--text')
+    ap.add_argument('--text-file', help='one sentence (phonemes) per line: all of them are synthesised, --in-flight at a time by the '
+                                        'forward model, and vocoded in one batched WaveRNN generation; outputs <out stem>_<i>.npy')
+    ap.add_argument('--in-flight', type=int, default=4, help='sentences the forward model keeps on the GPU at once with --text-file '
+                                                             '(ForwardTransformer.predict_many; 1 = one at a time)')
     ap.add_argument('--tts-weights')
     ap.add_argument('--vocoder-weights')
     ap.add_argument('--ref-mel', help='.npy reference mel (T, 80) for the style encoder (autoregressive model)')
@@ -45,10 +79,14 @@ def main():
     ap.add_argument('--max-length', type=int, default=1000, help='most mel frames the autoregressive model may decode (predict\'s max_length)')
     ap.add_argument('--out', default='out.npy')
     args = ap.parse_args()
+    if not args.text and not args.text_file:
+        ap.error('give --text or --text-file')
     cm = ConfigManager(args.config, args.model)
     if args.system_type:
         cm.config['system_type'] = args.system_type
     model = cm.load_model(args.tts_weights, verbose=True)
+    if args.text_file:
+        return synthesize_file(args, model)
     t0 = time.perf_counter()
     if args.model == 'forward':
         out = model.predict(args.text)

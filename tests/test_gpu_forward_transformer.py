@@ -151,6 +151,57 @@ def test_full_size_model_properties():
     print(f'full-size mel-L1 vs fp32 restatement: bf16x3 {l1:.2e}, bf16 {l1_bf16:.2e}')
 
 
+@pytest.mark.parametrize('in_flight', [1, 2, 4])
+def test_predict_many_is_bit_identical_to_one_at_a_time(in_flight):
+    """ForwardTransformer.predict_many: sentences of several lengths, repeated so that every lane meets shapes for the first
+    time (launch by launch), the second time (capture) and later (replay); every result must equal predict() on the same
+    sentence bit for bit, durations and attention maps included."""
+    cfg = small_cfg()
+    w = weights.init_forward_transformer(cfg, seed=3)
+    model = ForwardTransformer(w, cfg)
+    rng = np.random.default_rng(5)
+    base = [rng.integers(1, cfg['vocab_size'], size=n).astype(np.int32) for n in (23, 31, 23, 17, 40, 31, 23)]
+    sentences = base * 3
+    single = [model.predict(torch.from_numpy(t)[None], encode=False) for t in base]
+    for attn in (False, True):
+        many = model.predict_many(sentences, encode=False, in_flight=in_flight, return_attention=attn)
+        assert len(many) == len(sentences)
+        for i, out in enumerate(many):
+            ref = single[i % len(base)]
+            assert out['mel'].shape == ref['mel'].shape and torch.equal(out['mel'], ref['mel']), i
+            assert torch.equal(out['duration'], ref['duration']) and torch.equal(out['expanded_mask'], ref['expanded_mask'])
+            if attn:
+                for name, a in ref['decoder_attention'].items():
+                    assert torch.equal(out['decoder_attention'][name], a), (i, name)
+                for name, a in ref['encoder_attention'].items():
+                    assert torch.equal(out['encoder_attention'][name], a), (i, name)
+            else:
+                assert out['decoder_attention'] == {} and out['encoder_attention'] == {}
+    lanes = model._lanes(in_flight)
+    assert any(len(l.graphs) > 0 for l in lanes)            # shapes that came back were replayed from graphs
+
+
+def test_synthesis_script_with_sentences_in_flight(tmp_path, monkeypatch):
+    """scripts/synthesize_sentences.py --text-file: predict_many + one batched WaveRNN generation."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('synth_script_many', os.path.join(root, 'scripts', 'synthesize_sentences.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = 'D@ kwIk braUn fQks dZVmps oUv@ D@ leIzi dQg @nd kips rVnIN'
+    tf = tmp_path / 'sentences.txt'
+    tf.write_text('\n'.join([text, text[:40], text + ' ' + text[:20], text]) + '\n')
+    out = tmp_path / 'wav.npy'
+    monkeypatch.setattr(sys, 'argv', ['synthesize_sentences.py', '--config', os.path.join(root, 'config', 'wavernn'), '--model', 'forward',
+                                      '--text-file', str(tf), '--in-flight', '2', '--out', str(out)])
+    mod.main()
+    wavs = [np.load(tmp_path / f'wav_{i}.npy') for i in range(4)]
+    assert all(w.ndim == 1 and len(w) > 1000 and np.isfinite(w).all() for w in wavs)
+    assert len(wavs[0]) == len(wavs[3]) and len(wavs[1]) < len(wavs[0]) < len(wavs[2])
+
+
 def test_end_to_end_synthesis_script(tmp_path, monkeypatch):
     """scripts/synthesize_sentences.py: ConfigManager -> ForwardTransformer.predict -> (mel + 4) / 8 hand-off -> WaveRNN,
     on seeded random weights (checks the plumbing: shapes, finiteness, that nothing leaves the GPU path)."""
