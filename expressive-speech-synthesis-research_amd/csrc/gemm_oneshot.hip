@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_kernel(const estts_gemm_
 // LNCH > 0: the staged rows are not read from A but computed as LNb(act(LNa(ln_y)) + ln_x) (see estts_gemm_args.ln_y): one
 // wave per source row, LNCH float4 per lane (c_per_tap <= 256 LNCH), every operand of the wave's rows requested before the
 // first reduction; the workgroups of column tile 0 also write their own rows (not the halo) to ln_out.
-template <int NSPLIT, int T, int NW, int S, int LNCH>
+template <int NSPLIT, int T, int NW, int S, int LNCH, bool LNA>
 __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_gemm_args p, const int rows_staged, const int lda_s) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
     constexpr int NF = 4 * T * T;
@@ -276,8 +276,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
             cc[i] = min(c, C - 4);
             // (no load under a condition -- it would become a branch with a wait of its own, one round trip each: an absent
             // operand is read from a present one and ignored)
-            ga[i] = *reinterpret_cast<const float4*>((p.ln_ga ? p.ln_ga : p.ln_gb) + cc[i]);
-            ba[i] = *reinterpret_cast<const float4*>((p.ln_ba ? p.ln_ba : p.ln_bb) + cc[i]);
+            if constexpr (LNA) {
+                ga[i] = *reinterpret_cast<const float4*>(p.ln_ga + cc[i]);
+                ba[i] = *reinterpret_cast<const float4*>(p.ln_ba + cc[i]);
+            } else {
+                ga[i] = ba[i] = make_float4(0.f, 0.f, 0.f, 0.f);       // (never used)
+            }
             gb[i] = *reinterpret_cast<const float4*>((p.ln_gb ? p.ln_gb : p.ln_ga) + cc[i]);
             bb[i] = *reinterpret_cast<const float4*>((p.ln_bb ? p.ln_bb : p.ln_ba) + cc[i]);
         }
@@ -334,7 +338,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
                     y[r][i].w = (y[r][i].w - mean[r]) * inv[r] * g[i].w + b[i].w;
                 }
         };
-        if (p.ln_ga) layer_norm(ga, ba);      // (absent: the rows are LNb(ln_y + ln_x); the launcher then requires ln_act = none)
+        // (LNA false: the rows are LNb(ln_y + ln_x); a template parameter, not a test of the pointer: a branch around the first
+        // norm cost the launches that have one 25 % -- 11 -> 14 us at 600 x 512 x 768 -- through the schedule it left)
+        if constexpr (LNA) layer_norm(ga, ba);
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
 #pragma unroll
@@ -472,11 +478,11 @@ bool allow_large_lds(const void* kern, bool (&raised)[64]) {
     return true;
 }
 
-template <int NSPLIT, int T, int LNCH>
+template <int NSPLIT, int T, int LNCH, bool LNA>
 int launch_conv_s(const estts_gemm_args& a, dim3 grid, int S, int rows_staged, int lda_s, size_t smem, hipStream_t st) {
 #define ESTTS_ONESHOT_CASE(s_)                                                                                              \
     case s_: {                                                                                                              \
-        auto kern = gemm_oneshot_conv_kernel<NSPLIT, T, 8, s_, LNCH>;                                                      \
+        auto kern = gemm_oneshot_conv_kernel<NSPLIT, T, 8, s_, LNCH, LNA>;                                                    \
         static bool raised[64] = {};       /* per GPU: the attribute belongs to the device's copy of the kernel */         \
         if (!allow_large_lds(reinterpret_cast<const void*>(kern), raised)) return -2;                                      \
         ESTTS_LAUNCH(kern, grid, dim3(512), smem, st, a, rows_staged, lda_s);                                         \
@@ -538,10 +544,15 @@ int estts_launch_gemm_oneshot_conv(const estts_gemm_args& a, int kind, int tile1
                  (a.ln_act != ESTTS_ACT_NONE && a.ln_act != ESTTS_ACT_RELU) ||
                  (!a.ln_ga && a.ln_act != ESTTS_ACT_NONE))) return 1;   // (S > 3 there: 256 registers and spills)
 #define ESTTS_CONV_GO(t_)                                                                                               \
-    (lnch == 0 ? (a.precision == 3 ? launch_conv_s<3, t_, 0>(a, grid, S, rows_staged, lda_s, smem, st)                  \
-                                   : launch_conv_s<1, t_, 0>(a, grid, S, rows_staged, lda_s, smem, st))                 \
-     : lnch == 1 ? launch_conv_s<3, t_, 1>(a, grid, S, rows_staged, lda_s, smem, st)                                   \
-                 : launch_conv_s<3, t_, 2>(a, grid, S, rows_staged, lda_s, smem, st))
+    (lnch == 0 ? (a.precision == 3 ? launch_conv_s<3, t_, 0, true>(a, grid, S, rows_staged, lda_s, smem, st)            \
+                                   : launch_conv_s<1, t_, 0, true>(a, grid, S, rows_staged, lda_s, smem, st))           \
+     : lnch == 1 ? launch_conv_s<3, t_, 1, true>(a, grid, S, rows_staged, lda_s, smem, st)                             \
+                 : launch_conv_s<3, t_, 2, true>(a, grid, S, rows_staged, lda_s, smem, st))
+    if (lnch && !a.ln_ga) {      // LNb(ln_y + ln_x): built for the 16-row tile only (the few-row products that use it)
+        if (!tile16) return 1;
+        return lnch == 1 ? launch_conv_s<3, 1, 1, false>(a, grid, S, rows_staged, lda_s, smem, st)
+                         : launch_conv_s<3, 1, 2, false>(a, grid, S, rows_staged, lda_s, smem, st);
+    }
     return tile16 ? ESTTS_CONV_GO(1) : ESTTS_CONV_GO(2);
 #undef ESTTS_CONV_GO
 }

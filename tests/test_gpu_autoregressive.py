@@ -165,8 +165,9 @@ def test_incremental_predict_matches_full_redecode(system_type, r, conv_blocks):
 @pytest.mark.parametrize('system_type,r,dense,fold', [('style_text', 2, 2, True), ('speaker_text', 1, 2, False), ('text', 3, 1, True)])
 def test_step_norms_folded_into_their_consumers_change_nothing(system_type, r, dense, fold):
     """Incremental decoding with the row norms computed inside the one-row products that consume them (the default) against
-    the same steps with every norm as a launch of its own: same kernels downstream of the rows, so the mels agree to 1e-5; the
-    folded form issues three launches per dense block fewer."""
+    the same steps with every norm as a launch of its own.  The two forms of a norm round differently in the last bit (other
+    reduction order) and the loop feeds every frame back, so the mels agree to 1e-4 after nine steps (measured 1e-5 .. 3e-5;
+    the cached decoder against the full re-decode is held to 2e-4); the folded form issues three launches per dense block fewer."""
     from estts import _lib
     cfg = small_cfg(system_type, dense=dense)
     w = weights.init_autoregressive_transformer(cfg, seed=23)
@@ -186,9 +187,9 @@ def test_step_norms_folded_into_their_consumers_change_nothing(system_type, r, d
         launches.append(lib.estts_launch_count() - n0)
     a, b = outs
     assert a['mel'].shape == b['mel'].shape == (9 * r, 80)
-    assert np.abs(a['mel'].cpu().numpy() - b['mel'].cpu().numpy()).max() < 1e-5
+    assert np.abs(a['mel'].cpu().numpy() - b['mel'].cpu().numpy()).max() < 1e-4
     for name in a['decoder_attention']:
-        assert np.abs(a['decoder_attention'][name].cpu().numpy() - b['decoder_attention'][name].cpu().numpy()).max() < 1e-5
+        assert np.abs(a['decoder_attention'][name].cpu().numpy() - b['decoder_attention'][name].cpu().numpy()).max() < 1e-4
     # 9 steps; three norms per dense block (the last block's third norm moves into the final projection), one per conv block
     assert launches[1] - launches[0] == 9 * (3 * dense + (2 - dense)), launches
 
