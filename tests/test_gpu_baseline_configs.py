@@ -193,9 +193,16 @@ def test_config5_train_step_b32_vs_oracle():
     cfg['dropout_rate'] = 0.0
     model = ForwardTransformerTrainer(w, cfg, precision='bf16x3', seed=1)
     model.set_constants(learning_rate=1e-4, decoder_prenet_dropout=0.0, drop_n_heads=0)
+    # the oracle differentiates the branches the device took (every ReLU's side, the sign of every MAE term), so that the
+    # comparison below can be tight: without them a ReLU input within rounding of zero falls either way and moves everything
+    # upstream of it by a percent
+    model.gate_log = []
     out = model.train_step(tokens, mel, durs)
+    gates = [g.cpu().numpy() if g.dtype == torch.bool else g.float().cpu().numpy() for g in model.gate_log]
+    model.gate_log = None
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    ref = OTT.forward_train_step(w, cfg, tokens, mel, durs)
+    ref = OTT.forward_train_step(w, cfg, tokens, mel, durs, gates=gates)
+    del gates
     assert abs(float(out['loss']) - ref['loss']) < 1e-4 * max(1.0, abs(ref['loss']))
     assert abs(float(out['losses']['mel']) - ref['mel_loss']) < 1e-4
     assert abs(float(out['losses']['duration']) - ref['dur_loss']) < 1e-4
@@ -214,5 +221,11 @@ def test_config5_train_step_b32_vs_oracle():
     worst.sort(reverse=True)
     cosine = dot / np.sqrt(n1 * n2)
     print(f'config 5: gradient cosine {cosine:.6f}, worst tensors {worst[:3]}, median {worst[len(worst) // 2][0]:.1e}')
-    assert cosine > 0.999
-    assert worst[len(worst) // 2][0] < 2e-2 and worst[0][0] < 0.35
+    # first line: every tensor within 1e-3 of its own largest entry, as at small size (test_gpu_training.py); the query / key
+    # projections of the self-attentions get 1e-2 (where a softmax saturates their true gradient vanishes and what remains
+    # is the rounding of large cancelling terms).  Second line: the direction of the whole gradient.
+    loose = [(e, k) for e, k in worst if '.mha.wq.' in k or '.mha.wk.' in k or '.mha.wqkv.' in k]
+    tight = [(e, k) for e, k in worst if (e, k) not in loose]
+    assert tight[0][0] < 1e-3, tight[:5]
+    assert not loose or loose[0][0] < 1e-2, loose[:5]
+    assert cosine > 0.99999
