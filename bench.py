@@ -113,6 +113,28 @@ def launch_floor_us(n_launches=7, reps=50):
     return best
 
 
+def wavernn_mol_pass(precision):
+    """The same 64-utterance pass in the reference's shipped default output mode (voc_mode = 'MOL', WaveRNN/hparams.py:33:
+    30 mixture-of-logistics parameters per sample instead of 512 classes, no mu-law)."""
+    from estts.wavernn import WaveRNN
+    hp = configs.wavernn_hparams_22k(voc_mode='MOL')
+    m = WaveRNN.from_hparams(hp, precision=precision)
+    m.load_state_dict(weights.init_wavernn(hp, seed=1234))
+    rng = np.random.default_rng(1234)
+    mels = [rng.uniform(0, 1, size=(hp['num_mels'], 560)).astype(np.float32) for _ in range(64)]
+    m.generate_batch(mels[:1], True, 1000, 100, False, seed=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = m.generate_batch(mels, True, hp['voc_target'], hp['voc_overlap'], False, seed=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    samples = sum(len(o) for o in outs)
+    audio = samples / hp['sample_rate']
+    return {'workload': 'WaveRNN MOL (10 logistics), 64 utterances x 560 frames, hop 256 / 22050 Hz', 'rtf': dt / audio, 'wall_s': dt,
+            'audio_s': audio, 'samples_per_s': samples / dt, 'us_per_step': dt / (hp['voc_target'] + 2 * hp['voc_overlap']) * 1e6,
+            'finite': bool(all(np.isfinite(o).all() for o in outs))}
+
+
 def wavernn_pass(precision, cpu_leg=True, kernel_table=False):
     """BASELINE config 4, one pass: 64 utterances x 560 frames, hop 256 @ 22.05 kHz, RAW 9-bit mu-law, batched folds
     (target 11 000, overlap 550).  Reported beside the headline metric, not as `value`."""
@@ -1057,7 +1079,12 @@ def main():
     train_line = None
     if world > 1 and args.workload == 'forward' and args.train_batch > 0:
         # the data-parallel training step of BASELINE config 5 on the same ranks (its own model and buffers)
-        train_line = train_measure(args, rank, world, dist, args.train_batch, 10, 3, False)
+        try:
+            train_line = train_measure(args, rank, world, dist, args.train_batch, 10, 3, False)
+        except Exception as e:                # the headline line must survive a failing extra (every rank fails alike or not at all)
+            import traceback
+            traceback.print_exc()
+            train_line = {'error': f'{type(e).__name__}: {e}'} if rank == 0 else None
 
     if rank == 0:
         finish_roofline(roofline, ms)
@@ -1073,7 +1100,9 @@ def main():
             'roofline': roofline,
             'cpu_baseline': cpu,
         }
-        if train_line is not None:
+        if train_line is not None and 'error' in train_line:
+            line['train'] = train_line
+        elif train_line is not None:
             keep = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'steps_per_s', 'algorithmic_tflops', 'scaling',
                     'loss_first_step', 'loss_last_step', 'exchange', 'roofline')
             line['train'] = {k: train_line[k] for k in keep if k in train_line}
@@ -1084,6 +1113,10 @@ def main():
             line['serving'] = serving_pass(w, cfg, tokens, args)
         if world == 1 and not args.no_wavernn:
             line['wavernn'] = wavernn_pass(args.precision, cpu_leg=not args.no_cpu_baseline, kernel_table=args.kernel_table)
+            try:
+                line['wavernn']['mol'] = wavernn_mol_pass(args.precision)
+            except Exception as e:            # the headline line must survive a failing extra
+                line['wavernn']['mol'] = {'error': f'{type(e).__name__}: {e}'}
             if args.workload == 'forward' and B == 1:
                 # the other single-GPU configurations, each in a child process of its own (fresh allocator and graphs)
                 line['config3'] = secondary_pass(['--workload', 'gst', '--batch', '32', '--steps', '20', '--warmup', '3'], args.precision)

@@ -128,8 +128,12 @@ __device__ __forceinline__ bool dropout_keep(uint32_t seed, uint32_t site, uint3
 // group is given one contiguous run of tile numbers (bijective for any grid size), the split-K slices of a tile are
 // adjacent in it, and a run walks the tile grid along y first (a strip of columns: all of the row operand, 1/8 of the
 // column operand per L2) or along x first (a strip of rows), whichever operand the caller says is the smaller one.
+// panel > 0 (grids with gz = 1): the run of an L2 walks panels of `panel` columns, row by row inside a panel, so that it
+// covers a block of rows x columns instead of a whole strip: with both operands of similar size every L2 then pulls a
+// fraction of each instead of all of one (the LayerNorm-prologue convolution of a 600-frame decoder block: 13.5 -> about
+// 10 MB of L2 fills per launch; with eight L2s no order gets below ~9.5 MB against 4.6 MB read and written once).
 struct TileCoord { int tx, ty, tz; };
-__device__ __forceinline__ TileCoord xcd_tile_coord(bool y_first, bool remap = true) {
+__device__ __forceinline__ TileCoord xcd_tile_coord(bool y_first, bool remap = true, int panel = 0) {
     const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
     const int nwg = gx * gy * gz;
     int id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
@@ -140,6 +144,14 @@ __device__ __forceinline__ TileCoord xcd_tile_coord(bool y_first, bool remap = t
     TileCoord t;
     t.tz = id % gz;
     const int tile = id / gz;
+    if (panel > 0 && gz == 1) {
+        const int per = panel * gy;
+        const int pn = tile / per, rem = tile - pn * per;
+        const int w = min(panel, gx - pn * panel);       // (the last panel may be narrower)
+        t.ty = rem / w;
+        t.tx = pn * panel + (rem - t.ty * w);
+        return t;
+    }
     if (y_first) { t.ty = tile % gy; t.tx = tile / gy; }
     else         { t.tx = tile % gx; t.ty = tile / gx; }
     return t;

@@ -198,7 +198,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15;
     const int g = lane >> 4;
-    const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)));
+    // (LayerNorm prologue: every column tile of a row tile re-reads that tile's y and x rows, so an L2 should hold a block of
+    // rows x columns, not a strip: panels of four column tiles)
+    const TileCoord tc = xcd_tile_coord((p.tune & (1 << 25)) ? false : gemm_y_first(p), !(p.tune & (1 << 24)),
+                                        (LNCH > 0 && !(p.tune & (1 << 26))) ? 4 : 0);
     const int m0 = tc.ty * 16 * T;
     const int n0 = tc.tx * 16 * T;
     const int KS = p.ldw >> 5;

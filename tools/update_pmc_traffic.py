@@ -3,7 +3,8 @@
 rocprofv3 --pmc passes, and stamp it with a hash of the kernel sources it was measured on: bench.py reports `traffic` only
 while that hash matches the tree, so a changed kernel cannot inherit an old measurement.
 
-usage: update_pmc_traffic.py FETCH_SIZE.csv WRITE_SIZE.csv"""
+usage: update_pmc_traffic.py FETCH_SIZE.csv WRITE_SIZE.csv [FETCH_SIZE.csv WRITE_SIZE.csv ...]
+(one pair of counter files per profiled command; a kernel is looked up in every pair)"""
 import hashlib
 import json
 import os
@@ -13,8 +14,21 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'expressive-speech-synthesis-research_amd', 'csrc')
 
-# bench.py roofline key -> (substring of the kernel name, note appended to the source line)
+# bench.py roofline key -> (substring of the kernel name, note appended to the source line[, grid size in threads when one
+# instantiation serves several shapes])
 KERNELS = {
+    'gemm {"M": 19200, "N": 256, "K": 512, "taps": 1}': (
+        'gemm_big_kernel<3, 1, 2, 3, 1>',
+        ' (config 3: the 19200 x 256 x 512 dense layers -- attention output projections over [x | ctx] and the cross-attention'
+        ' key / value projections; 64 x 128 tiles, 600 workgroups)', 153600),
+    'attention_bwd {"B": 32, "H": 4, "Lq": 600, "Lk": 600, "depth": 64}': (
+        'attention_bwd_wide_kernel',
+        ' (config 5: one of the two passes -- owning queries, owning keys -- of the decoder self-attention backward, 600 x 600,'
+        ' batch 32; the roofline entry prices the pair, this is the mean of the two)', None),
+    'wavernn_layer {"mode": 2, "n_seq": 832, "n_units": 512, "K": 544}': (
+        'wavernn_layer_kernel<2, 4, 2>',
+        ' (config 4: rnn2 of one sampling step, 832 sequences; 17.9 MB of weights per step are re-read from L2 / the Infinity'
+        ' Cache, which these counters see only when they miss there)', None),
     'gemm {"M": 100, "N": 512, "K": 1536, "taps": 3}': (
         'gemm_oneshot_kernel<3, 2, 1, 8, 6>',
         ' (the second convolution of each encoder block: M = 100, N = 512, K = 3 x 512; 224 workgroups of 16 x 16 outputs)'),
@@ -38,15 +52,18 @@ def csrc_hash():
 
 
 def main():
-    fetch, write = sys.argv[1], sys.argv[2]
-    rows = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), fetch, write]))
+    pairs = list(zip(sys.argv[1::2], sys.argv[2::2]))
+    sets = [(f, w, json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), f, w])))
+            for f, w in pairs]
     out = {'csrc_sha1': csrc_hash()}
-    for key, (pat, note) in KERNELS.items():
-        hit = [r for r in rows if pat in r['kernel']]
+    for key, spec in KERNELS.items():
+        pat, note = spec[0], spec[1]
+        grid = spec[2] if len(spec) > 2 else None
+        hit = [(r, f, w) for f, w, rows in sets for r in rows if pat in r['kernel'] and (grid is None or r['grid'] == grid)]
         if not hit:
             print(f'no dispatch of {pat} in the passes', file=sys.stderr)
             continue
-        r = max(hit, key=lambda x: x['dispatches'])
+        r, fetch, write = max(hit, key=lambda x: x[0]['dispatches'])
         out[key] = {
             'hbm_bytes': round(r['hbm_bytes']), 'read_bytes': round(r['read_bytes']), 'write_bytes': round(r['write_bytes']),
             'source': f"profiles/{os.path.basename(fetch)} + {os.path.basename(write)} (rocprofv3 --pmc, separate passes; read = 2 x "
