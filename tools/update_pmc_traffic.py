@@ -3,8 +3,9 @@
 rocprofv3 --pmc passes, and stamp it with a hash of the kernel sources it was measured on: bench.py reports `traffic` only
 while that hash matches the tree, so a changed kernel cannot inherit an old measurement.
 
-usage: update_pmc_traffic.py FETCH_SIZE.csv WRITE_SIZE.csv [FETCH_SIZE.csv WRITE_SIZE.csv ...]
-(one pair of counter files per profiled command; a kernel is looked up in every pair)"""
+usage: update_pmc_traffic.py FETCH_SIZE.csv WRITE_SIZE.csv [FETCH_SIZE.csv WRITE_SIZE.csv | summary.json ...]
+(one pair of counter files per profiled command, or the per-kernel summary tools/pmc_summary.py made of such a pair; a kernel
+is looked up in every set)"""
 import hashlib
 import json
 import os
@@ -33,10 +34,10 @@ KERNELS = {
         'gemm_oneshot_kernel<3, 2, 1, 8, 6>',
         ' (the second convolution of each encoder block: M = 100, N = 512, K = 3 x 512; 224 workgroups of 16 x 16 outputs)'),
     'gemm {"M": 100, "N": 512, "K": 1536, "taps": 3, "ln_prologue": true}': (
-        'gemm_oneshot_conv_kernel<3, 1, 8, 6, 2>',
+        'gemm_oneshot_conv_kernel<3, 1, 8, 6, 2,',
         ' (the first convolution of each encoder block with the attention block\'s LN(LN(y) + x) computed on the way in)'),
     'gemm {"M": 600, "N": 512, "K": 768, "taps": 3, "ln_prologue": true}': (
-        'gemm_oneshot_conv_kernel<3, 2, 8, 3, 1>',
+        'gemm_oneshot_conv_kernel<3, 2, 8, 3, 1,',
         ' (the first convolution of each decoder block with the attention block\'s LN(LN(y) + x) computed on the way in)'),
     'attention {"B": 1, "H": 4, "Lq": 600, "Lk": 600, "depth": 64, "weights": true}': ('attention_kernel<64, 2, 3, 8>', ''),
 }
@@ -52,9 +53,16 @@ def csrc_hash():
 
 
 def main():
-    pairs = list(zip(sys.argv[1::2], sys.argv[2::2]))
-    sets = [(f, w, json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), f, w])))
-            for f, w in pairs]
+    sets, args = [], sys.argv[1:]
+    while args:
+        if args[0].endswith('.json'):           # a summary made earlier (the raw counter files of the larger workloads are not kept)
+            with open(args[0]) as f:
+                sets.append((args[0], None, json.load(f)))
+            args = args[1:]
+        else:
+            f, w = args[0], args[1]
+            sets.append((f, w, json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, 'tools', 'pmc_summary.py'), f, w]))))
+            args = args[2:]
     out = {'csrc_sha1': csrc_hash()}
     for key, spec in KERNELS.items():
         pat, note = spec[0], spec[1]
@@ -66,7 +74,8 @@ def main():
         r, fetch, write = max(hit, key=lambda x: x[0]['dispatches'])
         out[key] = {
             'hbm_bytes': round(r['hbm_bytes']), 'read_bytes': round(r['read_bytes']), 'write_bytes': round(r['write_bytes']),
-            'source': f"profiles/{os.path.basename(fetch)} + {os.path.basename(write)} (rocprofv3 --pmc, separate passes; read = 2 x "
+            'source': f"profiles/{os.path.basename(fetch)}" + (f" + {os.path.basename(write)}" if write else " (per-kernel summary of the two counter files)") +
+                      f" (rocprofv3 --pmc, separate passes; read = 2 x "
                       f"FETCH_SIZE KiB per the gfx950 correction, write = WRITE_SIZE KiB), mean of {r['dispatches']} dispatches of "
                       f"{pat} with {r['grid']} threads{note}, summarised by tools/pmc_summary.py"}
     with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w') as f:
