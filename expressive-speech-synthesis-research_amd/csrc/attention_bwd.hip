@@ -403,27 +403,32 @@ __global__ __launch_bounds__(256, (bwd_wide_occupancy<DH, NS, OWN_Q>())) void at
 #pragma unroll
     for (int nt = 0; nt < (OWN_Q ? 1 : NT); ++nt) o2[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // (dQ pass) the fast form of load_p alone, for tiles known to lie inside the map: no condition around its loads
+    auto load_p_inside = [&](int kt, float (&pp)[8], float (&dl)[8]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const float4 t = *reinterpret_cast<const float4*>(pbase + kt * 32 + sub * 16);
+            pp[sub * 4] = t.x, pp[sub * 4 + 1] = t.y, pp[sub * 4 + 2] = t.z, pp[sub * 4 + 3] = t.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dl[sub * 4 + j] = own_delta;
+        }
+    };
+
     const int nkt = (L_oth + 31) / 32;
+    const int ninside = quad_ok ? L_oth / 32 : 0;   // tiles [0, ninside) take load_p_inside
     float4 sx[NLD], ox[NLD];
-    float pn[8], dn[8];
-    load_tile(sbase, s_ld, 0, sx);
-    load_tile(obase, o_ld, 0, ox);
-    load_p(0, pn, dn);
-    int par = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // One swept tile: stage the rows held in sx / ox, meet the other waves, multiply.  `after_barrier` requests the rows of
+    // the next tile; `after_p` runs once this tile's weights and delta (pv, dl) are dead: the dQ pass requests those of the
+    // tile after the next into the same registers there, so that the weights -- the operand that comes from HBM, 184 MB per
+    // pass at batch 32 -- have a tile and a half to arrive instead of one.
+    auto step = [&](int par, float (&pv)[8], float (&dl)[8], auto&& after_barrier, auto&& after_p) {
         __bf16* simg = &smem[par][0][0][0];
         __bf16* oimg = &smem[par][1][0][0];
         stage_tile(sx, simg);
         stage_tile(ox, oimg);
-        float pv[8], dl[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pv[e] = pn[e], dl[e] = dn[e];
         __syncthreads();   // also: every wave is done with the other buffer, which the next tile will overwrite
-        if (kt + 1 < nkt) {
-            load_tile(sbase, s_ld, kt + 1, sx);
-            load_tile(obase, o_ld, kt + 1, ox);
-            load_p(kt + 1, pn, dn);
-        }
+        after_barrier();
+        if constexpr (OWN_Q) __builtin_amdgcn_sched_barrier(0);   // the requests go out here, not wherever the matrix instructions leave a gap
         float dsv[8];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -439,13 +444,63 @@ __global__ __launch_bounds__(256, (bwd_wide_occupancy<DH, NS, OWN_Q>())) void at
 #pragma unroll
             for (int j = 0; j < 4; ++j) dsv[sub * 4 + j] = pv[sub * 4 + j] * (acc[j] - dl[sub * 4 + j]) * scale;
         }
-        if constexpr (!OWN_Q) {
-            const Frag<NS> pf = make_frag<NS>(pv);
-            accumulate(o2, pf, simg);
-        }
+        Frag<NS> pf;
+        if constexpr (!OWN_Q) pf = make_frag<NS>(pv);
+        after_p();
+        if constexpr (OWN_Q) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!OWN_Q) accumulate(o2, pf, simg);
         const Frag<NS> dsf = make_frag<NS>(dsv);
         accumulate(o1, dsf, oimg);
-        par ^= 1;
+    };
+    auto load_rows = [&](int kt) {
+        load_tile(sbase, s_ld, kt, sx);
+        load_tile(obase, o_ld, kt, ox);
+    };
+
+    load_rows(0);
+    if constexpr (OWN_Q) {
+        float pa[8], da[8], pb[8], db[8];   // weights and delta of the even / odd tiles
+        int kt = 0;
+        if (ninside >= 4) {
+            // Steady state: no load under a condition, entered behind loads in the loop's own order.  The compiler's s_waitcnt
+            // counts are static; one path on which a younger set of loads was not issued makes every iteration wait for all
+            // loads in flight (vmcnt(0)), and the longer prefetch distance buys nothing.
+            load_p_inside(0, pa, da);
+            __builtin_amdgcn_sched_barrier(0);
+            load_p_inside(1, pb, db);
+            __builtin_amdgcn_sched_barrier(0);
+            for (; kt + 3 < ninside; kt += 2) {
+                step(0, pa, da, [&] { load_rows(kt + 1); }, [&] { load_p_inside(kt + 2, pa, da); });
+                step(1, pb, db, [&] { load_rows(kt + 2); }, [&] { load_p_inside(kt + 3, pb, db); });
+            }
+        } else {
+            load_p(0, pa, da);
+            if (nkt > 1) load_p(1, pb, db);
+        }
+        // the last tiles (and maps too small for the loop above): the same steps with every request under its condition
+        for (; kt < nkt; kt += 2) {
+            step(0, pa, da, [&] { if (kt + 1 < nkt) load_rows(kt + 1); }, [&] { if (kt + 2 < nkt) load_p(kt + 2, pa, da); });
+            if (kt + 1 < nkt)
+                step(1, pb, db, [&] { if (kt + 2 < nkt) load_rows(kt + 2); }, [&] { if (kt + 3 < nkt) load_p(kt + 3, pb, db); });
+        }
+    } else {
+        // the dK / dV pass has no registers to spare for a second set at three workgroups per CU (eight scalar loads with
+        // 64-bit lane addresses per tile): weights and delta one tile ahead, requested together with the rows
+        float pn[8], dn[8];
+        load_p(0, pn, dn);
+        int par = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            float pv[8], dl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = pn[e], dl[e] = dn[e];
+            step(par, pv, dl, [&] {
+                if (kt + 1 < nkt) {
+                    load_rows(kt + 1);
+                    load_p(kt + 1, pn, dn);
+                }
+            }, [] {});
+            par ^= 1;
+        }
     }
 
     if (own_ok) {

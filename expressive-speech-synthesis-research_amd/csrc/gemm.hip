@@ -638,19 +638,44 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
     float4 a0[AI], a1[AI];
     bool ok0[AI], ok1[AI];
     uint4 u0, u1, u2, u3, v0, v1, v2, v3;
-    load_tiles(a0, ok0, u0, u1, u2, u3, 0);
-    if (nk > 1) load_tiles(a1, ok1, v0, v1, v2, v3, 1);
-    for (int kt = 0; kt < nk; kt += 2) {
-        store_tiles(a0, ok0, u0, u1, u2, u3, 0);
-        __syncthreads();
-        if (kt + 2 < nk) load_tiles(a0, ok0, u0, u1, u2, u3, kt + 2);
-        multiply(0);
-        if (kt + 1 < nk) {
+    // The steady-state loop holds NO load under a condition, and can only be entered behind two unconditional sets of loads.
+    // The compiler's s_waitcnt counts are static: were a set's loads conditional (if (kt + 2 < nk) ...), the path that skips
+    // them would make the older set the youngest loads in flight, so every iteration would wait for vmcnt(0) before its
+    // first LDS store, i.e. for the set requested one multiply phase ago, and the second register set would buy nothing.
+    int kt = 0;
+    if (nk >= 4) {
+        load_tiles(a0, ok0, u0, u1, u2, u3, 0);
+        __builtin_amdgcn_sched_barrier(0);   // the same goes for the order on entry: all of set 0 before any of set 1
+        load_tiles(a1, ok1, v0, v1, v2, v3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; kt + 3 < nk; kt += 2) {
+            store_tiles(a0, ok0, u0, u1, u2, u3, 0);
+            __syncthreads();
+            load_tiles(a0, ok0, u0, u1, u2, u3, kt + 2);
+            multiply(0);
             store_tiles(a1, ok1, v0, v1, v2, v3, 1);
             __syncthreads();
-            if (kt + 3 < nk) load_tiles(a1, ok1, v0, v1, v2, v3, kt + 3);
+            load_tiles(a1, ok1, v0, v1, v2, v3, kt + 3);
             multiply(1);
         }
+    } else {
+        load_tiles(a0, ok0, u0, u1, u2, u3, 0);
+        if (nk > 1) load_tiles(a1, ok1, v0, v1, v2, v3, 1);
+    }
+    // tail: K-steps kt and kt + 1 are in the registers, kt + 2 (nk - kt = 3) is still to be requested
+    store_tiles(a0, ok0, u0, u1, u2, u3, 0);
+    __syncthreads();
+    if (kt + 2 < nk) load_tiles(a0, ok0, u0, u1, u2, u3, kt + 2);
+    multiply(0);
+    if (kt + 1 < nk) {
+        store_tiles(a1, ok1, v0, v1, v2, v3, 1);
+        __syncthreads();
+        multiply(1);
+    }
+    if (kt + 2 < nk) {
+        store_tiles(a0, ok0, u0, u1, u2, u3, 0);   // every wave is past the barrier in front of multiply(1): buffer 0 is free
+        __syncthreads();
+        multiply(0);
     }
 
     // column moments of the output (stat_slots): a lane sums its 16 TM rows of the column, the two half-waves are added with

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Times the LDS-staged tiles of estts_gemm (ids 6 and 8) on the large-M shapes of configs 3 and 5 and checks them against a
+float64 product of a row sample (GPU box only).  Run once per library build to compare two builds on one box:
+  cp ab_libs/old.so <package>/libestts.so && python3 tools/ab_gemm_big.py && cp ab_libs/new.so <package>/libestts.so && ..."""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import estts  # noqa
+from estts import ops
+from estts.ops import PackedLinear
+from tune_gemm import timeit
+
+SHAPES = [  # (M, N, K, taps)
+    (19200, 256, 512, 1), (19200, 256, 1536, 3), (19200, 512, 768, 3), (19200, 256, 1280, 5), (19200, 768, 256, 1),
+    (19200, 1024, 512, 1), (19200, 256, 256, 1), (19200, 256, 96, 1), (19200, 256, 160, 1), (4800, 256, 512, 1), (3200, 1536, 512, 1),
+]
+
+
+def main():
+    g = torch.Generator().manual_seed(0)
+    for M, N, K, taps in SHAPES:
+        cin = K // taps
+        x = torch.randn(M, cin, generator=g).cuda()
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        lin = PackedLinear(w.numpy(), device='cuda', taps=taps, lpad=(taps - 1) // 2)
+        out = torch.empty(M, N, device='cuda')
+        # float64 reference on the rows around the sequence start and end and a few in the middle
+        rows = torch.tensor([0, 1, 2, 63, 64, 65, M // 2, M - 66, M - 3, M - 2, M - 1])
+        xp = torch.nn.functional.pad(x.double().cpu(), (0, 0, (taps - 1) // 2, taps - 1 - (taps - 1) // 2))
+        cols = torch.cat([xp[rows + t] for t in range(taps)], dim=1)       # tap-major columns
+        ref = cols @ w.double().t()
+        res = []
+        for tile in (6, 8):
+            ops.gemm(x, lin, out, seg_len=M, precision='bf16x3', tune=tile | (1 << 8))
+            err = (out[rows.cuda()].double().cpu() - ref).abs().max().item()
+            t = timeit(lambda: ops.gemm(x, lin, out, seg_len=M, precision='bf16x3', tune=tile | (1 << 8)), reps=10, rounds=5)
+            res.append(f'tile{tile} {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.1f} TF/s (err {err:.1e})')
+        print(f'M={M:6d} N={N:5d} K={K:5d} taps={taps} | ' + ' | '.join(res), flush=True)
+
+
+if __name__ == '__main__':
+    main()
