@@ -870,9 +870,10 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         // kernels (ids 1-3) never win at these sizes and are kept for explicit selection only.
         const long mt = (long)((a.M + 63) / 64) * (a.batch > 1 ? a.batch : 1);
         const long n8 = mt * ((a.N + 127) / 128), n6 = mt * ((a.N + 63) / 64);
-        // (with K <= 256 a workgroup's eight K-steps do not amortise the wider tile's prologue: 19200 x 768 x 256 runs 44 us
-        // as 64 x 64 tiles, 49 us as 64 x 128)
-        tile = (a.N >= 128 && n8 >= 384 && a.K > 256) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
+        // (with K <= 512 a workgroup's K-steps do not amortise the wider tile's prologue and epilogue unless N is large:
+        // 19200 x 768 x 256 runs 44 us as 64 x 64 tiles, 47 us as 64 x 128; 19200 x 256 x 512 29.7 against 31.3;
+        // 3200 x 1536 x 512 29.6 against 30.8; 19200 x 1024 x 512 90 against 88)
+        tile = (a.N >= 128 && n8 >= 384 && (a.K > 512 || a.N >= 1024)) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
     }
     if (a.stat_slots) {
         ESTTS_CHECK_ARG(a.batch <= 1 && !a.ln_y, "estts_gemm: stat_slots not with batch > 1 or a LayerNorm prologue");
