@@ -476,6 +476,61 @@ constexpr int BG_LD = 40;  // bf16 per staged A row (32 + 8 pad = 80 B)
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// Epilogue of the LDS-staged kernels: a wave holds TM x TN accumulator tiles of 32 x 32 (D[row (reg & 3) + 8 (reg >> 2) + 4 h][col r])
+// whose first row / column inside the workgroup tile are 32 TM wm and 32 TN wn.
+template <int TM, int TN>
+__device__ __forceinline__ void big_epilogue(const estts_gemm_args& p, f32x16 (&acc)[TM][TN], const int m0, const int n0, const int wm,
+                                             const int wn, const int r, const int h, const TileCoord& tc) {
+    // column moments of the output (stat_slots): a lane sums its 16 TM rows of the column, the two half-waves are added with
+    // one lane swap, and each wave adds its 32 TN columns to copy (row tile % 16) of the sums
+    const bool stats = p.stat_slots != nullptr;
+    const long stat_cp = (long)((p.N + 255) / 256) * 256;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * 32 * TN + j * 32 + r;
+        if (col >= p.N) continue;
+        const float s1 = p.s1 ? p.s1[col] : 1.0f;
+        const float b1 = p.b1 ? p.b1[col] : 0.0f;
+        const float s2 = p.s2 ? p.s2[col] : 1.0f;
+        const float b2 = p.s2 ? p.b2[col] : 0.0f;
+        const float k0 = (stats && p.stat_shift) ? p.stat_shift[col] : 0.0f;
+        float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // the tile's 16 values of R first: R may be C itself (accumulation), so the compiler has to keep every load behind
+            // the stores before it, and loads left between the stores become 16 dependent round trips
+            // (19200 x 256 x 256 with R: 28.3 us against 18.9 us without)
+            float res[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                res[e] = (p.R && row < p.M) ? epilogue_residual(p, row, col) : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < p.M) {
+                    const float v = epilogue_value_r(p, acc[i][j][e], row, col, s1, b1, s2, b2, res[e]);
+                    p.C[(long)row * p.ldc + col] = v;
+                    const float d = v - k0;
+                    q0 += d;
+                    q1 += d * d;
+                }
+            }
+        }
+        if (stats) {
+            q0 += lane_xor32(q0);
+            q1 += lane_xor32(q1);
+            if (h == 0) {
+                float* dst = p.stat_slots + (long)(tc.ty % 16) * 2 * stat_cp + col;
+                atomic_add_f32(dst, q0);
+                atomic_add_f32(dst + stat_cp, q1);
+            }
+        }
+    }
+}
+
+
 // TM x TN = 32 x 32 MFMA tiles per wave: the workgroup tile is (64 TM) x (64 TN).  2 x 2 is the kernel described above;
 // 1 x 1, 2 x 1 and 1 x 2 keep its main loop for launches whose 128 x 128 tiles would leave most CUs idle.
 template <int NSPLIT, int TM, int TN, int OCC, int KIND>
@@ -678,53 +733,182 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
         multiply(0);
     }
 
-    // column moments of the output (stat_slots): a lane sums its 16 TM rows of the column, the two half-waves are added with
-    // one lane swap, and each wave adds its 32 TN columns to copy (row tile % 16) of the sums
-    const bool stats = p.stat_slots != nullptr;
-    const long stat_cp = (long)((p.N + 255) / 256) * 256;
+    big_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, r, h, tc);
+}
+
+// ======================================================================================================
+// W-from-memory kernel (tile id 13): the 64 x 128 tile with half the LDS traffic.  The four waves sit side by side over N:
+// wave w owns all 64 rows x columns 32 w .. 32 w + 31 (two 32 x 32 accumulator tiles), so no W byte is needed by two waves
+// and W never passes through LDS -- packed W is already the B-operand register image, a lane fetches its 16 bytes of
+// K-step q with one coalesced load (four 256-byte runs per wave) straight into the registers the matrix instruction
+// reads.  Only A is staged (split on its way in, as in the kernel above).  Per workgroup and 32-wide K-step: LDS stores
+// 8 KB instead of 24, LDS fragment reads 32 KB instead of 48, the same 24 KB from memory and the same 48 matrix
+// instructions.  Same arithmetic in the same order as the 64 x 128 tile of the kernel above: identical results.
+// ======================================================================================================
+template <int NSPLIT, int TM, int OCC, int KIND>
+__global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm_args p_in) {
+    constexpr int NS = (NSPLIT > 1) ? 2 : 1;
+    constexpr int BM = 32 * TM, BN = 128;   // TM = 2 (or 4: 128 rows, half the W loads per matrix instruction)
+    constexpr int AI = TM;       // float4 loads of A per thread and K-step
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][BM * BG_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const TileCoord tc = xcd_tile_coord((p_in.tune & (1 << 25)) ? false : gemm_y_first(p_in), !(p_in.tune & (1 << 24)));
+    const estts_gemm_args& p = p_in;
+    const int m0 = tc.ty * BM;
+    const int n0 = tc.tx * BN;
+    const int KS = p.ldw >> 5;
+
+    const int nb_end = ((p.N + 63) / 64) * 4;  // 16-column blocks present in W
+    const int a_ch = tid & 7;    // float4 chunk of the 32-wide K slice
+    const int a_r0 = tid >> 3;   // rows a_r0 + 32 i
+    ARow a_row[AI];
+    const float* a_ptr[AI];   // KIND 1 / 2: start of the row (rows past M re-read the last one; their results are never stored)
+    int a_pos[AI];            // KIND 2: position of the row inside its sequence
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * 32 * TN + j * 32 + r;
-        if (col >= p.N) continue;
-        const float s1 = p.s1 ? p.s1[col] : 1.0f;
-        const float b1 = p.b1 ? p.b1[col] : 0.0f;
-        const float s2 = p.s2 ? p.s2[col] : 1.0f;
-        const float b2 = p.s2 ? p.b2[col] : 0.0f;
-        const float k0 = (stats && p.stat_shift) ? p.stat_shift[col] : 0.0f;
-        float q0 = 0.0f, q1 = 0.0f;
+    for (int i = 0; i < AI; ++i) {
+        const int row = min(m0 + a_r0 + 32 * i, p.M - 1);
+        if (KIND == 1) a_ptr[i] = p.A + (long)row * p.lda + a_ch * 4;
+        else if (KIND == 2) { a_ptr[i] = p.A + (long)row * p.lda; a_pos[i] = row % p.conv_w; }
+        else a_row[i] = make_arow(p, m0 + a_r0 + 32 * i);
+    }
+    KCursor kcur = make_kcursor(p, a_ch * 4);   // load_a is called for kt = 0, 1, 2, ... in order
+    auto load_a = [&](float4 (&ga)[AI], bool (&gok)[AI], int kt) {
+        if (KIND == 1) {
+            const bool ok = kt * 32 + a_ch * 4 < p.K;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            // the tile's 16 values of R first: R may be C itself (accumulation), so the compiler has to keep every load behind
-            // the stores before it, and loads left between the stores become 16 dependent round trips
-            // (19200 x 256 x 256 with R: 28.3 us against 18.9 us without)
-            float res[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                res[e] = (p.R && row < p.M) ? epilogue_residual(p, row, col) : 0.0f;
+            for (int i = 0; i < AI; ++i) {
+                ga[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? kt * 32 : -a_ch * 4));
+                gok[i] = ok;
             }
+        } else if (KIND == 2) {
+            const int dw = kcur.tap - p.conv_pl;
+            const long off = (long)dw * p.lda + kcur.c;
+            const bool kok = kcur.kk < p.K;
+            advance(p, kcur, 32);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < p.M) {
-                    const float v = epilogue_value_r(p, acc[i][j][e], row, col, s1, b1, s2, b2, res[e]);
-                    p.C[(long)row * p.ldc + col] = v;
-                    const float d = v - k0;
-                    q0 += d;
-                    q1 += d * d;
-                }
+            for (int i = 0; i < AI; ++i) {
+                const bool ok = kok && (unsigned)(a_pos[i] + dw) < (unsigned)p.conv_w;
+                ga[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? off : 0L));
+                gok[i] = ok;
             }
+        } else {
+            const ATap tp = atap_from(p, kcur.kk, kcur.tap, kcur.c);
+            advance(p, kcur, 32);
+#pragma unroll
+            for (int i = 0; i < AI; ++i) ga[i] = load_a_raw(p, a_row[i], tp, gok[i]);
         }
-        if (stats) {
-            q0 += lane_xor32(q0);
-            q1 += lane_xor32(q1);
-            if (h == 0) {
-                float* dst = p.stat_slots + (long)(tc.ty % 16) * 2 * stat_cp + col;
-                atomic_add_f32(dst, q0);
-                atomic_add_f32(dst + stat_cp, q1);
+    };
+    auto store_a = [&](const float4 (&ga)[AI], const bool (&gok)[AI], int buf) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int o = (a_r0 + 32 * i) * BG_LD + a_ch * 4;
+            // KIND 1 needs no zeroing: a K index past the end re-reads valid data of the row, and W is zero-padded there
+            const float4 az = KIND == 1 ? ga[i] : zero_unless(gok[i], ga[i]);
+            bf16x4 hi, lo;
+            split_bf16x4(az, hi, lo);
+            *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = hi;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = lo;
+        }
+    };
+    // this lane's 16 bytes of W for the two 16-wide halves q of K-step kt: 16-column block (n0 + 32 wave) / 16 + (r >> 4)
+    // (clamped: W holds ceil(N / 64) * 64 rows, columns >= N are never stored), lane slot (r & 15) + 16 (2 q + h) of its 1 KiB
+    const int w_nb = min((n0 >> 4) + wave * 2 + (r >> 4), nb_end - 1);
+    const long w_lane = (long)w_nb * KS * 512 + ((r & 15) + 16 * h) * 8;
+    auto load_w = [&](bf16x8 (&wf)[NS][2], int kt) {
+        const long o = w_lane + (long)kt * 512;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            wf[0][q] = *reinterpret_cast<const bf16x8*>(p.W_hi + o + q * 32 * 8);
+            if (NS == 2) wf[NS - 1][q] = *reinterpret_cast<const bf16x8*>(p.W_lo + o + q * 32 * 8);
+        }
+    };
+
+    f32x16 acc[TM][1];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.0f;
+
+    const int nk = (p.K + 31) / 32;
+    const int a_base = r * BG_LD + 8 * h;
+    auto multiply = [&](int buf, const bf16x8 (&wf)[NS][2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bf16x8 af[NS][TM];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[s][i] = *reinterpret_cast<const bf16x8*>(&As[buf][s][a_base + i * 32 * BG_LD + q * 16]);
+            if (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NS - 1][i], wf[0][q], acc[i][0], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], wf[NS - 1][q], acc[i][0], 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], wf[0][q], acc[i][0], 0, 0, 0);
+        }
+    };
+
+    // two register sets of each operand; steady state without a load under a condition (see the kernel above).  A set of W
+    // is requested again as soon as its K-step has been multiplied, a set of A as soon as it has been staged.
+    float4 a0[AI], a1[AI];
+    bool ok0[AI], ok1[AI];
+    bf16x8 w0[NS][2], w1[NS][2];
+    int kt = 0;
+    if (nk >= 4) {
+        load_a(a0, ok0, 0);
+        load_w(w0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(a1, ok1, 1);
+        load_w(w1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; kt + 3 < nk; kt += 2) {
+            store_a(a0, ok0, 0);
+            __syncthreads();
+            load_a(a0, ok0, kt + 2);
+            multiply(0, w0);
+            load_w(w0, kt + 2);
+            store_a(a1, ok1, 1);
+            __syncthreads();
+            load_a(a1, ok1, kt + 3);
+            multiply(1, w1);
+            load_w(w1, kt + 3);
+        }
+    } else {
+        load_a(a0, ok0, 0);
+        load_w(w0, 0);
+        if (nk > 1) {
+            load_a(a1, ok1, 1);
+            load_w(w1, 1);
         }
     }
+    // tail: K-steps kt and kt + 1 are in the registers, kt + 2 (nk - kt = 3) is still to be requested
+    store_a(a0, ok0, 0);
+    __syncthreads();
+    if (kt + 2 < nk) load_a(a0, ok0, kt + 2);
+    multiply(0, w0);
+    if (kt + 2 < nk) load_w(w0, kt + 2);
+    if (kt + 1 < nk) {
+        store_a(a1, ok1, 1);
+        __syncthreads();
+        multiply(1, w1);
+    }
+    if (kt + 2 < nk) {
+        store_a(a0, ok0, 0);   // every wave is past the barrier in front of multiply(1): buffer 0 is free
+        __syncthreads();
+        multiply(0, w0);
+    }
+
+    big_epilogue<TM, 1>(p, acc, m0, n0, 0, wave, r, h, tc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -818,6 +1002,23 @@ int launch_big_d(const estts_gemm_args& a, hipStream_t st) {
     return 0;
 }
 
+template <int TM, int OCC, int KIND>
+int launch_wdirect_d(const estts_gemm_args& a, hipStream_t st) {
+    dim3 grid((a.N + 127) / 128, (a.M + 32 * TM - 1) / (32 * TM), 1);
+    if (a.precision == 3)
+        ESTTS_LAUNCH((gemm_wdirect_kernel<3, TM, OCC, KIND>), grid, dim3(256), 0, st, a);
+    else
+        ESTTS_LAUNCH((gemm_wdirect_kernel<1, TM, OCC, KIND>), grid, dim3(256), 0, st, a);
+    ESTTS_CHECK_LAUNCH("estts_gemm");
+    return 0;
+}
+
+template <int TM, int OCC>
+int launch_wdirect(const estts_gemm_args& a, hipStream_t st) {
+    const int kind = operand_kind(a);
+    return kind == 1 ? launch_wdirect_d<TM, OCC, 1>(a, st) : kind == 2 ? launch_wdirect_d<TM, OCC, 2>(a, st) : launch_wdirect_d<TM, OCC, 0>(a, st);
+}
+
 template <int TM, int TN, int OCC>
 int launch_big(const estts_gemm_args& a, hipStream_t st) {
     const int kind = operand_kind(a);
@@ -864,20 +1065,20 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
     int tile = a.tune & 0xff;
     int splitk = (a.tune >> 8) & 0xff;
     if (tile == 0) {
-        // measured on MI355X (tools/tune_gemm_big.py, tools/tune_wavernn_gemm.py): the LDS-staged kernel wins once its
-        // workgroups fill the chip -- as 64 x 128 tiles when there are enough of those, else as 64 x 64 tiles -- and
-        // below that the barrier-free 32 x 32 kernel does.  The 128 x 128 and 128 x 64 shapes and the older 64 x 64
-        // kernels (ids 1-3) never win at these sizes and are kept for explicit selection only.
+        // measured on MI355X (tools/ab_gemm_big.py, tools/tune_gemm_big.py, tools/tune_wavernn_gemm.py): the LDS-staged kernels win
+        // once their workgroups fill the chip -- as 64 x 128 tiles when there are enough of those, else as 64 x 64 tiles --
+        // and below that the barrier-free 32 x 32 kernel does.  The 128 x 128, 128 x 64 and LDS-staged 64 x 128 shapes (ids 5, 7,
+        // 8) and the older 64 x 64 kernels (ids 1-3) never win at these sizes and are kept for explicit selection only.
         const long mt = (long)((a.M + 63) / 64) * (a.batch > 1 ? a.batch : 1);
         const long n8 = mt * ((a.N + 127) / 128), n6 = mt * ((a.N + 63) / 64);
-        // (with K <= 512 a workgroup's K-steps do not amortise the wider tile's prologue and epilogue unless N is large:
-        // 19200 x 768 x 256 runs 44 us as 64 x 64 tiles, 47 us as 64 x 128; 19200 x 256 x 512 29.7 against 31.3;
-        // 3200 x 1536 x 512 29.6 against 30.8; 19200 x 1024 x 512 90 against 88)
-        tile = (a.N >= 128 && n8 >= 384 && (a.K > 512 || a.N >= 1024)) ? 8 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
+        // 64 x 128 tiles run on the W-from-memory kernel (id 13: 19200 x 256 x 512 28.1 us against 31.1 for id 8 and 30.2 as
+        // 64 x 64 tiles; 19200 x 256 x 1536, three taps: 63.5 / 76 / 81 us; 19200 x 1024 x 512: 76 / 89 / 98 us); below 384 such
+        // tiles the 64 x 64 tiles are as fast or faster (9600 x 256 x 512: 19.8 against 20.4 us)
+        tile = (a.N >= 128 && n8 >= 384 && a.batch <= 1) ? 13 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
     }
     if (a.stat_slots) {
         ESTTS_CHECK_ARG(a.batch <= 1 && !a.ln_y, "estts_gemm: stat_slots not with batch > 1 or a LayerNorm prologue");
-        if (tile < 5 || tile > 8) {   // a kernel without the summing epilogue: the product, then a pass over C
+        if ((tile < 5 || tile > 8) && tile != 13) {   // a kernel without the summing epilogue: the product, then a pass over C
             ESTTS_CHECK_ARG((a.N & 3) == 0 && (a.ldc & 3) == 0, "estts_gemm: stat_slots needs N and ldc multiples of 4 at this size");
             estts_gemm_args b = *args;
             b.stat_slots = nullptr;
@@ -948,6 +1149,9 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         case 6: return launch_big<1, 1, 4>(a, st);
         case 7: return launch_big<2, 1, 2>(a, st);
         case 8: return launch_big<1, 2, 3>(a, st);
+        case 13:
+            ESTTS_CHECK_ARG(a.batch <= 1, "estts_gemm: tile 13 takes no batch");
+            return launch_wdirect<2, 4>(a, st);
 
         default: estts_set_error("estts_gemm: unknown tile id %d", tile); return -1;
     }

@@ -78,8 +78,10 @@ long long estts_launch_count(void);
  * 64 x 64 / 32 x 64 / 32 x 32 with split-K; 4 register-ring 32 x 32 (waves: 4, 8 or 16 per workgroup, 0 = by K; split-K);
  * 5..8 LDS-staged 128 x 128 / 64 x 64 / 128 x 64 / 64 x 128 for thousands of rows (no split-K); 9 / 10 one-shot 16 x 16 /
  * 32 x 32 (every load issued up front: dense layers and 1-D convolutions with K <= 192 x waves, K and c_per_tap multiples
- * of 8; waves 4 or 8); 11 / 12 the same for convolutions with the tile's source rows staged once in LDS.  An explicit id
- * outside its kernel's envelope is an error; tune = 0 never fails on shape.
+ * of 8; waves 4 or 8); 11 / 12 the same for convolutions with the tile's source rows staged once in LDS; 13 the 64 x 128
+ * tile with W read from memory straight into the matrix instruction's registers and only A staged (what tune = 0 picks
+ * for thousands of rows; results identical to id 8; no batch, no split-K).  An explicit id outside its kernel's envelope is
+ * an error; tune = 0 never fails on shape.
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_gemm_args {
     const float* A;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times the LDS-staged tiles of estts_gemm (ids 6 and 8) on the large-M shapes of configs 3 and 5 and checks them against a
+"""Times the LDS-staged tiles of estts_gemm (ids 6, 8 and the W-from-memory tile 13) on the large-M shapes of configs 3 and 5 and checks them against a
 float64 product of a row sample (GPU box only).  Run once per library build to compare two builds on one box:
   cp ab_libs/old.so <package>/libestts.so && python3 tools/ab_gemm_big.py && cp ab_libs/new.so <package>/libestts.so && ..."""
 import math
@@ -14,15 +14,20 @@ from estts import ops
 from estts.ops import PackedLinear
 from tune_gemm import timeit
 
+TILES = [int(t) for t in os.environ.get('AB_TILES', '6,8,13').split(',')]
 SHAPES = [  # (M, N, K, taps)
     (19200, 256, 512, 1), (19200, 256, 1536, 3), (19200, 512, 768, 3), (19200, 256, 1280, 5), (19200, 768, 256, 1),
     (19200, 1024, 512, 1), (19200, 256, 256, 1), (19200, 256, 96, 1), (19200, 256, 160, 1), (4800, 256, 512, 1), (3200, 1536, 512, 1),
 ]
 
 
+SMALL = [(4800, 256, 512, 1), (4800, 256, 1536, 3), (4800, 512, 768, 3), (4800, 256, 1280, 5), (3200, 512, 1536, 3), (3200, 512, 1024, 1),
+         (3200, 512, 512, 1), (2400, 256, 512, 1), (1200, 256, 512, 1), (2400, 512, 768, 3), (1600, 512, 1536, 3), (9600, 256, 512, 1)]
+
+
 def main():
     g = torch.Generator().manual_seed(0)
-    for M, N, K, taps in SHAPES:
+    for M, N, K, taps in (SMALL if os.environ.get('AB_SMALL') else SHAPES):
         cin = K // taps
         x = torch.randn(M, cin, generator=g).cuda()
         w = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -34,11 +39,14 @@ def main():
         cols = torch.cat([xp[rows + t] for t in range(taps)], dim=1)       # tap-major columns
         ref = cols @ w.double().t()
         res = []
-        for tile in (6, 8):
+        prev = None
+        for tile in TILES:
             ops.gemm(x, lin, out, seg_len=M, precision='bf16x3', tune=tile | (1 << 8))
             err = (out[rows.cuda()].double().cpu() - ref).abs().max().item()
+            same = '' if prev is None or tile < 13 else (' = prev' if torch.equal(out, prev) else ' != prev (max %.1e)' % (out - prev).abs().max().item())
+            prev = out.clone()
             t = timeit(lambda: ops.gemm(x, lin, out, seg_len=M, precision='bf16x3', tune=tile | (1 << 8)), reps=10, rounds=5)
-            res.append(f'tile{tile} {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.1f} TF/s (err {err:.1e})')
+            res.append(f'tile{tile} {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.1f} TF/s (err {err:.1e}{same})')
         print(f'M={M:6d} N={N:5d} K={K:5d} taps={taps} | ' + ' | '.join(res), flush=True)
 
 

@@ -19,9 +19,9 @@ CSRC = os.path.join(ROOT, 'expressive-speech-synthesis-research_amd', 'csrc')
 # instantiation serves several shapes])
 KERNELS = {
     'gemm {"M": 19200, "N": 256, "K": 512, "taps": 1}': (
-        'gemm_big_kernel<3, 1, 2, 3, 1>',
+        'gemm_wdirect_kernel<3, 2, 4, 1>',
         ' (config 3: the 19200 x 256 x 512 dense layers -- attention output projections over [x | ctx] and the cross-attention'
-        ' key / value projections; 64 x 128 tiles, 600 workgroups)', 153600),
+        ' key / value projections; 64 x 128 tiles, W from memory, 600 workgroups)', 153600),
     'attention_bwd {"B": 32, "H": 4, "Lq": 600, "Lk": 600, "depth": 64}': (
         'attention_bwd_wide_kernel',
         ' (config 5: one of the two passes -- owning queries, owning keys -- of the decoder self-attention backward, 600 x 600,'
