@@ -86,7 +86,7 @@ def test_gemm_conv_epilogue(taps, lpad, cin, cout, T, B):
     assert (out_full[:, cout:] == 0).all()
 
 
-@pytest.mark.parametrize('tile', [1, 4, 5, 9, 10, 9 | (4 << 16), 10 | (4 << 16)])
+@pytest.mark.parametrize('tile', [1, 4, 5, 6, 7, 8, 13, 9, 10, 9 | (4 << 16), 10 | (4 << 16)])
 def test_gemm_tile_layouts_identity_and_conv(tile):
     # identity input picks out W^T exactly (values exact in bf16): catches permuted fragment maps of each kernel
     K, N = 96, 160
@@ -189,6 +189,51 @@ def test_gemm_oneshot_kernels_agree_with_the_ring_kernel_on_random_shapes():
             assert err < 2e-5, (case, tune, M, N, K, taps, lpad, T, err)
             checked += 1
     assert checked > 400
+
+
+def test_gemm_large_tiles_agree_with_the_ring_kernel_on_random_shapes():
+    # The kernels for thousands of rows (LDS-staged tiles 5..8, and tile 13, which reads W from memory straight into the matrix
+    # instruction's registers) on 80 random dense / convolution shapes: partial row and column tiles, K tails inside a 32-wide
+    # step and K-step counts from 1 (every branch of the peeled main loop: fewer than four steps, odd and even counts),
+    # 1..4 sequences so that tiles straddle sequence boundaries, causal and 'same' padding, padded row strides, r_mod; against
+    # the register-ring kernel (tile 4), which the float64 tests above pin.  Tile 13 does the arithmetic of tile 8 in the same
+    # order: those two must agree bit for bit.
+    rng = np.random.default_rng(11)
+    checked = 0
+    for case in range(80):
+        taps = int(rng.choice([1, 1, 3, 5]))
+        cin = 4 * int(rng.integers(1, 80 if taps == 1 else 40))
+        K = taps * cin
+        B, T = int(rng.integers(1, 5)), int(rng.integers(1, 160))
+        N = int(rng.integers(1, 300))
+        lpad = int(rng.integers(0, taps))
+        M = B * T
+        pa, pc, pr = (4 * int(rng.integers(0, 3)) for _ in range(3))
+        x = _rand(M, cin + pa, seed=6000 + case)
+        w = _rand(N, K, seed=7000 + case, scale=1 / math.sqrt(K))
+        b1, s1 = _rand(N, seed=8000 + case), _rand(N, seed=9000 + case).abs() + 0.5
+        use_rmod = bool(rng.integers(0, 2)) and T > 1
+        res = _rand(T if use_rmod else M, N + pr, seed=10000 + case)
+        lin = PackedLinear(w.numpy(), bias=b1.numpy(), scale=s1.numpy(), device=DEV, taps=taps, lpad=lpad, act='tanh')
+        xd, rd = x.to(DEV), res.to(DEV)
+
+        def run(tune):
+            out = torch.full((M, N + pc), float('nan'), device=DEV)
+            ops.gemm(xd[:, :cin], lin, out[:, :N], seg_len=T, residual=rd[:, :N], r_mod=T if use_rmod else 0, alpha=0.7,
+                     precision='bf16x3', tune=tune)
+            assert torch.isnan(out[:, N:]).all()
+            return out[:, :N].clone()
+
+        ref = run(4)
+        assert torch.isfinite(ref).all()
+        got = {}
+        for tune in (5, 6, 7, 8, 13):
+            got[tune] = run(tune)
+            err = ((got[tune] - ref).abs().max() / ref.abs().max().clamp_min(1e-3)).item()
+            assert err < 2e-5, (case, tune, M, N, K, taps, lpad, T, err)
+            checked += 1
+        assert torch.equal(got[13], got[8]), (case, M, N, K, taps, lpad, T)
+    assert checked == 400
 
 
 @pytest.mark.parametrize('B,T,cin,taps,lpad,N', [(1, 100, 512, 3, 1, 512), (1, 600, 256, 3, 1, 512), (3, 23, 96, 5, 2, 72),
