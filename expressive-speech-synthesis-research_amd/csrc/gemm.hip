@@ -745,6 +745,27 @@ __global__ __launch_bounds__(256, OCC) void gemm_big_kernel(const estts_gemm_arg
 // 8 KB instead of 24, LDS fragment reads 32 KB instead of 48, the same 24 KB from memory and the same 48 matrix
 // instructions.  Same arithmetic in the same order as the 64 x 128 tile of the kernel above: identical results.
 // ======================================================================================================
+#ifdef ESTTS_GEMM_STAMPS
+// Diagnostic build (-DESTTS_GEMM_STAMPS, tools/gemm_stamps.py): lane 0 of every wave of ONE workgroup in the middle of the grid
+// adds up the shader-clock cycles between the marks of the steady-state loop.  The marks constrain the instruction scheduler,
+// so the kernel under test is not quite the shipped one.
+__device__ unsigned long long gemm_stamps[4][8];
+#define GS_DECL unsigned long long gs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gs_prev = clock64(), gs_first = gs_prev; \
+    const bool gs_on = (threadIdx.x & 63) == 0 && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2
+#define GS(i) do { const unsigned long long t_ = clock64(); gs_acc[i] += t_ - gs_prev; gs_prev = t_; } while (0)
+#define GS_RESET do { gs_prev = clock64(); } while (0)
+#define GS_WRITE do { if (gs_on) { for (int i_ = 0; i_ < 7; ++i_) gemm_stamps[threadIdx.x >> 6][i_] = gs_acc[i_]; \
+    gemm_stamps[threadIdx.x >> 6][7] = clock64() - gs_first; } } while (0)
+}  // namespace
+extern "C" int estts_debug_gemm_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gemm_stamps), sizeof(gemm_stamps)); }
+namespace {
+#else
+#define GS_DECL
+#define GS(i)
+#define GS_RESET
+#define GS_WRITE
+#endif
+
 template <int NSPLIT, int TM, int OCC, int KIND>
 __global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm_args p_in) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
@@ -844,17 +865,15 @@ __global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     af[s][i] = *reinterpret_cast<const bf16x8*>(&As[buf][s][a_base + i * 32 * BG_LD + q * 16]);
+            auto mma = [&](const bf16x8& a, const bf16x8& w, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, c, 0, 0, 0); };
             if (NS == 2) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[NS - 1][i], wf[0][q], acc[i][0], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) acc[i][0] = mma(af[NS - 1][i], wf[0][q], acc[i][0]);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], wf[NS - 1][q], acc[i][0], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) acc[i][0] = mma(af[0][i], wf[NS - 1][q], acc[i][0]);
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], wf[0][q], acc[i][0], 0, 0, 0);
+            for (int i = 0; i < TM; ++i) acc[i][0] = mma(af[0][i], wf[0][q], acc[i][0]);
         }
     };
 
@@ -864,6 +883,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm
     bool ok0[AI], ok1[AI];
     bf16x8 w0[NS][2], w1[NS][2];
     int kt = 0;
+    GS_DECL;
     if (nk >= 4) {
         load_a(a0, ok0, 0);
         load_w(w0, 0);
@@ -871,17 +891,28 @@ __global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm
         load_a(a1, ok1, 1);
         load_w(w1, 1);
         __builtin_amdgcn_sched_barrier(0);
+        GS_RESET;
         for (; kt + 3 < nk; kt += 2) {
             store_a(a0, ok0, 0);
+            GS(0);
             __syncthreads();
+            GS(1);
             load_a(a0, ok0, kt + 2);
+            GS(2);
             multiply(0, w0);
+            GS(3);
             load_w(w0, kt + 2);
+            GS(4);
             store_a(a1, ok1, 1);
+            GS(0);
             __syncthreads();
+            GS(1);
             load_a(a1, ok1, kt + 3);
+            GS(2);
             multiply(1, w1);
+            GS(3);
             load_w(w1, kt + 3);
+            GS(4);
         }
     } else {
         load_a(a0, ok0, 0);
@@ -908,7 +939,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm
         multiply(0, w0);
     }
 
+    GS(5);
     big_epilogue<TM, 1>(p, acc, m0, n0, 0, wave, r, h, tc);
+    GS(6);
+    GS_WRITE;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ from estts import ops
 from estts.ops import PackedLinear
 from tune_gemm import timeit
 
-TILES = [int(t) for t in os.environ.get('AB_TILES', '6,8,13').split(',')]
+TILES = [int(t, 0) for t in os.environ.get('AB_TILES', '6,8,13').split(',')]   # e.g. AB_TILES=8,13
 SHAPES = [  # (M, N, K, taps)
     (19200, 256, 512, 1), (19200, 256, 1536, 3), (19200, 512, 768, 3), (19200, 256, 1280, 5), (19200, 768, 256, 1),
     (19200, 1024, 512, 1), (19200, 256, 256, 1), (19200, 256, 96, 1), (19200, 256, 160, 1), (4800, 256, 512, 1), (3200, 1536, 512, 1),
@@ -46,7 +46,7 @@ def main():
             same = '' if prev is None or tile < 13 else (' = prev' if torch.equal(out, prev) else ' != prev (max %.1e)' % (out - prev).abs().max().item())
             prev = out.clone()
             t = timeit(lambda: ops.gemm(x, lin, out, seg_len=M, precision='bf16x3', tune=tile | (1 << 8)), reps=10, rounds=5)
-            res.append(f'tile{tile} {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.1f} TF/s (err {err:.1e}{same})')
+            res.append(f'tile{tile & 0xff}{"*" if tile >> 8 else ""} {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.1f} TF/s (err {err:.1e}{same})')
         print(f'M={M:6d} N={N:5d} K={K:5d} taps={taps} | ' + ' | '.join(res), flush=True)
 
 
