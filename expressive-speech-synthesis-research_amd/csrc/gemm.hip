@@ -485,6 +485,7 @@ __device__ __forceinline__ void big_epilogue(const estts_gemm_args& p, f32x16 (&
     // one lane swap, and each wave adds its 32 TN columns to copy (row tile % 16) of the sums
     const bool stats = p.stat_slots != nullptr;
     const long stat_cp = (long)((p.N + 255) / 256) * 256;
+    const bool plain = m0 + wm * 32 * TM + 32 * TM <= p.M && p.r_mod <= 0 && !(p.drop_rate > 0.0f);   // uniform over the wave
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * 32 * TN + j * 32 + r;
@@ -495,6 +496,50 @@ __device__ __forceinline__ void big_epilogue(const estts_gemm_args& p, f32x16 (&
         const float b2 = p.s2 ? p.b2[col] : 0.0f;
         const float k0 = (stats && p.stat_shift) ? p.stat_shift[col] : 0.0f;
         float q0 = 0.0f, q1 = 0.0f;
+        if (plain) {
+            // Straight-line form for a wave whose rows all exist, without dropout and without a wrapped residual: no test per
+            // element, the activation chosen once per tile, row addresses by offset from the tile's first row.  (The general
+            // form below costs a wave some 2000 instructions -- a row test, a division for r_mod, the activation's branches
+            // and a 64-bit address product per element -- and all workgroups of a one-round launch run it at the same time:
+            // a third of the launch at K = 512.)
+            const int act = p.act;
+            const float alpha = p.alpha;
+            const bool has_r = p.R != nullptr, has2 = p.s2 != nullptr;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row0 = m0 + wm * 32 * TM + i * 32 + 4 * h;
+                float* cp = p.C + (long)row0 * p.ldc + col;
+                float res[16];
+                if (has_r) {   // all 16 first (see below)
+                    const float* rp = p.R + (long)row0 * p.ldr + col;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) res[e] = rp[(long)((e & 3) + 8 * (e >> 2)) * p.ldr];
+                }
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e] * s1 + b1;
+                if (act == ESTTS_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.0f);
+                } else if (act == ESTTS_ACT_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = tanhf(v[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    v[e] *= alpha;
+                    if (has_r) v[e] += res[e];
+                    if (has2) v[e] = v[e] * s2 + b2;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    cp[(long)((e & 3) + 8 * (e >> 2)) * p.ldc] = v[e];
+                    const float d = v[e] - k0;
+                    q0 += d;
+                    q1 += d * d;
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             // the tile's 16 values of R first: R may be C itself (accumulation), so the compiler has to keep every load behind
@@ -1105,10 +1150,11 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         // 8) and the older 64 x 64 kernels (ids 1-3) never win at these sizes and are kept for explicit selection only.
         const long mt = (long)((a.M + 63) / 64) * (a.batch > 1 ? a.batch : 1);
         const long n8 = mt * ((a.N + 127) / 128), n6 = mt * ((a.N + 63) / 64);
-        // 64 x 128 tiles run on the W-from-memory kernel (id 13: 19200 x 256 x 512 28.1 us against 31.1 for id 8 and 30.2 as
-        // 64 x 64 tiles; 19200 x 256 x 1536, three taps: 63.5 / 76 / 81 us; 19200 x 1024 x 512: 76 / 89 / 98 us); below 384 such
-        // tiles the 64 x 64 tiles are as fast or faster (9600 x 256 x 512: 19.8 against 20.4 us)
-        tile = (a.N >= 128 && n8 >= 384 && a.batch <= 1) ? 13 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
+        // 64 x 128 tiles run on the W-from-memory kernel (id 13: 19200 x 256 x 512 24.2 us against 27.3 as 64 x 64 tiles;
+        // 19200 x 256 x 1536, three taps: 58 / 75 us; 19200 x 1024 x 512: 68 / 85 us; 4800 x 256 x 512: 11.5 / 13.1 us;
+        // 3200 x 512 x 1024: 19.2 / 22.9 us); below about 150 such tiles the 64 x 64 tiles win (2400 x 256 x 512: 9.4 against
+        // 11.6 us; 1600 x 512 x 1536, three taps: 26.5 against 28.7 us)
+        tile = (a.N >= 128 && n8 >= 144 && a.batch <= 1) ? 13 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
     }
     if (a.stat_slots) {
         ESTTS_CHECK_ARG(a.batch <= 1 && !a.ln_y, "estts_gemm: stat_slots not with batch > 1 or a LayerNorm prologue");

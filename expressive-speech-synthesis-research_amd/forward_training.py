@@ -600,7 +600,7 @@ class ForwardTransformerTrainer:
         """BatchNorm moving statistics are per replica during data-parallel training (the reference is single-GPU; there is
         no SyncBN): before a checkpoint every rank takes rank `src`'s, so that all replicas resume from what was saved."""
         if self.world > 1:
-            torch.distributed.broadcast(self.store.state, src=src, group=self.pg)
+            parallel.broadcast_(self.store.state, src=src, group=self.pg)
 
     def weights(self):
         """Current variables as a dict name -> ndarray in the layouts of weights.py (for ForwardTransformer / checkpoints)."""

@@ -66,6 +66,35 @@ def barrier():
         dist.barrier()
 
 
+def _staged(t, group=None):
+    """True for a device tensor on a backend other than RCCL (gloo: two ranks rehearsing on one GPU)."""
+    return t.is_cuda and dist.get_backend(group) != 'nccl'
+
+
+def all_reduce_sum_(t, group=None):
+    """In-place sum of `t` over all ranks, blocking.  Over gloo a device tensor goes through a host copy made HERE and the
+    host tensor is what gloo sees: ProcessGroupGloo's own device path (staging threads and streams of its own) has stalled for
+    good with two processes on one GPU -- two collectives in flight behind queued kernels at first
+    (tools/gloo_concurrent.py), later a single one, both ranks inside the same all-reduce with two of gloo's threads in an
+    uninterruptible driver call -- and the rehearsal transport is not what is being rehearsed."""
+    if _staged(t, group):
+        h = t.detach().to('cpu')
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+def broadcast_(t, src=0, group=None):
+    """In-place broadcast from rank `src`, blocking; device tensors over gloo through a host copy (see all_reduce_sum_)."""
+    if _staged(t, group):
+        h = t.detach().to('cpu')
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 def bucket_ranges(n, bucket_elems):
     """[(start, end)] covering range(n) in pieces of at most bucket_elems elements."""
     bucket_elems = max(int(bucket_elems), 1)
@@ -76,11 +105,16 @@ def allreduce_buckets(flat, bucket_elems, group=None, comm_stream=None):
     """Sums the 1-D tensor `flat` over all ranks in place, one asynchronous all-reduce per bucket (xGMI rings are
     per-link bound, so a handful of ~25 MB buckets keeps every link busy without the latency of many small calls).
     On a GPU the collectives are issued on `comm_stream` (which first waits for the current stream) and the current
-    stream waits for them at the end; on the CPU (gloo) they are simply waited for.  No-op when not distributed."""
+    stream waits for them at the end; on the CPU (gloo) they are simply waited for, and a device tensor over gloo goes
+    bucket by bucket through host copies (all_reduce_sum_).  No-op when not distributed."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     ranges = bucket_ranges(flat.numel(), bucket_elems)
-    if flat.is_cuda and comm_stream is not None:
+    if _staged(flat, group):   # gloo on device memory (two ranks rehearsing on one GPU): bucket by bucket through the host
+        torch.cuda.current_stream(flat.device).synchronize()
+        for a, b in ranges:
+            all_reduce_sum_(flat[a:b], group)
+    elif flat.is_cuda and comm_stream is not None:
         cur = torch.cuda.current_stream(flat.device)
         comm_stream.wait_stream(cur)
         with torch.cuda.stream(comm_stream):
@@ -109,7 +143,8 @@ class GradientOverlap:
         self.min_elems = bucket_elems // 4 if min_elems is None else min_elems
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         # gloo stages device buffers through host threads of its own; collectives issued while kernels are still queued
-        # stalled two ranks sharing one GPU, so with gloo on device memory the whole exchange waits for finish()
+        # stalled two ranks sharing one GPU, so with gloo on device memory the whole exchange waits for finish() and then
+        # goes out bucket by bucket through host copies made here
         self.defer = (self.active and flat.is_cuda and dist.get_backend(group) != 'nccl'
                       and os.environ.get('ESTTS_GLOO_OVERLAP', '0') != '1')     # (diagnostic switch: overlap over gloo anyway)
         self.final = False
@@ -129,6 +164,9 @@ class GradientOverlap:
             self.comm.wait_stream(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.comm):
                 self.works += [dist.all_reduce(self.flat[a:b], group=self.group, async_op=True) for a, b in ranges]
+        elif self.defer:   # gloo on device memory: bucket by bucket through the host (see all_reduce_sum_)
+            for a, b in ranges:
+                all_reduce_sum_(self.flat[a:b], self.group)
         else:
             self.works += [dist.all_reduce(self.flat[a:b], group=self.group, async_op=True) for a, b in ranges]
         self.calls += ranges

@@ -236,7 +236,7 @@ class WaveRNNTrainer:
         """BatchNorm running statistics are per replica during data-parallel training; before a checkpoint every rank takes
         rank `src`'s."""
         if self.world > 1:
-            torch.distributed.broadcast(self.store.state, src=src, group=self.pg)
+            parallel.broadcast_(self.store.state, src=src, group=self.pg)
 
     def restore(self, path):
         """fatchord_version.py:396-402: a new session writes its initial weights, an old one is loaded."""

@@ -167,7 +167,6 @@ def main():
     restore_heads(cm, heads, mi_holder, model.step, rank == 0)
     max_steps = args.max_steps or cfg['max_steps']
     # ragged ranks: every rank divides its losses by the global batch's padded frame count (train_step(global_frames=...))
-    frames_buf = torch.zeros(1, dtype=torch.int64, device='cuda') if world > 1 else None
     losses = []
     while model.step < max_steps:
         mel, phonemes, stop, spk = next(batches)
@@ -180,9 +179,7 @@ def main():
                             drop_n_heads=reduction_schedule(model.step, cfg['head_drop_schedule']))
         global_frames = None
         if world > 1:
-            frames_buf.fill_(mel.shape[1] - 1)
-            torch.distributed.all_reduce(frames_buf, op=torch.distributed.ReduceOp.MAX)
-            global_frames = int(frames_buf.item())
+            global_frames = int(parallel.max_over_ranks(mel.shape[1] - 1))
         out = train_models_step(mel, phonemes, stop, spk, m_mel, m_ph, m_stop, m_spk, model, heads, mi_holder,
                                 cfg.get('train_text_encoder', True), cfg.get('train_style_encoder', True),
                                 cfg.get('train_decoder', True), cfg.get('use_style_loss', False), global_frames=global_frames)

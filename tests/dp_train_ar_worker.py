@@ -24,9 +24,10 @@ from test_gpu_autoregressive_training import batch, small_cfg  # noqa: E402
 
 
 def gathered(t):
-    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, t)
-    return out
+    h = t.detach().to('cpu')     # gloo sees host tensors only (its device path has stalled with two ranks on one GPU)
+    out = [torch.empty_like(h) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, h)
+    return [o.to(t.device) for o in out]
 
 
 def main():
