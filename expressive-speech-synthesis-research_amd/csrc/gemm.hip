@@ -485,7 +485,9 @@ __device__ __forceinline__ void big_epilogue(const estts_gemm_args& p, f32x16 (&
     // one lane swap, and each wave adds its 32 TN columns to copy (row tile % 16) of the sums
     const bool stats = p.stat_slots != nullptr;
     const long stat_cp = (long)((p.N + 255) / 256) * 256;
-    const bool plain = m0 + wm * 32 * TM + 32 * TM <= p.M && p.r_mod <= 0 && !(p.drop_rate > 0.0f);   // uniform over the wave
+    // (a wrapped residual -- r_mod: the positional-encoding table added by row modulo the sequence length -- stays in as long as
+    // the 28 rows a lane spans wrap at most once)
+    const bool plain = m0 + wm * 32 * TM + 32 * TM <= p.M && (p.r_mod <= 0 || p.r_mod >= 32) && !(p.drop_rate > 0.0f);   // uniform over the wave
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * 32 * TN + j * 32 + r;
@@ -497,7 +499,7 @@ __device__ __forceinline__ void big_epilogue(const estts_gemm_args& p, f32x16 (&
         const float k0 = (stats && p.stat_shift) ? p.stat_shift[col] : 0.0f;
         float q0 = 0.0f, q1 = 0.0f;
         if (plain) {
-            // Straight-line form for a wave whose rows all exist, without dropout and without a wrapped residual: no test per
+            // Straight-line form for a wave whose rows all exist, without dropout: no test per
             // element, the activation chosen once per tile, row addresses by offset from the tile's first row.  (The general
             // form below costs a wave some 2000 instructions -- a row test, a division for r_mod, the activation's branches
             // and a 64-bit address product per element -- and all workgroups of a one-round launch run it at the same time:
@@ -511,9 +513,19 @@ __device__ __forceinline__ void big_epilogue(const estts_gemm_args& p, f32x16 (&
                 float* cp = p.C + (long)row0 * p.ldc + col;
                 float res[16];
                 if (has_r) {   // all 16 first (see below)
-                    const float* rp = p.R + (long)row0 * p.ldr + col;
+                    if (p.r_mod > 0) {
+                        const int rr0 = row0 % p.r_mod;   // one division per tile instead of one per element
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) res[e] = rp[(long)((e & 3) + 8 * (e >> 2)) * p.ldr];
+                        for (int e = 0; e < 16; ++e) {
+                            int rr = rr0 + (e & 3) + 8 * (e >> 2);
+                            rr -= rr >= p.r_mod ? p.r_mod : 0;
+                            res[e] = p.R[(long)rr * p.ldr + col];
+                        }
+                    } else {
+                        const float* rp = p.R + (long)row0 * p.ldr + col;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) res[e] = rp[(long)((e & 3) + 8 * (e >> 2)) * p.ldr];
+                    }
                 }
                 float v[16];
 #pragma unroll

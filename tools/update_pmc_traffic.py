@@ -22,6 +22,10 @@ KERNELS = {
         'gemm_wdirect_kernel<3, 2, 4, 1>',
         ' (config 3: the 19200 x 256 x 512 dense layers -- attention output projections over [x | ctx] and the cross-attention'
         ' key / value projections; 64 x 128 tiles, W from memory, 600 workgroups)', 153600),
+    'gemm {"M": 19200, "N": 256, "K": 256, "taps": 1}': (
+        'gemm_wdirect_kernel<3, 2, 4, 1>',
+        ' (config 3: the 19200 x 256 x 256 dense layers run the same instantiation on the same grid as the 19200 x 256 x 512 ones,'
+        ' 600 workgroups; the counters cannot tell the two apart, this is the mean over both: K = 256 reads 19.7 MB less of A)', 153600),
     'attention_bwd {"B": 32, "H": 4, "Lq": 600, "Lk": 600, "depth": 64}': (
         'attention_bwd_wide_kernel',
         ' (config 5: one of the two passes -- owning queries, owning keys -- of the decoder self-attention backward, 600 x 600,'
