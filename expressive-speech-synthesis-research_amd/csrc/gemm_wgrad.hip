@@ -26,6 +26,25 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const __bf16* p0, const __bf16* p
     return __builtin_bit_cast(bf16x8, r);
 }
 
+#ifdef ESTTS_WGRAD_STAMPS
+// Diagnostic build (-DESTTS_WGRAD_STAMPS, tools/wgrad_stamps.py): lane 0 of every wave of ONE workgroup in the middle of the grid
+// adds up the shader-clock cycles between the marks of the row loop.  The marks constrain the instruction scheduler, so the
+// kernel under test is not quite the shipped one.
+__device__ unsigned long long wgrad_stamps[4][8];
+#define WS_DECL unsigned long long ws_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_prev = clock64(), ws_first = ws_prev; \
+    const bool ws_on = (threadIdx.x & 63) == 0 && blockIdx.x == gridDim.x / 2
+#define WS(i) do { const unsigned long long t_ = clock64(); ws_acc[i] += t_ - ws_prev; ws_prev = t_; } while (0)
+#define WS_WRITE do { if (ws_on) { for (int i_ = 0; i_ < 7; ++i_) wgrad_stamps[threadIdx.x >> 6][i_] = ws_acc[i_]; \
+    wgrad_stamps[threadIdx.x >> 6][7] = clock64() - ws_first; } } while (0)
+}  // namespace
+extern "C" int estts_debug_wgrad_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wgrad_stamps), sizeof(wgrad_stamps)); }
+namespace {
+#else
+#define WS_DECL
+#define WS(i)
+#define WS_WRITE
+#endif
+
 template <int NSPLIT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, const float* dY, const int lddy, float* dW,
                                                     const int lddw, const int rows_per_split, float* db, const int ktiles,
@@ -125,10 +144,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     const int frag = (4 * g + (i16 >> 2)) * LD + 4 * (i16 & 3);
     if (m_begin < m_end) load(m_begin);
     int buf = 0;
+    WS_DECL;
     for (int m0 = m_begin; m0 < m_end; m0 += 32) {
         stage(buf);
+        WS(0);
         __syncthreads();
+        WS(1);
         if (m0 + 32 < m_end) load(m0 + 32);
+        WS(2);
         bf16x8 af[NS][2], yf[NS][2];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -157,6 +180,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], yf[0][j], acc[i][j], 0, 0, 0);
         buf ^= 1;
+        WS(3);
     }
 
     // bias gradient: the workgroups of the first K tile add up the dY rows they staged anyway
@@ -185,6 +209,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
                 if (row < ga.K) atomic_add_f32(dW + (long)row * lddw + col, acc[i][j][r]);
             }
         }
+    WS(4);
+    WS_WRITE;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -13,6 +13,10 @@ from estts import train_ops as T  # noqa: E402
 if os.environ.get('TUNE_SMALL'):      # the B = 8 step of the autoregressive trainer, the B = 32 encoder
     SHAPES = [(4800, 256, 1536, 3, 600), (4800, 512, 768, 3, 600), (4800, 256, 1280, 5, 600), (3200, 512, 1536, 3, 100),
               (800, 512, 1536, 3, 100)]
+elif os.environ.get('TUNE_ONETAP'):   # dense layers of the B = 32 step (decoder 256 wide, encoder 512 wide)
+    SHAPES = [(19200, 1024, 256, 1, 0), (19200, 256, 1024, 1, 0), (19200, 768, 256, 1, 0), (19200, 256, 256, 1, 0), (19200, 256, 512, 1, 0),
+              (19200, 128, 256, 1, 0), (3200, 1536, 512, 1, 0), (3200, 512, 512, 1, 0), (3200, 2048, 512, 1, 0), (3200, 512, 2048, 1, 0),
+              (19200, 200, 260, 1, 0)]
 else:
   SHAPES = [(19200, 256, 1536, 3, 600), (19200, 512, 768, 3, 600), (3200, 512, 1536, 3, 100), (19200, 256, 1280, 5, 600),
             (19200, 80, 1280, 5, 600), (19200, 256, 768, 1, 0)]
@@ -24,6 +28,12 @@ for M, N, K, taps, seg in SHAPES:
     dw = torch.zeros(K, N, device='cuda')
     db = torch.zeros(N, device='cuda') if os.environ.get('TUNE_DB') else None
     for sp in SPLITS:
+        if os.environ.get('TUNE_CHECK'):     # against a float64 product (one-tap shapes)
+            dw.zero_()
+            T.wgrad(xs[0], dys[0], dw, taps=taps, lpad=(taps - 1) // 2, seg_len=seg, splits=sp, db=db)
+            if taps == 1:
+                ref = xs[0].double().t() @ dys[0].double()
+                print('   max err vs float64: %.2e (scale %.1f)' % ((dw.double() - ref).abs().max().item(), ref.abs().max().item()))
         for i in range(3):
             T.wgrad(xs[i % ROTATE], dys[i % ROTATE], dw, taps=taps, lpad=(taps - 1) // 2, seg_len=seg, splits=sp, db=db)
         torch.cuda.synchronize()
