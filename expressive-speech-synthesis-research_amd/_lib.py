@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -31,7 +31,7 @@ class GemmArgs(C.Structure):
                 ('batch_stride_v', _i64),
                 ('ln_y', _vp), ('ln_x', _vp), ('ln_ga', _vp), ('ln_ba', _vp), ('ln_gb', _vp), ('ln_bb', _vp), ('ln_out', _vp),
                 ('ln_ldy', _i32), ('ln_ldx', _i32), ('ln_ldo', _i32), ('ln_act', _i32), ('ln_eps', _f32),
-                ('stat_slots', _vp), ('stat_shift', _vp)]
+                ('stat_slots', _vp), ('stat_shift', _vp), ('ln_epilogue', _i32)]
 
 
 class AttentionArgs(C.Structure):

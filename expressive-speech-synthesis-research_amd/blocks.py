@@ -72,6 +72,10 @@ class SelfAttentionLayer:
         ops.gemm(xc[:, :d], self.qkv, qkv, precision=precision, site='qkv')
         ops.attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], xc[:, d:], B, self.heads, L, L, d // self.heads,
                       key_mask=key_mask, causal=causal, attn=attn, precision=precision)
+        if not defer_norm and ops.can_fuse_ln_epilogue(self.out, B * L):   # batch sizes: the norms inside the projection's launch
+            ops.gemm(xc, self.out, x1, precision=precision, site='attn_out',
+                     norm=dict(ln_a=self.ln, residual=xc[:, :d], ln_b=self.last_ln))
+            return None
         ops.gemm(xc, self.out, y, precision=precision, site='attn_out')
         if defer_norm:
             return dict(y=y, x=xc[:, :d], ln_a=self.ln, ln_b=self.last_ln, out=x1)
@@ -101,6 +105,10 @@ class FFNLayer:
         return 0 if self.fold else self.d1.N
 
     def run(self, x1, h, y, out, precision):
+        if self.fold and ops.can_fuse_ln_epilogue(self.d12, x1.shape[0]):
+            ops.gemm(x1, self.d12, out, precision=precision, site='ffn',
+                     norm=dict(ln_a=self.ln, act='relu', residual=x1, ln_b=self.last_ln))
+            return
         if self.fold:
             ops.gemm(x1, self.d12, y, precision=precision, site='ffn')
         else:
@@ -209,6 +217,9 @@ class CrossAttentionLayer:
         ops.gemm(xc[:, :d], self.wq, q, precision=precision, site='cross_q')
         ops.attention(q, kv[:, :d], kv[:, d:], xc[:, d:], B, self.heads, Lq, Lk, d // self.heads, key_mask=enc_mask,
                       attn=attn, precision=precision)
+        if ops.can_fuse_ln_epilogue(self.out, B * Lq):
+            ops.gemm(xc, self.out, out, precision=precision, site='attn_out', norm=dict(residual=xc[:, :d], ln_b=self.ln))
+            return
         ops.gemm(xc, self.out, y, precision=precision, site='attn_out')
         ops.rownorm(y, out, residual=xc[:, :d], ln_b=self.ln)
 

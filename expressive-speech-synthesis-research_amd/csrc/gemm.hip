@@ -823,38 +823,49 @@ namespace {
 #define GS_WRITE
 #endif
 
-template <int NSPLIT, int TM, int OCC, int KIND>
-__global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm_args p_in) {
+// NWV = 8: eight waves side by side, a workgroup owns 64 rows x 256 columns (id 14).  LNE (NWV = 8, N = 256: the workgroup
+// owns whole rows): the epilogue is estts_rownorm, C = LNb(act_ln(LNa(acc s1 + b1)) + ln_x) -- the tile goes through LDS (in the
+// place of the A images) so that a wave normalises whole rows exactly as rownorm_fast_kernel does, and writes them as float4.
+template <int NSPLIT, int TM, int NWV, bool LNE>
+constexpr int wdirect_smem_bytes() {
+    constexpr int a_bytes = 2 * ((NSPLIT > 1) ? 2 : 1) * 32 * TM * BG_LD * 2;      // two buffers of the hi (+ lo) A images
+    constexpr int t_bytes = LNE ? 32 * TM * (32 * NWV + 4) * 4 : 0;                // the epilogue's float32 tile
+    return a_bytes > t_bytes ? a_bytes : t_bytes;
+}
+
+// the tile with first row m0 and first column n0; smem: wdirect_smem_bytes() of LDS
+template <int NSPLIT, int TM, int KIND, int NWV, bool LNE>
+__device__ __forceinline__ void wdirect_tile(const estts_gemm_args& p, unsigned char* smem, const int m0, const int n0, const TileCoord tc) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
-    constexpr int BM = 32 * TM, BN = 128;   // TM = 2 (or 4: 128 rows, half the W loads per matrix instruction)
-    constexpr int AI = TM;       // float4 loads of A per thread and K-step
-    __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][BM * BG_LD];
+    constexpr int BM = 32 * TM, BN = 32 * NWV;   // TM = 2 (or 4: 128 rows, half the W loads per matrix instruction)
+    constexpr int RP = 8 * NWV;  // rows the workgroup's threads cover with one float4 each
+    constexpr int AI = (BM + RP - 1) / RP;  // float4 loads of A per thread and K-step
+    constexpr int T_LD = BN + 4;                           // floats per row of the epilogue's tile
+    __bf16 (*As)[NS][BM * BG_LD] = reinterpret_cast<__bf16 (*)[NS][BM * BG_LD]>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const TileCoord tc = xcd_tile_coord((p_in.tune & (1 << 25)) ? false : gemm_y_first(p_in), !(p_in.tune & (1 << 24)));
-    const estts_gemm_args& p = p_in;
-    const int m0 = tc.ty * BM;
-    const int n0 = tc.tx * BN;
     const int KS = p.ldw >> 5;
 
     const int nb_end = ((p.N + 63) / 64) * 4;  // 16-column blocks present in W
     const int a_ch = tid & 7;    // float4 chunk of the 32-wide K slice
-    const int a_r0 = tid >> 3;   // rows a_r0 + 32 i
+    const int a_r0 = tid >> 3;   // rows a_r0 + RP i
+    // (32-row tiles of eight waves: the upper four waves stage nothing; uniform per wave)
     ARow a_row[AI];
     const float* a_ptr[AI];   // KIND 1 / 2: start of the row (rows past M re-read the last one; their results are never stored)
     int a_pos[AI];            // KIND 2: position of the row inside its sequence
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int row = min(m0 + a_r0 + 32 * i, p.M - 1);
+        const int row = min(m0 + a_r0 + RP * i, p.M - 1);
         if (KIND == 1) a_ptr[i] = p.A + (long)row * p.lda + a_ch * 4;
         else if (KIND == 2) { a_ptr[i] = p.A + (long)row * p.lda; a_pos[i] = row % p.conv_w; }
-        else a_row[i] = make_arow(p, m0 + a_r0 + 32 * i);
+        else a_row[i] = make_arow(p, m0 + a_r0 + RP * i);
     }
     KCursor kcur = make_kcursor(p, a_ch * 4);   // load_a is called for kt = 0, 1, 2, ... in order
     auto load_a = [&](float4 (&ga)[AI], bool (&gok)[AI], int kt) {
+        if constexpr (BM < RP) { if (a_r0 >= BM) return; }
         if (KIND == 1) {
             const bool ok = kt * 32 + a_ch * 4 < p.K;
 #pragma unroll
@@ -881,9 +892,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm
         }
     };
     auto store_a = [&](const float4 (&ga)[AI], const bool (&gok)[AI], int buf) {
+        if constexpr (BM < RP) { if (a_r0 >= BM) return; }
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            const int o = (a_r0 + 32 * i) * BG_LD + a_ch * 4;
+            const int o = (a_r0 + RP * i) * BG_LD + a_ch * 4;
             // KIND 1 needs no zeroing: a K index past the end re-reads valid data of the row, and W is zero-padded there
             const float4 az = KIND == 1 ? ga[i] : zero_unless(gok[i], ga[i]);
             bf16x4 hi, lo;
@@ -997,9 +1009,117 @@ __global__ __launch_bounds__(256, OCC) void gemm_wdirect_kernel(const estts_gemm
     }
 
     GS(5);
-    big_epilogue<TM, 1>(p, acc, m0, n0, 0, wave, r, h, tc);
+    if constexpr (LNE) {
+        // the row operands of the norms first: their round trips run beside the trip of the tile through LDS
+        constexpr int RW = BM / NWV;   // rows per wave; lane <-> columns 4 lane .. 4 lane + 3, as in rownorm_fast_kernel
+        const int c = lane * 4;
+        const bool lna = p.ln_ga != nullptr, lnb = p.ln_gb != nullptr, res = p.ln_x != nullptr;   // uniform
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v[RW], rx[RW];
+        const int row0 = m0 + wave * RW;
+        float4 ga = zero4, ba = zero4, gb = zero4, bb = zero4;
+#pragma unroll
+        for (int q = 0; q < RW; ++q) rx[q] = zero4;
+        if (res) {   // (uniform branches: a load chosen by a condition becomes a load through a generic pointer)
+#pragma unroll
+            for (int q = 0; q < RW; ++q)   // a surplus slot repeats the last row and is not stored
+                rx[q] = *reinterpret_cast<const float4*>(p.ln_x + (long)min(row0 + q, p.M - 1) * p.ln_ldx + c);
+        }
+        if (lna) {
+            ga = *reinterpret_cast<const float4*>(p.ln_ga + c);
+            ba = *reinterpret_cast<const float4*>(p.ln_ba + c);
+        }
+        if (lnb) {
+            gb = *reinterpret_cast<const float4*>(p.ln_gb + c);
+            bb = *reinterpret_cast<const float4*>(p.ln_bb + c);
+        }
+        __syncthreads();   // every wave is past its last fragment read: the tile takes the place of the A images
+        float* T = reinterpret_cast<float*>(smem);
+        {
+            const int col = wave * 32 + r;   // n0 = 0
+            const float s1 = p.s1 ? p.s1[col] : 1.0f, b1 = p.b1 ? p.b1[col] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) T[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * T_LD + col] = acc[i][0][e] * s1 + b1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RW; ++q) v[q] = *reinterpret_cast<const float4*>(T + (wave * RW + q) * T_LD + c);
+        auto layer_norm = [&](const float4& g, const float4& b) {
+            float mean[RW], inv[RW];
+#pragma unroll
+            for (int q = 0; q < RW; ++q) mean[q] = v[q].x + v[q].y + v[q].z + v[q].w;
+#pragma unroll
+            for (int q = 0; q < RW; ++q) mean[q] = wave_sum(mean[q]) / (float)BN;
+#pragma unroll
+            for (int q = 0; q < RW; ++q) {
+                const float a = v[q].x - mean[q], b2 = v[q].y - mean[q], c2 = v[q].z - mean[q], d = v[q].w - mean[q];
+                inv[q] = a * a + b2 * b2 + c2 * c2 + d * d;
+            }
+#pragma unroll
+            for (int q = 0; q < RW; ++q) inv[q] = rsqrtf(wave_sum(inv[q]) / (float)BN + p.ln_eps);
+#pragma unroll
+            for (int q = 0; q < RW; ++q) {
+                v[q].x = (v[q].x - mean[q]) * inv[q] * g.x + b.x;
+                v[q].y = (v[q].y - mean[q]) * inv[q] * g.y + b.y;
+                v[q].z = (v[q].z - mean[q]) * inv[q] * g.z + b.z;
+                v[q].w = (v[q].w - mean[q]) * inv[q] * g.w + b.w;
+            }
+        };
+        if (lna) layer_norm(ga, ba);
+#pragma unroll
+        for (int q = 0; q < RW; ++q) {
+            v[q].x = apply_act(v[q].x, p.ln_act) + rx[q].x;
+            v[q].y = apply_act(v[q].y, p.ln_act) + rx[q].y;
+            v[q].z = apply_act(v[q].z, p.ln_act) + rx[q].z;
+            v[q].w = apply_act(v[q].w, p.ln_act) + rx[q].w;
+        }
+        if (lnb) layer_norm(gb, bb);
+#pragma unroll
+        for (int q = 0; q < RW; ++q)
+            if (row0 + q < p.M) *reinterpret_cast<float4*>(p.C + (long)(row0 + q) * p.ldc + c) = v[q];
+    } else {
+        big_epilogue<TM, 1>(p, acc, m0, n0, 0, wave, r, h, tc);
+    }
     GS(6);
     GS_WRITE;
+}
+
+// Tile order of a launch region of gx x gy tiles whose workgroups the hardware hands to the XCDs round robin (id & 7): as
+// xcd_tile_coord, for a region that is not the whole grid.
+__device__ __forceinline__ TileCoord region_tile_coord(int id, const int gx, const int gy, const bool y_first, const bool remap) {
+    const int nwg = gx * gy;
+    if (remap && nwg >= 16) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    TileCoord t;
+    t.tz = 0;
+    if (y_first) { t.ty = id % gy; t.tx = id / gy; }
+    else         { t.tx = id % gx; t.ty = id / gx; }
+    return t;
+}
+
+// Rows in 64-row tiles and, behind them, 32-row tiles: workgroups 0 .. n_big - 1 (dispatched first) own 64 rows each, the rest
+// 32 (rows gy_big * 64 and up).  Workgroups of one launch are all resident at these sizes, so a launch takes as long as its
+// busiest CU: 19 200 x 256 as 600 equal tiles of 64 x 128 puts three tiles on 88 CUs and two on the others; as 512 + 176 the
+// busiest CU has two and a half.
+template <int NSPLIT, int OCC, int KIND, int NWV = 4, bool LNE = false>
+__global__ __launch_bounds__(64 * NWV, OCC) void gemm_wdirect_kernel(const estts_gemm_args p_in, const int n_big, const int gy_big, const int gy_small) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[wdirect_smem_bytes<NSPLIT, 2, NWV, LNE>()];
+    constexpr int BN = 32 * NWV;
+    const int gx = (p_in.N + BN - 1) / BN;
+    const bool y_first = (p_in.tune & (1 << 25)) ? false : gemm_y_first(p_in);
+    const bool remap = !(p_in.tune & (1 << 24));
+    const int id = blockIdx.x;
+    if (id < n_big) {
+        const TileCoord tc = region_tile_coord(id, gx, gy_big, y_first, remap);
+        wdirect_tile<NSPLIT, 2, KIND, NWV, LNE>(p_in, smem, tc.ty * 64, tc.tx * BN, tc);
+    } else {
+        const TileCoord tc = region_tile_coord(id - n_big, gx, gy_small, y_first, remap && (n_big & 7) == 0);
+        wdirect_tile<NSPLIT, 1, KIND, NWV, LNE>(p_in, smem, gy_big * 64 + tc.ty * 32, tc.tx * BN, tc);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1093,21 +1213,39 @@ int launch_big_d(const estts_gemm_args& a, hipStream_t st) {
     return 0;
 }
 
-template <int TM, int OCC, int KIND>
+// Tile 13 (four waves, 64 x 128 tiles, four workgroups per CU) and tile 14 (eight waves, 64 x 256, two per CU; LNE: with the
+// LayerNorm epilogue, N = 256).  When the launch's last round of tiles (a round = one tile per CU) would be at most half full,
+// the row tiles of that round go out as 32-row tiles behind the others (tune bit 26: equal tiles only, for measurements).
+template <int OCC, int KIND, int NWV, bool LNE>
 int launch_wdirect_d(const estts_gemm_args& a, hipStream_t st) {
-    dim3 grid((a.N + 127) / 128, (a.M + 32 * TM - 1) / (32 * TM), 1);
+    constexpr int BN = 32 * NWV;
+    const long cus = 256;
+    const long gx = (a.N + BN - 1) / BN, t64 = (a.M + 63) / 64;
+    const long total = gx * t64;
+    long gy_big = t64, gy_small = 0;
+    if (!(a.tune & (1 << 26)) && total > cus) {
+        const long rem = total % cus;
+        if (rem != 0 && rem <= cus / 2) {
+            gy_big = t64 - (rem + gx - 1) / gx;
+            gy_small = (a.M - gy_big * 64 + 31) / 32;
+        }
+    }
+    const long n_big = gy_big * gx, nwg = n_big + gy_small * gx;
+    ESTTS_CHECK_ARG(nwg < (1L << 31), "estts_gemm: too many workgroups");
+    dim3 grid((unsigned)nwg, 1, 1);
     if (a.precision == 3)
-        ESTTS_LAUNCH((gemm_wdirect_kernel<3, TM, OCC, KIND>), grid, dim3(256), 0, st, a);
+        ESTTS_LAUNCH((gemm_wdirect_kernel<3, OCC, KIND, NWV, LNE>), grid, dim3(64 * NWV), 0, st, a, (int)n_big, (int)gy_big, (int)gy_small);
     else
-        ESTTS_LAUNCH((gemm_wdirect_kernel<1, TM, OCC, KIND>), grid, dim3(256), 0, st, a);
+        ESTTS_LAUNCH((gemm_wdirect_kernel<1, OCC, KIND, NWV, LNE>), grid, dim3(64 * NWV), 0, st, a, (int)n_big, (int)gy_big, (int)gy_small);
     ESTTS_CHECK_LAUNCH("estts_gemm");
     return 0;
 }
 
-template <int TM, int OCC>
+template <int OCC, int NWV, bool LNE>
 int launch_wdirect(const estts_gemm_args& a, hipStream_t st) {
     const int kind = operand_kind(a);
-    return kind == 1 ? launch_wdirect_d<TM, OCC, 1>(a, st) : kind == 2 ? launch_wdirect_d<TM, OCC, 2>(a, st) : launch_wdirect_d<TM, OCC, 0>(a, st);
+    return kind == 1 ? launch_wdirect_d<OCC, 1, NWV, LNE>(a, st) : kind == 2 ? launch_wdirect_d<OCC, 2, NWV, LNE>(a, st)
+                                                                              : launch_wdirect_d<OCC, 0, NWV, LNE>(a, st);
 }
 
 template <int TM, int TN, int OCC>
@@ -1167,10 +1305,16 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         // 3200 x 512 x 1024: 19.2 / 22.9 us); below about 150 such tiles the 64 x 64 tiles win (2400 x 256 x 512: 9.4 against
         // 11.6 us; 1600 x 512 x 1536, three taps: 26.5 against 28.7 us)
         tile = (a.N >= 128 && n8 >= 144 && a.batch <= 1) ? 13 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
+        // from 512 columns up, eight waves sharing the staged A rows (64 x 256 tiles, id 14) once there are two rounds of those:
+        // 19200 x 512 x 768, three taps: 54.5 against 57.0 us; 19200 x 1024 x 512: 67.4 / 70.3; 19200 x 512 x 1536, three taps:
+        // 99 / 104; with fewer tiles id 13 wins (9600 x 512 x 768, three taps: 31.4 against 33.6 us; 3200 x 512 x 2048: 32 / 42)
+        if (tile == 13 && a.N >= 512 && mt * ((a.N + 255) / 256) >= 512) tile = 14;
     }
+    static const bool equal_tiles = [] { const char* e = getenv("ESTTS_GEMM_EQUAL_TILES"); return e && atoi(e) != 0; }();   // (measurements)
+    if (equal_tiles) a.tune |= 1 << 26;
     if (a.stat_slots) {
         ESTTS_CHECK_ARG(a.batch <= 1 && !a.ln_y, "estts_gemm: stat_slots not with batch > 1 or a LayerNorm prologue");
-        if ((tile < 5 || tile > 8) && tile != 13) {   // a kernel without the summing epilogue: the product, then a pass over C
+        if ((tile < 5 || tile > 8) && tile != 13 && tile != 14) {   // a kernel without the summing epilogue: the product, then a pass over C
             ESTTS_CHECK_ARG((a.N & 3) == 0 && (a.ldc & 3) == 0, "estts_gemm: stat_slots needs N and ldc multiples of 4 at this size");
             estts_gemm_args b = *args;
             b.stat_slots = nullptr;
@@ -1182,6 +1326,24 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
             c.ws = a.stat_slots; c.ws_bytes = (int64_t)16 * 2 * ((a.N + 255) / 256) * 256 * 4;
             return estts_colreduce(&c, stream);
         }
+    }
+    if (a.ln_epilogue) {   // LayerNorm epilogue: the kernel whose workgroups own whole rows of 256 outputs
+        ESTTS_CHECK_ARG(!a.ln_y && !a.ln_out, "estts_gemm: ln_epilogue not together with a LayerNorm prologue (ln_y / ln_out)");
+        ESTTS_CHECK_ARG((!a.ln_ga == !a.ln_ba) && (!a.ln_gb == !a.ln_bb) && (a.ln_ga || a.ln_gb) && (a.ln_ga || a.ln_act == ESTTS_ACT_NONE),
+                        "estts_gemm: LayerNorm epilogue needs at least one of (ln_ga, ln_ba) / (ln_gb, ln_bb); ln_act only with the first");
+        ESTTS_CHECK_ARG(a.ln_act == ESTTS_ACT_NONE || a.ln_act == ESTTS_ACT_RELU, "estts_gemm: ln_act must be none or ReLU");
+        ESTTS_CHECK_ARG(a.N == 256 && a.batch <= 1 && !a.R && !a.s2 && a.act == ESTTS_ACT_NONE && a.alpha == 1.0f && !(a.drop_rate > 0.0f) &&
+                        !a.stat_slots && (tile == 13 || tile == 14 || (a.tune & 0xff) == 0),
+                        "estts_gemm: this launch cannot take a LayerNorm epilogue (N = 256, one product, no residual / second affine / "
+                        "activation / alpha / dropout / column moments of its own, tile 0 or 14): run estts_rownorm after it");
+        ESTTS_CHECK_ARG(((uintptr_t)a.ln_x & 15) == 0 && ((uintptr_t)a.ln_ga & 15) == 0 && ((uintptr_t)a.ln_ba & 15) == 0 &&
+                        ((uintptr_t)a.ln_gb & 15) == 0 && ((uintptr_t)a.ln_bb & 15) == 0 && ((uintptr_t)a.C & 15) == 0 && (a.ldc & 3) == 0 &&
+                        (!a.ln_x || ((a.ln_ldx & 3) == 0 && a.ln_ldx >= a.N)),
+                        "estts_gemm: LayerNorm epilogue operands and C must be 16-byte aligned with row strides >= N, multiples of 4");
+        // C may be ln_x, and the A of a dense layer, row for row (a workgroup owns whole rows and writes them after its last read);
+        // a convolution's neighbours read each other's rows
+        ESTTS_CHECK_ARG(a.C != a.A || operand_kind(a) == 1, "estts_gemm: with a LayerNorm epilogue C may alias A only for a dense layer");
+        return launch_wdirect<2, 8, true>(a, st);
     }
     if (a.ln_y) {   // LayerNorm prologue: only the kernel that stages a tile's source rows can compute them on the way in
         ESTTS_CHECK_ARG(a.ln_out && (!a.ln_ga == !a.ln_ba) && (!a.ln_gb == !a.ln_bb) && (a.ln_ga || a.ln_gb) &&
@@ -1243,7 +1405,10 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         case 8: return launch_big<1, 2, 3>(a, st);
         case 13:
             ESTTS_CHECK_ARG(a.batch <= 1, "estts_gemm: tile 13 takes no batch");
-            return launch_wdirect<2, 4>(a, st);
+            return launch_wdirect<4, 4, false>(a, st);
+        case 14:
+            ESTTS_CHECK_ARG(a.batch <= 1, "estts_gemm: tile 14 takes no batch");
+            return launch_wdirect<2, 8, false>(a, st);
 
         default: estts_set_error("estts_gemm: unknown tile id %d", tile); return -1;
     }

@@ -265,8 +265,21 @@ def can_fuse_ln(lin, M, N_out=None, precision='bf16x3', site=None, act=None):
     return not (tm == 32 and C > 256 and lin.K > 768)      # (that variant would not fit its registers)
 
 
+LN_EPILOGUE_MIN_ROWS = 8192     # rows from which gemm(norm=...) beats gemm() + rownorm() (64-row tiles: 128 workgroups of 512 threads)
+
+
+def can_fuse_ln_epilogue(lin, M, act=None):
+    """True when gemm(..., norm=...) can apply the LayerNorm combination that follows the layer inside its own launch
+    (estts_gemm_args.ln_epilogue) and that pays: 256 outputs, no epilogue operands of the layer's own beyond scale / bias,
+    thousands of rows, and not while a step program is being recorded.  Callers fall back to gemm() + rownorm()."""
+    if os.environ.get('ESTTS_LN_EPILOGUE', '1') == '0':      # (measurements: the two-launch form)
+        return False
+    return (lin.N == 256 and M >= LN_EPILOGUE_MIN_ROWS and lin.act == 0 and act in (None, 'linear', 'none') and lin.s2 is None
+            and _program is None)
+
+
 def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, precision='bf16x3', act=None, tune=0,
-         split=True, conv2d=None, dropout=None, batch=None, workspace=None, site=None, ln=None, stats=None):
+         split=True, conv2d=None, dropout=None, batch=None, workspace=None, site=None, ln=None, stats=None, norm=None):
     """out[:, :N] = epilogue(x[:, :K] (*) lin).  x, out, residual: 2-D float32 views (row stride arbitrary).
     dropout = (rate, seed, site, row0): keep/scale after the activation, generator row = row0 + output row.
     batch = (count, stride_a, stride_w, stride_c, stride_v): that many products of this shape in one launch; x / lin / out
@@ -278,7 +291,10 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     are LNb(act(LNa(y)) + x), computed inside the launch and also written to `out`, which is what `x` must be (see
     can_fuse_ln; rownorm() fused into the convolution that consumes it).
     stats = (slots pointer, shift [N] tensor or None): also add the column moments of the output about `shift` to the 16
-    copies at the pointer (train_ops.SumSlots.forward_region; estts_gemm_args.stat_slots), for bn_finalize(slots=...)."""
+    copies at the pointer (train_ops.SumSlots.forward_region; estts_gemm_args.stat_slots), for bn_finalize(slots=...).
+    norm = dict(ln_a=(gamma, beta) or None, act= or None, residual= or None, ln_b=(gamma, beta) or None, eps=1e-6): out =
+    LNb(act(LNa(x (*) lin)) + residual), i.e. the rownorm() that follows the layer, inside this launch (see
+    can_fuse_ln_epilogue; N = 256 only)."""
     precision = precision_at(precision, site)
     _check_f32(x, 'x'); _check_f32(out, 'out')
     M = x.shape[0] if M is None else M
@@ -327,6 +343,21 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
         a.ln_act, a.ln_eps = ACT[ln.get('act')], ln.get('eps', 1e-6)
     if stats is not None:
         a.stat_slots, a.stat_shift = stats[0], _ptr(stats[1])
+    if norm is not None:
+        if ln is not None or residual is not None or stats is not None or batch is not None or (dropout is not None and dropout[0] > 0.0):
+            raise ValueError('gemm: norm= not together with ln=, residual=, stats=, batch= or dropout=')
+        a.ln_epilogue = 1
+        xr = norm.get('residual')
+        if xr is not None:
+            _check_f32(xr, 'norm.residual')
+            a.ln_x, a.ln_ldx = xr.data_ptr(), xr.stride(0)
+        if norm.get('ln_a') is not None:
+            a.ln_ga, a.ln_ba = norm['ln_a'][0].data_ptr(), norm['ln_a'][1].data_ptr()
+        elif norm.get('ln_b') is None or norm.get('act') not in (None, 'linear', 'none'):
+            raise ValueError('gemm: norm= needs ln_a or ln_b, and an activation only with ln_a')
+        if norm.get('ln_b') is not None:
+            a.ln_gb, a.ln_bb = norm['ln_b'][0].data_ptr(), norm['ln_b'][1].data_ptr()
+        a.ln_act, a.ln_eps = ACT[norm.get('act')], norm.get('eps', 1e-6)
     if split:
         ws, cnt = workspace if workspace is not None else (_ws_override if _ws_override is not None else gemm_workspace(x.device))
         a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
@@ -344,8 +375,11 @@ def gemm(x, lin, out, M=None, seg_len=0, residual=None, r_mod=0, alpha=1.0, prec
     if ln is not None:       # another kernel (rows normalised on the way in, read twice, written once): its own line in a kernel table
         info['ln_prologue'] = True
         info['bytes'] += 4.0 * M * lin.c_per_tap * (2 if ln.get('x') is not None else 1)
+    if norm is not None:     # the rows are normalised on the way out: the same bytes as the plain layer plus the residual rows
+        info['ln_epilogue'] = True
+        info['bytes'] += 4.0 * M * lin.N if norm.get('residual') is not None else 0.0
     _record('gemm', info,
-            _lib.load().estts_gemm, a, keep=(x, out, residual, lin, ln))
+            _lib.load().estts_gemm, a, keep=(x, out, residual, lin, ln, norm))
     return out
 
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 32
+#define ESTTS_ABI_VERSION 33
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -80,8 +80,8 @@ long long estts_launch_count(void);
  * 32 x 32 (every load issued up front: dense layers and 1-D convolutions with K <= 192 x waves, K and c_per_tap multiples
  * of 8; waves 4 or 8); 11 / 12 the same for convolutions with the tile's source rows staged once in LDS; 13 the 64 x 128
  * tile with W read from memory straight into the matrix instruction's registers and only A staged (what tune = 0 picks
- * for thousands of rows; results identical to id 8; no batch, no split-K).  An explicit id outside its kernel's envelope is
- * an error; tune = 0 never fails on shape.
+ * for thousands of rows; results identical to id 8; no batch, no split-K); 14 the same kernel with eight waves and 64 x 256
+ * tiles (what ln_epilogue runs on).  An explicit id outside its kernel's envelope is an error; tune = 0 never fails on shape.
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_gemm_args {
     const float* A;
@@ -146,6 +146,14 @@ typedef struct estts_gemm_args {
      * The large-M tiles (5..8) sum inside their epilogue; any other kernel is followed by a reduction pass over C
      * (same result layout).  Not with batch > 1 or a LayerNorm prologue. */
     float* stat_slots; const float* stat_shift;
+    /* LayerNorm epilogue (ln_epilogue != 0; ln_y and ln_out NULL): C = LNb( act_ln( LNa(acc * s1 + b1) ) + ln_x ) with the
+     * ln_* fields above read as in the prologue form -- estts_rownorm fused into the layer that PRODUCES its input (the
+     * output projections of SelfAttentionResNorm / CrossAttentionResnorm and the folded FFNResNorm product at batch size,
+     * TransformerTTS/model/layers.py:65-71, 163-168, 270-274), which saves writing and re-reading the un-normalised rows.
+     * Needs N = 256 (a workgroup of the 64 x 256 tile owns whole rows), one product, and none of R / s2 / act / alpha /
+     * dropout / stat_slots; it pays from a few hundred row tiles up (the caller decides: estts_gemm does what it is told or
+     * fails with an error).  C may be ln_x, and for a dense layer A, row for row. */
+    int32_t ln_epilogue;
 } estts_gemm_args;
 
 int estts_gemm(const estts_gemm_args* args, void* stream);

@@ -236,6 +236,99 @@ def test_gemm_large_tiles_agree_with_the_ring_kernel_on_random_shapes():
     assert checked == 400
 
 
+def test_gemm_large_tiles_id_14_agrees_with_id_13():
+    # eight waves side by side (64 x 256 tiles): the arithmetic of tile 13 in the same order, on shapes with partial row and
+    # column tiles, K tails, convolutions across sequence boundaries, and every epilogue operand
+    rng = np.random.default_rng(12)
+    for case in range(24):
+        taps = int(rng.choice([1, 1, 3, 5]))
+        cin = 4 * int(rng.integers(1, 80 if taps == 1 else 40))
+        K = taps * cin
+        B, T = int(rng.integers(1, 5)), int(rng.integers(1, 200))
+        N = int(rng.choice([256, 256, 512, 300, 100, 37]))
+        lpad = int(rng.integers(0, taps))
+        M = B * T
+        x = _rand(M, cin, seed=16000 + case).to(DEV)
+        w = _rand(N, K, seed=17000 + case, scale=1 / math.sqrt(K))
+        lin = PackedLinear(w.numpy(), bias=_rand(N, seed=18000 + case).numpy(), scale=(_rand(N, seed=19000 + case).abs() + 0.5).numpy(),
+                           device=DEV, taps=taps, lpad=lpad, act='relu')
+        res = _rand(M, N, seed=20000 + case).to(DEV)
+        outs = []
+        for tune in (13, 14):
+            out = torch.full((M, N + 4), float('nan'), device=DEV)
+            ops.gemm(x, lin, out[:, :N], seg_len=T, residual=res, alpha=0.7, precision='bf16x3', tune=tune)
+            assert torch.isnan(out[:, N:]).all()
+            outs.append(out[:, :N].clone())
+        assert torch.isfinite(outs[0]).all()
+        assert torch.equal(outs[0], outs[1]), (case, M, N, K, taps, lpad, T)
+    # launches of more tiles than CUs whose last round would be at most half full send that round's rows out as 32-row tiles
+    # behind the 64-row ones (tune bit 26 turns that off): same values wherever a row lands, ragged ends included
+    for case, (M, N, cin, taps, T) in enumerate([(19200, 256, 512, 1, 600), (19203, 256, 64, 3, 6401), (17000, 384, 96, 1, 17000),
+                                                  (16640, 256, 128, 1, 16640), (33000, 100, 32, 5, 1100), (9000, 512, 64, 1, 9000)]):
+        K = taps * cin
+        x = _rand(M, cin, seed=30000 + case).to(DEV)
+        lin = PackedLinear(_rand(N, K, seed=31000 + case, scale=1 / math.sqrt(K)).numpy(), bias=_rand(N, seed=32000 + case).numpy(),
+                           device=DEV, taps=taps, lpad=(taps - 1) // 2, act='relu')
+        res = _rand(M, N, seed=33000 + case).to(DEV)
+        outs = []
+        for tune in (13 | (1 << 26), 13, 14 | (1 << 26), 14):
+            out = torch.full((M + 1, N + 4), float('nan'), device=DEV)
+            ops.gemm(x, lin, out[:M, :N], seg_len=T, residual=res, precision='bf16x3', tune=tune)
+            assert torch.isnan(out[:, N:]).all() and torch.isnan(out[M:]).all()
+            outs.append(out[:M, :N].clone())
+        assert torch.isfinite(outs[0]).all()
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (case, M, N, K, taps)
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_gemm_layernorm_epilogue_is_gemm_then_rownorm(precision):
+    # estts_gemm_args.ln_epilogue: the rownorm() that follows a 256-output layer inside the layer's launch -- the three
+    # combinations the transformer blocks use (layers.py:65-71 FFNResNorm, :163-168 SelfAttentionResNorm, :270-274
+    # CrossAttentionResnorm) and a single norm, on dense layers and a convolution, row counts that end inside a 64-row tile, padded
+    # row strides, the output aliasing the residual.  Same products in the same order and the same row arithmetic as
+    # rownorm_fast_kernel: equal up to the contraction of multiply-adds (1e-6 of the largest value).
+    N = 256
+    cases = [  # (B, T, cin, taps, lpad, ln_a, act, residual, ln_b)
+        (1, 64, 512, 1, 0, True, None, True, True),
+        (2, 100, 256, 1, 0, True, 'relu', True, True),
+        (3, 211, 512, 1, 0, False, None, True, True),
+        (1, 1000, 96, 1, 0, True, 'relu', False, False),
+        (2, 150, 64, 3, 1, True, None, True, True),
+        (32, 600, 512, 1, 0, True, None, True, True),     # 300 row tiles: 256 of 64 rows and 88 of 32
+        (1, 16999, 64, 1, 0, True, 'relu', True, True),    # ... ending inside a 32-row tile
+        (3, 6000, 32, 3, 1, False, None, True, True),
+        (1, 1, 256, 1, 0, False, None, True, True),
+    ]
+    for idx, (B, T, cin, taps, lpad, use_a, act, use_res, use_b) in enumerate(cases):
+        M, K = B * T, taps * cin
+        x = _rand(M, cin + 4, seed=21000 + idx).to(DEV)
+        w = _rand(N, K, seed=22000 + idx, scale=1 / math.sqrt(K))
+        lin = PackedLinear(w.numpy(), bias=_rand(N, seed=23000 + idx).numpy(), device=DEV, taps=taps, lpad=lpad)
+        ln_a = ((_rand(N, seed=24000 + idx).abs() + 0.5).to(DEV), _rand(N, seed=25000 + idx).to(DEV)) if use_a else None
+        ln_b = ((_rand(N, seed=26000 + idx).abs() + 0.5).to(DEV), _rand(N, seed=27000 + idx).to(DEV)) if use_b else None
+        res = _rand(M, N + 8, seed=28000 + idx).to(DEV) if use_res else None
+        y = torch.empty(M, N, device=DEV)
+        want = torch.empty(M, N, device=DEV)
+        ops.gemm(x[:, :cin], lin, y, seg_len=T, precision=precision, tune=13)
+        ops.rownorm(y, want, ln_a=ln_a, act=act, residual=None if res is None else res[:, :N], ln_b=ln_b)
+        got = torch.full((M + 3, N + 4), float('nan'), device=DEV)
+        ops.gemm(x[:, :cin], lin, got[:M, :N], seg_len=T, precision=precision,
+                 norm=dict(ln_a=ln_a, act=act, residual=None if res is None else res[:, :N], ln_b=ln_b))
+        assert torch.isnan(got[M:]).all() and torch.isnan(got[:, N:]).all()
+        assert torch.isfinite(want).all()
+        err = (got[:M, :N] - want).abs().max().item() / want.abs().max().item()
+        assert err < 1e-6, (idx, precision, err)
+        if use_res:   # in place over the residual rows, as a block that overwrites its input would
+            r2 = res[:, :N].clone()
+            ops.gemm(x[:, :cin], lin, r2, seg_len=T, precision=precision, norm=dict(ln_a=ln_a, act=act, residual=r2, ln_b=ln_b))
+            assert torch.equal(r2, got[:M, :N]), idx
+    # what the launch cannot do is an error, not a silent fallback
+    lin = PackedLinear(_rand(128, 64, seed=1).numpy(), device=DEV)
+    with pytest.raises(RuntimeError, match='LayerNorm epilogue'):
+        ops.gemm(_rand(64, 64, seed=2).to(DEV), lin, torch.empty(64, 128, device=DEV), norm=dict(ln_b=(torch.ones(128, device=DEV), torch.zeros(128, device=DEV))))
+
+
 @pytest.mark.parametrize('B,T,cin,taps,lpad,N', [(1, 100, 512, 3, 1, 512), (1, 600, 256, 3, 1, 512), (3, 23, 96, 5, 2, 72),
                                                 (2, 37, 264, 2, 1, 40), (4, 150, 256, 3, 2, 256)])
 @pytest.mark.parametrize('form', ['double', 'single_relu', 'residual_only_a'])

@@ -55,7 +55,7 @@ def test_struct_sizes_match_header_layout(tmp_path):
     sizes = dict(line.split() for line in out.strip().splitlines())
     for name, cls in pairs.items():
         assert ctypes.sizeof(cls) == int(sizes[name]), name
-    assert ctypes.sizeof(_lib.GemmArgs) == 352
+    assert ctypes.sizeof(_lib.GemmArgs) == 360
 
 
 def test_deferred_sum_arguments_are_validated_before_any_launch():

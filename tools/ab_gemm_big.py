@@ -25,9 +25,14 @@ SMALL = [(4800, 256, 512, 1), (4800, 256, 1536, 3), (4800, 512, 768, 3), (4800, 
          (3200, 512, 512, 1), (2400, 256, 512, 1), (1200, 256, 512, 1), (2400, 512, 768, 3), (1600, 512, 1536, 3), (9600, 256, 512, 1)]
 
 
+WIDE = [(19200, 512, 768, 3), (19200, 1024, 512, 1), (19200, 768, 256, 1), (19200, 512, 512, 1), (19200, 512, 1536, 3), (9600, 512, 768, 3),
+        (9600, 1024, 512, 1), (9600, 768, 256, 1), (4800, 512, 768, 3), (4800, 1024, 256, 1), (4800, 768, 256, 1), (3200, 512, 1536, 3),
+        (3200, 1536, 512, 1), (3200, 2048, 512, 1), (3200, 512, 2048, 1), (3200, 512, 512, 1), (6400, 512, 1536, 3), (6400, 1536, 512, 1)]
+
+
 def main():
     g = torch.Generator().manual_seed(0)
-    for M, N, K, taps in (SMALL if os.environ.get('AB_SMALL') else SHAPES):
+    for M, N, K, taps in (SMALL if os.environ.get('AB_SMALL') else WIDE if os.environ.get('AB_WIDE') else SHAPES):
         cin = K // taps
         x = torch.randn(M, cin, generator=g).cuda()
         w = torch.randn(N, K, generator=g) / math.sqrt(K)
