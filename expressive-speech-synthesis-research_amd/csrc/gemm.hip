@@ -826,24 +826,29 @@ namespace {
 // NWV = 8: eight waves side by side, a workgroup owns 64 rows x 256 columns (id 14).  LNE (NWV = 8, N = 256: the workgroup
 // owns whole rows): the epilogue is estts_rownorm, C = LNb(act_ln(LNa(acc s1 + b1)) + ln_x) -- the tile goes through LDS (in the
 // place of the A images) so that a wave normalises whole rows exactly as rownorm_fast_kernel does, and writes them as float4.
-template <int NSPLIT, int TM, int NWV, bool LNE>
+template <int NSPLIT, int TM, int NWV, bool LNE, int KG = 1>
 constexpr int wdirect_smem_bytes() {
-    constexpr int a_bytes = 2 * ((NSPLIT > 1) ? 2 : 1) * 32 * TM * BG_LD * 2;      // two buffers of the hi (+ lo) A images
+    constexpr int a_bytes = KG * 2 * ((NSPLIT > 1) ? 2 : 1) * 32 * TM * BG_LD * 2;  // per K group: two buffers of the hi (+ lo) A images
     constexpr int t_bytes = LNE ? 32 * TM * (32 * NWV + 4) * 4 : 0;                // the epilogue's float32 tile
     return a_bytes > t_bytes ? a_bytes : t_bytes;
 }
 
 // the tile with first row m0 and first column n0; smem: wdirect_smem_bytes() of LDS
-template <int NSPLIT, int TM, int KIND, int NWV, bool LNE>
+// KG = 2 (id 15; TM = 2, K a multiple of 64): two groups of NWV waves take the two halves of K for the same tile, each staging
+// its own A images, and exchange halves of their accumulators through LDS at the end (group g finishes rows 32 g .. 32 g + 31).
+// For launches with at most one tile per CU, where a K loop runs at the latency of its own steps: half as many steps.
+template <int NSPLIT, int TM, int KIND, int NWV, bool LNE, int KG = 1>
 __device__ __forceinline__ void wdirect_tile(const estts_gemm_args& p, unsigned char* smem, const int m0, const int n0, const TileCoord tc) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
     constexpr int BM = 32 * TM, BN = 32 * NWV;   // TM = 2 (or 4: 128 rows, half the W loads per matrix instruction)
     constexpr int RP = 8 * NWV;  // rows the workgroup's threads cover with one float4 each
     constexpr int AI = (BM + RP - 1) / RP;  // float4 loads of A per thread and K-step
     constexpr int T_LD = BN + 4;                           // floats per row of the epilogue's tile
-    __bf16 (*As)[NS][BM * BG_LD] = reinterpret_cast<__bf16 (*)[NS][BM * BG_LD]>(smem);
+    static_assert(KG == 1 || (KG == 2 && TM == 2 && !LNE), "two K groups: 64-row tiles, plain epilogue");
+    const int kg = KG > 1 ? (int)threadIdx.x / (64 * NWV) : 0;     // K group of this wave (uniform per wave)
+    __bf16 (*As)[NS][BM * BG_LD] = reinterpret_cast<__bf16 (*)[NS][BM * BG_LD]>(smem) + 2 * kg;
 
-    const int tid = threadIdx.x;
+    const int tid = KG > 1 ? (int)threadIdx.x % (64 * NWV) : (int)threadIdx.x;   // thread within the K group
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -863,14 +868,16 @@ __device__ __forceinline__ void wdirect_tile(const estts_gemm_args& p, unsigned 
         else if (KIND == 2) { a_ptr[i] = p.A + (long)row * p.lda; a_pos[i] = row % p.conv_w; }
         else a_row[i] = make_arow(p, m0 + a_r0 + RP * i);
     }
-    KCursor kcur = make_kcursor(p, a_ch * 4);   // load_a is called for kt = 0, 1, 2, ... in order
+    const int nk = (p.K + 31) / 32 / KG;        // K-steps of this group: kt0 .. kt0 + nk - 1
+    const int kt0 = kg * nk;
+    KCursor kcur = make_kcursor(p, kt0 * 32 + a_ch * 4);   // load_a is called for kt = 0, 1, 2, ... in order
     auto load_a = [&](float4 (&ga)[AI], bool (&gok)[AI], int kt) {
         if constexpr (BM < RP) { if (a_r0 >= BM) return; }
         if (KIND == 1) {
-            const bool ok = kt * 32 + a_ch * 4 < p.K;
+            const bool ok = (kt0 + kt) * 32 + a_ch * 4 < p.K;
 #pragma unroll
             for (int i = 0; i < AI; ++i) {
-                ga[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? kt * 32 : -a_ch * 4));
+                ga[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (ok ? (kt0 + kt) * 32 : -a_ch * 4));
                 gok[i] = ok;
             }
         } else if (KIND == 2) {
@@ -909,7 +916,7 @@ __device__ __forceinline__ void wdirect_tile(const estts_gemm_args& p, unsigned 
     const int w_nb = min((n0 >> 4) + wave * 2 + (r >> 4), nb_end - 1);
     const long w_lane = (long)w_nb * KS * 512 + ((r & 15) + 16 * h) * 8;
     auto load_w = [&](bf16x8 (&wf)[NS][2], int kt) {
-        const long o = w_lane + (long)kt * 512;
+        const long o = w_lane + (long)(kt0 + kt) * 512;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             wf[0][q] = *reinterpret_cast<const bf16x8*>(p.W_hi + o + q * 32 * 8);
@@ -923,7 +930,6 @@ __device__ __forceinline__ void wdirect_tile(const estts_gemm_args& p, unsigned 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.0f;
 
-    const int nk = (p.K + 31) / 32;
     const int a_base = r * BG_LD + 8 * h;
     auto multiply = [&](int buf, const bf16x8 (&wf)[NS][2]) {
 #pragma unroll
@@ -1079,6 +1085,22 @@ __device__ __forceinline__ void wdirect_tile(const estts_gemm_args& p, unsigned 
 #pragma unroll
         for (int q = 0; q < RW; ++q)
             if (row0 + q < p.M) *reinterpret_cast<float4*>(p.C + (long)(row0 + q) * p.ldc + c) = v[q];
+    } else if constexpr (KG == 2) {
+        __syncthreads();   // every wave is past its last fragment read: the A images make room for the exchange
+        float* X = reinterpret_cast<float*>(smem);   // [group][wave][16][64]: the half the other group finishes
+        {
+            float* mine = X + ((kg * NWV + wave) * 16) * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mine[e * 64] = kg == 0 ? acc[1][0][e] : acc[0][0][e];
+        }
+        __syncthreads();
+        f32x16 half[1][1];
+        {
+            const float* theirs = X + (((1 - kg) * NWV + wave) * 16) * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) half[0][0][e] = (kg == 0 ? acc[0][0][e] : acc[1][0][e]) + theirs[e * 64];
+        }
+        big_epilogue<1, 1>(p, half, m0 + 32 * kg, n0, 0, wave, r, h, tc);
     } else {
         big_epilogue<TM, 1>(p, acc, m0, n0, 0, wave, r, h, tc);
     }
@@ -1105,6 +1127,14 @@ __device__ __forceinline__ TileCoord region_tile_coord(int id, const int gx, con
 // 32 (rows gy_big * 64 and up).  Workgroups of one launch are all resident at these sizes, so a launch takes as long as its
 // busiest CU: 19 200 x 256 as 600 equal tiles of 64 x 128 puts three tiles on 88 CUs and two on the others; as 512 + 176 the
 // busiest CU has two and a half.
+// id 15: 64 x 128 tiles, eight waves: two groups of four take the halves of K
+template <int NSPLIT, int KIND>
+__global__ __launch_bounds__(512, 2) void gemm_wdirect_k2_kernel(const estts_gemm_args p_in) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[wdirect_smem_bytes<NSPLIT, 2, 4, false, 2>()];
+    const TileCoord tc = xcd_tile_coord((p_in.tune & (1 << 25)) ? false : gemm_y_first(p_in), !(p_in.tune & (1 << 24)));
+    wdirect_tile<NSPLIT, 2, KIND, 4, false, 2>(p_in, smem, tc.ty * 64, tc.tx * 128, tc);
+}
+
 template <int NSPLIT, int OCC, int KIND, int NWV = 4, bool LNE = false>
 __global__ __launch_bounds__(64 * NWV, OCC) void gemm_wdirect_kernel(const estts_gemm_args p_in, const int n_big, const int gy_big, const int gy_small) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[wdirect_smem_bytes<NSPLIT, 2, NWV, LNE>()];
@@ -1241,6 +1271,22 @@ int launch_wdirect_d(const estts_gemm_args& a, hipStream_t st) {
     return 0;
 }
 
+template <int KIND>
+int launch_wdirect_k2_d(const estts_gemm_args& a, hipStream_t st) {
+    dim3 grid((a.N + 127) / 128, (a.M + 63) / 64, 1);
+    if (a.precision == 3)
+        ESTTS_LAUNCH((gemm_wdirect_k2_kernel<3, KIND>), grid, dim3(512), 0, st, a);
+    else
+        ESTTS_LAUNCH((gemm_wdirect_k2_kernel<1, KIND>), grid, dim3(512), 0, st, a);
+    ESTTS_CHECK_LAUNCH("estts_gemm");
+    return 0;
+}
+
+int launch_wdirect_k2(const estts_gemm_args& a, hipStream_t st) {
+    const int kind = operand_kind(a);
+    return kind == 1 ? launch_wdirect_k2_d<1>(a, st) : kind == 2 ? launch_wdirect_k2_d<2>(a, st) : launch_wdirect_k2_d<0>(a, st);
+}
+
 template <int OCC, int NWV, bool LNE>
 int launch_wdirect(const estts_gemm_args& a, hipStream_t st) {
     const int kind = operand_kind(a);
@@ -1295,26 +1341,44 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
     int splitk = (a.tune >> 8) & 0xff;
     if (tile == 0) {
         // measured on MI355X (tools/ab_gemm_big.py, tools/tune_gemm_big.py, tools/tune_wavernn_gemm.py): the LDS-staged kernels win
-        // once their workgroups fill the chip -- as 64 x 128 tiles when there are enough of those, else as 64 x 64 tiles --
+        // once their workgroups fill most of the chip -- as 64 x 128 tiles when there are enough of those, else as 64 x 64 tiles --
         // and below that the barrier-free 32 x 32 kernel does.  The 128 x 128, 128 x 64 and LDS-staged 64 x 128 shapes (ids 5, 7,
         // 8) and the older 64 x 64 kernels (ids 1-3) never win at these sizes and are kept for explicit selection only.
         const long mt = (long)((a.M + 63) / 64) * (a.batch > 1 ? a.batch : 1);
         const long n8 = mt * ((a.N + 127) / 128), n6 = mt * ((a.N + 63) / 64);
-        // 64 x 128 tiles run on the W-from-memory kernel (id 13: 19200 x 256 x 512 24.2 us against 27.3 as 64 x 64 tiles;
-        // 19200 x 256 x 1536, three taps: 58 / 75 us; 19200 x 1024 x 512: 68 / 85 us; 4800 x 256 x 512: 11.5 / 13.1 us;
-        // 3200 x 512 x 1024: 19.2 / 22.9 us); below about 150 such tiles the 64 x 64 tiles win (2400 x 256 x 512: 9.4 against
-        // 11.6 us; 1600 x 512 x 1536, three taps: 26.5 against 28.7 us)
-        tile = (a.N >= 128 && n8 >= 144 && a.batch <= 1) ? 13 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
-        // from 512 columns up, eight waves sharing the staged A rows (64 x 256 tiles, id 14) once there are two rounds of those:
-        // 19200 x 512 x 768, three taps: 54.5 against 57.0 us; 19200 x 1024 x 512: 67.4 / 70.3; 19200 x 512 x 1536, three taps:
-        // 99 / 104; with fewer tiles id 13 wins (9600 x 512 x 768, three taps: 31.4 against 33.6 us; 3200 x 512 x 2048: 32 / 42)
-        if (tile == 13 && a.N >= 512 && mt * ((a.N + 255) / 256) >= 512) tile = 14;
+        const bool k2_ok = (a.K & 63) == 0 && a.K >= 256 && a.N >= 128;   // what id 15 needs
+        if (a.batch > 1) {
+            tile = 6;
+        } else if (a.N >= 128 && n8 >= 144) {
+            // 64 x 128 tiles run on the W-from-memory kernel (id 13: 19200 x 256 x 512 21.7 us against 27.3 as 64 x 64 tiles;
+            // 19200 x 256 x 1536, three taps: 52 / 75 us; 4800 x 256 x 512: 11.5 / 13.1 us; 3200 x 512 x 1024: 19.2 / 22.9 us)
+            tile = 13;
+            // at most one tile per CU: two groups of waves on the halves of K (id 15: 3200 x 512 x 1536, three taps: 24.5 against
+            // 29.5 us; 2400 x 512 x 512: 10.9 / 12.5; 1600 x 768 x 256: 7.8 / 7.9; with more tiles id 13 wins: 3200 x 768 x 1536,
+            // three taps, 300 tiles: 33.5 against 38.4 us)
+            if (n8 <= 256 && k2_ok) tile = 15;
+            // from 512 columns up, eight waves sharing the staged A rows (64 x 256 tiles, id 14) once there are two rounds of those:
+            // 19200 x 512 x 768, three taps: 54.5 against 57.0 us; 19200 x 1024 x 512: 67.4 / 70.3; 19200 x 512 x 1536, three taps:
+            // 99 / 104; with fewer tiles id 13 wins (9600 x 512 x 768, three taps: 31.4 against 33.6 us; 3200 x 512 x 2048: 32 / 42)
+            else if (a.N >= 512 && mt * ((a.N + 255) / 256) >= 512) tile = 14;
+        } else if (n6 >= 144) {
+            // fewer 64 x 128 tiles than that: 64 x 64 tiles (id 6: 3200 x 256 x 512 9.8 us against 13.3 on 32 x 32 tiles and 10.6 as
+            // id 13; 1600 x 512 x 256: 6.9 / 10.2 / 7.5; 832 x 768 x 256: 6.7 / 9.1 / 7.3), long K on id 15 (1600 x 512 x 1536,
+            // three taps: 22.1 against 26.5 (id 6) and 27.6 us; 2400 x 256 x 1536: 21.6 / 25.5 / 22.8); below 144 of them the
+            // 32 x 32 kernels win everywhere (1600 x 256 x 512: 8.1 against 9.1 us; 832 x 512 x 1536, three taps: 15.3 / 25.0)
+            tile = (a.K >= 1024 && k2_ok) ? 15 : 6;
+        } else {
+            tile = 4;
+        }
+        // (measurements: the rule these replaced -- ids 13 / 6 / 4 by tile counts alone)
+        static const bool old_rule = [] { const char* e = getenv("ESTTS_GEMM_OLD_RULE"); return e && atoi(e) != 0; }();
+        if (old_rule) tile = (a.N >= 128 && n8 >= 144 && a.batch <= 1) ? 13 : ((n6 >= 288 || a.batch > 1) ? 6 : 4);
     }
     static const bool equal_tiles = [] { const char* e = getenv("ESTTS_GEMM_EQUAL_TILES"); return e && atoi(e) != 0; }();   // (measurements)
     if (equal_tiles) a.tune |= 1 << 26;
     if (a.stat_slots) {
         ESTTS_CHECK_ARG(a.batch <= 1 && !a.ln_y, "estts_gemm: stat_slots not with batch > 1 or a LayerNorm prologue");
-        if ((tile < 5 || tile > 8) && tile != 13 && tile != 14) {   // a kernel without the summing epilogue: the product, then a pass over C
+        if ((tile < 5 || tile > 8) && (tile < 13 || tile > 15)) {   // a kernel without the summing epilogue: the product, then a pass over C
             ESTTS_CHECK_ARG((a.N & 3) == 0 && (a.ldc & 3) == 0, "estts_gemm: stat_slots needs N and ldc multiples of 4 at this size");
             estts_gemm_args b = *args;
             b.stat_slots = nullptr;
@@ -1409,6 +1473,9 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         case 14:
             ESTTS_CHECK_ARG(a.batch <= 1, "estts_gemm: tile 14 takes no batch");
             return launch_wdirect<2, 8, false>(a, st);
+        case 15:
+            ESTTS_CHECK_ARG(a.batch <= 1 && (a.K & 63) == 0, "estts_gemm: tile 15 takes no batch and needs K a multiple of 64");
+            return launch_wdirect_k2(a, st);
 
         default: estts_set_error("estts_gemm: unknown tile id %d", tile); return -1;
     }

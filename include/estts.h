@@ -81,7 +81,10 @@ long long estts_launch_count(void);
  * of 8; waves 4 or 8); 11 / 12 the same for convolutions with the tile's source rows staged once in LDS; 13 the 64 x 128
  * tile with W read from memory straight into the matrix instruction's registers and only A staged (what tune = 0 picks
  * for thousands of rows; results identical to id 8; no batch, no split-K); 14 the same kernel with eight waves and 64 x 256
- * tiles (what ln_epilogue runs on).  An explicit id outside its kernel's envelope is an error; tune = 0 never fails on shape.
+ * tiles (what ln_epilogue runs on; tune = 0 picks it from 512 columns up); 15 the 64 x 128 tile with eight waves, two groups
+ * of four on the two halves of K (K a multiple of 64; for launches of at most one tile per CU).  Launches of ids 13 / 14 with
+ * more tiles than CUs send the rows of a last round that would be at most half full out as 32-row tiles (bit 26 of tune:
+ * equal tiles only).  An explicit id outside its kernel's envelope is an error; tune = 0 never fails on shape.
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_gemm_args {
     const float* A;

@@ -281,6 +281,37 @@ def test_gemm_large_tiles_id_14_agrees_with_id_13():
             assert torch.equal(outs[0], o), (case, M, N, K, taps)
 
 
+def test_gemm_two_k_groups_id_15_agrees_with_id_13():
+    # 64 x 128 tiles whose eight waves take the two halves of K in two groups and add their accumulators up at the end: the
+    # products of tile 13 in another order of summation (2e-6 of the largest value), with partial tiles, every epilogue operand,
+    # convolutions across sequence boundaries, K from 64 (one step per group) up; K not a multiple of 64 is an error
+    rng = np.random.default_rng(13)
+    for case in range(24):
+        taps = int(rng.choice([1, 1, 3, 5]))
+        cin = 64 * int(rng.integers(1, 9)) if taps == 1 else 64 * int(rng.integers(1, 4))
+        K = taps * cin
+        B, T = int(rng.integers(1, 5)), int(rng.integers(1, 200))
+        N = int(rng.choice([256, 512, 300, 100, 37, 128]))
+        lpad = int(rng.integers(0, taps))
+        M = B * T
+        x = _rand(M, cin, seed=40000 + case).to(DEV)
+        lin = PackedLinear(_rand(N, K, seed=41000 + case, scale=1 / math.sqrt(K)).numpy(), bias=_rand(N, seed=42000 + case).numpy(),
+                           scale=(_rand(N, seed=43000 + case).abs() + 0.5).numpy(), device=DEV, taps=taps, lpad=lpad, act='tanh')
+        res = _rand(M, N, seed=44000 + case).to(DEV)
+        outs = []
+        for tune in (13, 15):
+            out = torch.full((M + 1, N + 4), float('nan'), device=DEV)
+            ops.gemm(x, lin, out[:M, :N], seg_len=T, residual=res, alpha=0.7, precision='bf16x3', tune=tune)
+            assert torch.isnan(out[:, N:]).all() and torch.isnan(out[M:]).all()
+            outs.append(out[:M, :N].clone())
+        assert torch.isfinite(outs[0]).all()
+        err = ((outs[0] - outs[1]).abs().max() / outs[0].abs().max()).item()
+        assert err < 2e-6, (case, M, N, K, taps, lpad, T, err)
+    lin = PackedLinear(_rand(128, 96, seed=1).numpy(), device=DEV)
+    with pytest.raises(RuntimeError, match='multiple of 64'):
+        ops.gemm(_rand(64, 96, seed=2).to(DEV), lin, torch.empty(64, 128, device=DEV), tune=15)
+
+
 @pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
 def test_gemm_layernorm_epilogue_is_gemm_then_rownorm(precision):
     # estts_gemm_args.ln_epilogue: the rownorm() that follows a 256-output layer inside the layer's launch -- the three

@@ -30,9 +30,17 @@ WIDE = [(19200, 512, 768, 3), (19200, 1024, 512, 1), (19200, 768, 256, 1), (1920
         (3200, 1536, 512, 1), (3200, 2048, 512, 1), (3200, 512, 2048, 1), (3200, 512, 512, 1), (6400, 512, 1536, 3), (6400, 1536, 512, 1)]
 
 
+MID = [(3200, 512, 1536, 3), (3200, 512, 1024, 1), (3200, 512, 1536, 1), (3200, 512, 512, 1), (3200, 256, 512, 1), (3200, 768, 256, 1),
+       (3200, 1536, 512, 1), (4800, 256, 512, 1), (4800, 256, 1536, 3), (4800, 512, 768, 3), (2400, 256, 512, 1), (2400, 512, 1536, 3),
+       (1600, 512, 1536, 3), (6400, 512, 1536, 3), (6400, 256, 512, 1), (9600, 256, 512, 1), (800, 512, 1536, 3), (3200, 256, 256, 1)]
+
+
+GRID = [(M, N, K, t) for M in (600, 832, 1200, 1600, 2400, 3200) for N in (256, 512, 768, 1536) for K, t in ((256, 1), (512, 1), (1536, 3))]
+
+
 def main():
     g = torch.Generator().manual_seed(0)
-    for M, N, K, taps in (SMALL if os.environ.get('AB_SMALL') else WIDE if os.environ.get('AB_WIDE') else SHAPES):
+    for M, N, K, taps in (SMALL if os.environ.get('AB_SMALL') else WIDE if os.environ.get('AB_WIDE') else MID if os.environ.get('AB_MID') else GRID if os.environ.get('AB_GRID') else SHAPES):
         cin = K // taps
         x = torch.randn(M, cin, generator=g).cuda()
         w = torch.randn(N, K, generator=g) / math.sqrt(K)
