@@ -19,13 +19,22 @@ CSRC = os.path.join(ROOT, 'expressive-speech-synthesis-research_amd', 'csrc')
 # instantiation serves several shapes])
 KERNELS = {
     'gemm {"M": 19200, "N": 256, "K": 512, "taps": 1}': (
-        'gemm_wdirect_kernel<3, 2, 4, 1>',
-        ' (config 3: the 19200 x 256 x 512 dense layers -- attention output projections over [x | ctx] and the cross-attention'
-        ' key / value projections; 64 x 128 tiles, W from memory, 600 workgroups)', 153600),
+        'gemm_wdirect_kernel<3, 4, 1, 4, false>',
+        ' (the 19200 x 256 x 512 dense layers without a norm behind them -- config 3: the cross-attention key / value projections;'
+        ' config 5: the output projections -- 64 x 128 tiles, W from memory, 512 workgroups of 64 rows + 176 of 32)', 176128),
     'gemm {"M": 19200, "N": 256, "K": 256, "taps": 1}': (
-        'gemm_wdirect_kernel<3, 2, 4, 1>',
-        ' (config 3: the 19200 x 256 x 256 dense layers run the same instantiation on the same grid as the 19200 x 256 x 512 ones,'
-        ' 600 workgroups; the counters cannot tell the two apart, this is the mean over both: K = 256 reads 19.7 MB less of A)', 153600),
+        'gemm_wdirect_kernel<3, 4, 1, 4, false>',
+        ' (the 19200 x 256 x 256 dense layers run the same instantiation on the same grid as the 19200 x 256 x 512 ones; the'
+        ' counters cannot tell the two apart, this is the mean over both: K = 256 reads 19.7 MB less of A)', 176128),
+    'gemm {"M": 19200, "N": 256, "K": 512, "taps": 1, "ln_epilogue": true}': (
+        'gemm_wdirect_kernel<3, 2, 1, 8, true>',
+        ' (config 3: the attention output projections over [x | ctx] with the LayerNorm combination that follows them in the'
+        ' epilogue; 64 x 256 tiles of eight waves, W from memory, 256 workgroups of 64 rows + 88 of 32; the counters cannot tell'
+        ' K = 512 from the folded FFN product with K = 256 on the same grid, this is the mean over both)', 176128),
+    'gemm {"M": 19200, "N": 256, "K": 256, "taps": 1, "ln_epilogue": true}': (
+        'gemm_wdirect_kernel<3, 2, 1, 8, true>',
+        ' (config 3: the folded FFN product with its LayerNorm combination in the epilogue; same instantiation and grid as the'
+        ' K = 512 output projections, this is the mean over both)', 176128),
     'attention_bwd {"B": 32, "H": 4, "Lq": 600, "Lk": 600, "depth": 64}': (
         'attention_bwd_wide_kernel',
         ' (config 5: one of the two passes -- owning queries, owning keys -- of the decoder self-attention backward, 600 x 600,'
