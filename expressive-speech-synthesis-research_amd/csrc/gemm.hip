@@ -1349,7 +1349,8 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
         const bool k2_ok = (a.K & 63) == 0 && a.K >= 256 && a.N >= 128;   // what id 15 needs
         if (a.batch > 1) {
             tile = 6;
-        } else if (a.N >= 128 && n8 >= 144) {
+        } else if (a.N > 64 && n8 >= 144) {   // (also with a partly empty second half of the 128 columns: 19200 x 80 x 1280, five
+                                              // taps: 29.6 us against 38.6 as 64 x 64 tiles; 19200 x 112 x 1280: 29.6 / 40.2)
             // 64 x 128 tiles run on the W-from-memory kernel (id 13: 19200 x 256 x 512 21.7 us against 27.3 as 64 x 64 tiles;
             // 19200 x 256 x 1536, three taps: 52 / 75 us; 4800 x 256 x 512: 11.5 / 13.1 us; 3200 x 512 x 1024: 19.2 / 22.9 us)
             tile = 13;
@@ -1366,7 +1367,8 @@ extern "C" int estts_gemm(const estts_gemm_args* args, void* stream) {
             // id 13; 1600 x 512 x 256: 6.9 / 10.2 / 7.5; 832 x 768 x 256: 6.7 / 9.1 / 7.3), long K on id 15 (1600 x 512 x 1536,
             // three taps: 22.1 against 26.5 (id 6) and 27.6 us; 2400 x 256 x 1536: 21.6 / 25.5 / 22.8); below 144 of them the
             // 32 x 32 kernels win everywhere (1600 x 256 x 512: 8.1 against 9.1 us; 832 x 512 x 1536, three taps: 15.3 / 25.0)
-            tile = (a.K >= 1024 && k2_ok) ? 15 : 6;
+            // (long K without what id 15 needs stays on the 32 x 32 kernels: 4800 x 80 x 1280, five taps: 13.3 against 21.6 us)
+            tile = a.K >= 1024 ? (k2_ok ? 15 : 4) : 6;
         } else {
             tile = 4;
         }

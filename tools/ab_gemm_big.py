@@ -38,9 +38,13 @@ MID = [(3200, 512, 1536, 3), (3200, 512, 1024, 1), (3200, 512, 1536, 1), (3200, 
 GRID = [(M, N, K, t) for M in (600, 832, 1200, 1600, 2400, 3200) for N in (256, 512, 768, 1536) for K, t in ((256, 1), (512, 1), (1536, 3))]
 
 
+NARROW = [(19200, 80, 1280, 5), (19200, 80, 256, 1), (19200, 96, 512, 1), (19200, 112, 1280, 5), (4800, 80, 1280, 5), (19200, 64, 512, 1),
+          (24000, 64, 288, 1), (96000, 32, 288, 1)]
+
+
 def main():
     g = torch.Generator().manual_seed(0)
-    for M, N, K, taps in (SMALL if os.environ.get('AB_SMALL') else WIDE if os.environ.get('AB_WIDE') else MID if os.environ.get('AB_MID') else GRID if os.environ.get('AB_GRID') else SHAPES):
+    for M, N, K, taps in (SMALL if os.environ.get('AB_SMALL') else WIDE if os.environ.get('AB_WIDE') else MID if os.environ.get('AB_MID') else GRID if os.environ.get('AB_GRID') else NARROW if os.environ.get('AB_NARROW') else SHAPES):
         cin = K // taps
         x = torch.randn(M, cin, generator=g).cuda()
         w = torch.randn(N, K, generator=g) / math.sqrt(K)
