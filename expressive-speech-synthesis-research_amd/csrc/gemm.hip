@@ -1249,7 +1249,7 @@ int launch_big_d(const estts_gemm_args& a, hipStream_t st) {
 template <int OCC, int KIND, int NWV, bool LNE>
 int launch_wdirect_d(const estts_gemm_args& a, hipStream_t st) {
     constexpr int BN = 32 * NWV;
-    const long cus = 256;
+    const long cus = 256;   // MI355X in its single-partition mode, the one target of this library (a wrong count only costs balance)
     const long gx = (a.N + BN - 1) / BN, t64 = (a.M + 63) / 64;
     const long total = gx * t64;
     long gy_big = t64, gy_small = 0;
