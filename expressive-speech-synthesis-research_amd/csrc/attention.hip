@@ -353,8 +353,11 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const estts_attentio
 // ======================================================================================================
 // MAXT > 0: the weights are wanted and the keys fit MAXT tiles (Lk <= 32 MAXT): one sweep, the scaled scores stay in registers
 // and the weights are written after it (as in the kernel above) instead of a second sweep that recomputes them.
+// (four workgroups per CU up to depth 64: left alone the one-sweep form compiled to 156 registers -- three per CU, 1.67 rounds of
+// the 1280 workgroups of a 600-query batch of 32 -- where 122 do without a spill: 600 x 100 with weights 28.6 -> 25.8 us, causal
+// 600 x 600 46.5 -> 43.9 us)
 template <int DH, int NS, int MAXT = 0>
-__global__ __launch_bounds__(256) void attention_wide_kernel(const estts_attention_args p) {
+__global__ __launch_bounds__(256, DH <= 64 ? 4 : 1) void attention_wide_kernel(const estts_attention_args p) {
     constexpr int KS = DH / 32;
     constexpr int NT = DH / 16;
     constexpr int LD = DH + 8;
