@@ -281,6 +281,35 @@ def test_gemm_large_tiles_id_14_agrees_with_id_13():
             assert torch.equal(outs[0], o), (case, M, N, K, taps)
 
 
+def test_gemm_automatic_choice_agrees_with_the_ring_kernel_at_thousands_of_rows():
+    # tune = 0 over the sizes where it picks among ids 6 / 13 / 14 / 15 and the mixed 64- / 32-row launches (1500 .. 40000 rows,
+    # 65 .. 1100 columns, K with and without a multiple of 64, 1 / 3 / 5 taps over several sequences, residual, both affine
+    # pairs, activation) against the register-ring kernel (id 4), which the float64 tests pin
+    rng = np.random.default_rng(14)
+    for case in range(28):
+        taps = int(rng.choice([1, 1, 3, 5]))
+        cin = (64 if rng.integers(0, 2) else 4) * int(rng.integers(1, 9 if taps == 1 else 5))
+        K = taps * cin
+        B = int(rng.integers(1, 5))
+        T = int(rng.integers(1500, 40000)) // B
+        M = B * T
+        N = int(rng.choice([65, 80, 128, 200, 256, 256, 300, 512, 768, 1100]))
+        lpad = int(rng.integers(0, taps))
+        x = _rand(M, cin, seed=50000 + case).to(DEV)
+        lin = PackedLinear(_rand(N, K, seed=51000 + case, scale=1 / math.sqrt(K)).numpy(), bias=_rand(N, seed=52000 + case).numpy(),
+                           scale=(_rand(N, seed=53000 + case).abs() + 0.5).numpy(), device=DEV, taps=taps, lpad=lpad, act='relu')
+        res = _rand(M, N, seed=54000 + case).to(DEV)
+        outs = []
+        for tune in (4, 0):
+            out = torch.full((M + 1, N + 4), float('nan'), device=DEV)
+            ops.gemm(x, lin, out[:M, :N], seg_len=T, residual=res, alpha=0.7, precision='bf16x3', tune=tune)
+            assert torch.isnan(out[:, N:]).all() and torch.isnan(out[M:]).all()
+            outs.append(out[:M, :N].clone())
+        assert torch.isfinite(outs[0]).all()
+        err = ((outs[0] - outs[1]).abs().max() / outs[0].abs().max()).item()
+        assert err < 2e-5, (case, M, N, K, taps, lpad, T, err)
+
+
 def test_gemm_two_k_groups_id_15_agrees_with_id_13():
     # 64 x 128 tiles whose eight waves take the two halves of K in two groups and add their accumulators up at the end: the
     # products of tile 13 in another order of summation (2e-6 of the largest value), with partial tiles, every epilogue operand,
