@@ -3,7 +3,7 @@
 //
 // The reduction runs over the ROW index of both operands, so both MFMA operands are "transposed" views of row-major
 // tiles.  A workgroup owns a 64 (k) x 64 (n) tile of dW and walks its row range in steps of 32 rows: the A tile
-// [32][64] and the dY tile [32][64] are read with coalesced float4 loads (one step ahead), split into bf16 hi (+ lo)
+// [32][64] and the dY tile [32][64] are read with coalesced float4 loads (two steps ahead, two register sets), split into bf16 hi (+ lo)
 // and staged in LDS with 144-byte rows; every operand fragment then comes from the transposing ds_read_b64_tr_b16
 // (4 rows x 16 columns per 16-lane group, delivered column-per-lane).  Both operands use the same slot <-> row
 // permutation, so the product needs no reordering.  Row ranges are spread over the grid and the partial tiles are
@@ -45,18 +45,22 @@ namespace {
 #define WS_WRITE
 #endif
 
-template <int NSPLIT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, const float* dY, const int lddy, float* dW,
+// NB = 2: eight waves, 64 (k) x 128 (n) per workgroup (a wave still owns 32 x 32): the staged A rows serve twice the columns, a
+// thread stages three float4 per step instead of four for the same matrix work per wave.
+template <int NSPLIT, int NB = 1>
+__global__ __launch_bounds__(256 * NB) void wgrad_kernel(const estts_gemm_args ga, const float* dY, const int lddy, float* dW,
                                                     const int lddw, const int rows_per_split, float* db, const int ktiles,
                                                     const int ntiles, const int nsplits) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
+    constexpr int LDY = 64 * NB + 8;   // bf16 per staged dY row
+    constexpr int AI = 2 / NB;         // float4 of A per thread and step (rows r0 + 16 NB i)
     __shared__ __attribute__((aligned(16))) __bf16 As[2][NS][32 * LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Ys[2][NS][32 * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Ys[2][NS][32 * LDY];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wk = wave >> 1, wn = wave & 1;
+    const int wk = wave / (2 * NB), wn = wave % (2 * NB);
     const int i16 = lane & 15, g = lane >> 4;
     // Workgroups go to the eight XCDs round robin.  Every XCD takes a contiguous eighth of the (row range, n tile, k tile)
     // order, k fastest: the tiles of one row range read the same A and dY rows, which are then fetched into one L2 instead
@@ -65,13 +69,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     const int vid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (vid >= ktiles * ntiles * nsplits) return;   // padding of the grid to a multiple of 8 (uniform over the workgroup)
     const int kx = vid % ktiles;
-    const int k0 = kx * 64, n0 = (vid / ktiles) % ntiles * 64;
+    const int k0 = kx * 64, n0 = (vid / ktiles) % ntiles * (64 * NB);
     const int m_begin = vid / (ktiles * ntiles) * rows_per_split;
     const int m_end = min(m_begin + rows_per_split, ga.M);
 
-    const int chunk = tid & 15;
+    const int chunk = tid & 15;                 // A: 16 float4 per row, rows r0 + 16 NB i
     const int r0 = tid >> 4;
-    const int ncol = n0 + chunk * 4;
+    const int ychunk = tid % (16 * NB);         // dY: 16 NB float4 per row, rows yr0 + 16 i
+    const int yr0 = tid / (16 * NB);
+    const int ncol = n0 + ychunk * 4;
     const bool ycol_ok = ncol < ga.N;
 
     // A(m, k) of a dense layer or 1-D convolution: k = (tap, channel) is fixed per thread for the whole row loop, and the
@@ -88,50 +94,56 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
     const int shift = tap - ga.conv_pl;
     const int pos_lo = -shift, pos_hi = seg - shift;   // valid positions of m inside its sequence
     const bool need_pos = ga.taps > 1 || ga.conv_pl != 0;   // uniform (a one-tap layer may still be shifted: h_{t-1} of a GRU)
-    const float* a_col = ga.A + (long)shift * ga.lda + (k_ok ? ch : 0);
     const bool want_db = db != nullptr && kx == 0;     // uniform
 
-    // loads are unconditional (an invalid element reads A[0]) and zeroed where they are used: a load under a condition
-    // becomes a branch around it
-    float4 a_reg[2], y_reg[2];
-    bool a_ok[2], y_ok[2];
+    // loads are unconditional and branch-free (an invalid element reads the nearest existing row) and zeroed where they are
+    // used: a load or an address under a condition becomes a branch around it
+    const float* a_base = ga.A + (k_ok ? ch : 0);
+    const float* y_base = dY + (ycol_ok ? ncol : 0);
+    const int last_row = ga.M - 1;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // column sums of this thread's dY values (the bias gradient)
-    int pos[2];
+    int pos[AI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) pos[i] = need_pos ? (m_begin + r0 + 16 * i) % seg : 0;
-    auto load = [&](int m0) {   // called for m0 = m_begin, m_begin + 32, ... in order
+    for (int i = 0; i < AI; ++i) pos[i] = need_pos ? (m_begin + r0 + 16 * NB * i) % seg : 0;
+    auto load = [&](float4 (&a_reg)[AI], float4 (&y_reg)[2], bool (&a_ok)[AI], bool (&y_ok)[2], int m0) {   // m0 = m_begin, m_begin + 32, ... in order
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = m0 + r0 + 16 * i;
+        for (int i = 0; i < AI; ++i) {
+            const int row = m0 + r0 + 16 * NB * i;
             bool ok = k_ok && row < ga.M;
             if (need_pos) {
                 ok = ok && pos[i] >= pos_lo && pos[i] < pos_hi;
                 pos[i] += 32;
-                if (seg >= 32) pos[i] -= pos[i] >= seg ? seg : 0;
-                else pos[i] %= seg;
+                pos[i] -= pos[i] >= seg ? seg : 0;
+                if (seg < 32) pos[i] %= seg;
             }
             a_ok[i] = ok;
-            a_reg[i] = *reinterpret_cast<const float4*>(ok ? a_col + (long)row * ga.lda : ga.A);
-            y_ok[i] = row < ga.M && ycol_ok;
-            y_reg[i] = *reinterpret_cast<const float4*>(dY + (y_ok[i] ? (long)row * lddy + ncol : 0L));
+            a_reg[i] = *reinterpret_cast<const float4*>(a_base + (long)min(max(row + shift, 0), last_row) * ga.lda);
         }
-    };
-    auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int o = (r0 + 16 * i) * LD + chunk * 4;
-            const float4 az = zero_unless(a_ok[i], a_reg[i]);
+            const int row = m0 + yr0 + 16 * i;
+            y_ok[i] = row < ga.M && ycol_ok;
+            y_reg[i] = *reinterpret_cast<const float4*>(y_base + (long)min(row, last_row) * lddy);
+        }
+    };
+    auto stage = [&](const float4 (&a_reg)[AI], const float4 (&y_reg)[2], const bool (&a_ok)[AI], const bool (&y_ok)[2], int buf) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int o = (r0 + 16 * NB * i) * LD + chunk * 4;
+            bf16x4 ah, al;
+            split_bf16x4(zero_unless(a_ok[i], a_reg[i]), ah, al);
+            *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = ah;
+            if (NS == 2) *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = al;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = (yr0 + 16 * i) * LDY + ychunk * 4;
             const float4 yz = zero_unless(y_ok[i], y_reg[i]);
             if (want_db) { bsum.x += yz.x; bsum.y += yz.y; bsum.z += yz.z; bsum.w += yz.w; }
-            bf16x4 ah, al, yh, yl;
-            split_bf16x4(az, ah, al);
+            bf16x4 yh, yl;
             split_bf16x4(yz, yh, yl);
-            *reinterpret_cast<bf16x4*>(&As[buf][0][o]) = ah;
             *reinterpret_cast<bf16x4*>(&Ys[buf][0][o]) = yh;
-            if (NS == 2) {
-                *reinterpret_cast<bf16x4*>(&As[buf][NS - 1][o]) = al;
-                *reinterpret_cast<bf16x4*>(&Ys[buf][NS - 1][o]) = yl;
-            }
+            if (NS == 2) *reinterpret_cast<bf16x4*>(&Ys[buf][NS - 1][o]) = yl;
         }
     };
 
@@ -142,25 +154,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int frag = (4 * g + (i16 >> 2)) * LD + 4 * (i16 & 3);
-    if (m_begin < m_end) load(m_begin);
-    int buf = 0;
-    WS_DECL;
-    for (int m0 = m_begin; m0 < m_end; m0 += 32) {
-        stage(buf);
-        WS(0);
-        __syncthreads();
-        WS(1);
-        if (m0 + 32 < m_end) load(m0 + 32);
-        WS(2);
+    const int yfrag = (4 * g + (i16 >> 2)) * LDY + 4 * (i16 & 3);
+    auto multiply = [&](int buf) {
         bf16x8 af[NS][2], yf[NS][2];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const __bf16* pa = &As[buf][s][frag + wk * 32 + i * 16];
-                const __bf16* py = &Ys[buf][s][frag + wn * 32 + i * 16];
+                const __bf16* py = &Ys[buf][s][yfrag + wn * 32 + i * 16];
                 af[s][i] = tr_read_pair(pa, pa + 16 * LD);
-                yf[s][i] = tr_read_pair(py, py + 16 * LD);
+                yf[s][i] = tr_read_pair(py, py + 16 * LDY);
             }
         if (NS == 2) {
 #pragma unroll
@@ -179,20 +183,69 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const estts_gemm_args ga, co
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], yf[0][j], acc[i][j], 0, 0, 0);
-        buf ^= 1;
-        WS(3);
+    };
+
+    // Two register sets, two steps in flight; the steady-state loop has no load under a condition (the compiler's wait counts
+    // are static: a conditional prefetch makes every iteration wait for everything) and is entered behind loads pinned in the
+    // loop's own order.
+    float4 a0[AI], y0[2], a1[AI], y1[2];
+    bool ao0[AI], yo0[2], ao1[AI], yo1[2];
+    const int nk = (m_end - m_begin + 31) / 32;   // 32-row steps of this workgroup (>= 1)
+    int kt = 0;
+    WS_DECL;
+    if (nk >= 4) {
+        load(a0, y0, ao0, yo0, m_begin);
+        __builtin_amdgcn_sched_barrier(0);
+        load(a1, y1, ao1, yo1, m_begin + 32);
+        __builtin_amdgcn_sched_barrier(0);
+        for (; kt + 3 < nk; kt += 2) {
+            stage(a0, y0, ao0, yo0, 0);
+            WS(0);
+            __syncthreads();
+            WS(1);
+            load(a0, y0, ao0, yo0, m_begin + (kt + 2) * 32);
+            WS(2);
+            multiply(0);
+            WS(3);
+            stage(a1, y1, ao1, yo1, 1);
+            WS(0);
+            __syncthreads();
+            WS(1);
+            load(a1, y1, ao1, yo1, m_begin + (kt + 3) * 32);
+            WS(2);
+            multiply(1);
+            WS(3);
+        }
+    } else {
+        load(a0, y0, ao0, yo0, m_begin);
+        if (nk > 1) load(a1, y1, ao1, yo1, m_begin + 32);
+    }
+    // tail: steps kt and kt + 1 are in the registers, kt + 2 (nk - kt = 3) is still to be requested
+    stage(a0, y0, ao0, yo0, 0);
+    __syncthreads();
+    if (kt + 2 < nk) load(a0, y0, ao0, yo0, m_begin + (kt + 2) * 32);
+    multiply(0);
+    if (kt + 1 < nk) {
+        stage(a1, y1, ao1, yo1, 1);
+        __syncthreads();
+        multiply(1);
+    }
+    if (kt + 2 < nk) {
+        stage(a0, y0, ao0, yo0, 0);   // every wave is past the barrier in front of multiply(1): buffer 0 is free
+        __syncthreads();
+        multiply(0);
     }
 
     // bias gradient: the workgroups of the first K tile add up the dY rows they staged anyway
     if (want_db) {   // uniform over the workgroup
         __syncthreads();                      // the staging buffers are dead
-        float* red = reinterpret_cast<float*>(&As[0][0][0]);   // [16 row lanes][64 columns]
-        *reinterpret_cast<float4*>(red + r0 * 64 + chunk * 4) = bsum;
+        float* red = reinterpret_cast<float*>(&Ys[0][0][0]);   // [16 row lanes][64 NB columns]
+        *reinterpret_cast<float4*>(red + yr0 * (64 * NB) + ychunk * 4) = bsum;
         __syncthreads();
-        if (tid < 64 && n0 + tid < ga.N) {
+        if (tid < 64 * NB && n0 + tid < ga.N) {
             float t = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t += red[r * 64 + tid];
+            for (int r = 0; r < 16; ++r) t += red[r * (64 * NB) + tid];
             atomic_add_f32(db + n0 + tid, t);
         }
     }
@@ -478,10 +531,16 @@ extern "C" int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream) {
         (a.splits > 0 || a.M / wgrad_conv_splits(a) >= 512))
         return a.taps == 3 ? launch_wgrad_conv<3>(ga, a, (hipStream_t)stream) : launch_wgrad_conv<5>(ga, a, (hipStream_t)stream);
 
-    const int tiles = ((a.K + 63) / 64) * ((a.N + 63) / 64);
+    // large dW (48 tiles of 64 x 64 and more): the eight-wave 64 x 128 tile, two workgroups per CU -- 19200 x 1024 x 256: 59.8 ->
+    // 57.5 us, 19200 x 256 x 1024: 58.3 -> 55.0; smaller outputs lose on it (19200 x 256 x 512: 33.0 -> 35.7 us, 19200 x 256 x 256:
+    // 23.3 -> 26.0) and 3200-row launches do not care.  (ESTTS_WGRAD_WIDE=0 / 1: never / whenever N >= 128, for measurements)
+    static const int wide_env = [] { const char* e = getenv("ESTTS_WGRAD_WIDE"); return e ? atoi(e) : -1; }();
+    const bool wide = a.N >= 128 && (wide_env >= 0 ? wide_env != 0 : ((a.K + 63) / 64) * ((a.N + 63) / 64) >= 48);
+    const int nt = wide ? 128 : 64;
+    const int tiles = ((a.K + 63) / 64) * ((a.N + nt - 1) / nt);
     int splits = a.splits;
     if (splits <= 0) {
-        splits = 1024 / tiles;
+        splits = (wide ? 512 : 1024) / tiles;
         const int by_rows = (a.M + 255) / 256;
         if (splits > by_rows) splits = by_rows;
         if (splits > 64) splits = 64;
@@ -490,16 +549,21 @@ extern "C" int estts_gemm_wgrad(const estts_wgrad_args* args, void* stream) {
     const int steps = (a.M + 31) / 32;
     const int rows_per_split = ((steps + splits - 1) / splits) * 32;
     splits = (a.M + rows_per_split - 1) / rows_per_split;
-    const int ktiles = (a.K + 63) / 64, ntiles = (a.N + 63) / 64;
+    const int ktiles = (a.K + 63) / 64, ntiles = (a.N + nt - 1) / nt;
     const long total = (long)ktiles * ntiles * splits;
     ESTTS_CHECK_ARG(total < (1L << 30), "estts_gemm_wgrad: too many workgroups");
     dim3 grid((unsigned)((total + 7) / 8 * 8));
-    if (a.precision == 3)
-        ESTTS_LAUNCH((wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
-                           ktiles, ntiles, splits);
-    else
-        ESTTS_LAUNCH((wgrad_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, a.db,
-                           ktiles, ntiles, splits);
+#define ESTTS_WGRAD_GO(NSPLIT, NB)                                                                                                      \
+    ESTTS_LAUNCH((wgrad_kernel<NSPLIT, NB>), grid, dim3(256 * NB), 0, (hipStream_t)stream, ga, a.dY, a.lddy, a.dW, a.lddw, rows_per_split, \
+                 a.db, ktiles, ntiles, splits)
+    if (a.precision == 3) {
+        if (wide) ESTTS_WGRAD_GO(3, 2);
+        else ESTTS_WGRAD_GO(3, 1);
+    } else {
+        if (wide) ESTTS_WGRAD_GO(1, 2);
+        else ESTTS_WGRAD_GO(1, 1);
+    }
+#undef ESTTS_WGRAD_GO
     ESTTS_CHECK_LAUNCH("estts_gemm_wgrad");
     return 0;
 }
