@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -79,6 +79,17 @@ class RowmaskArgs(C.Structure):
 
 
 PROG_MAX_PATCH = 8
+
+
+class CrossRowArgs(C.Structure):
+    _fields_ = [('x', _vp), ('ldx', _i32), ('ln_y', _vp), ('ln_x', _vp), ('ln_ga', _vp), ('ln_ba', _vp), ('ln_gb', _vp), ('ln_bb', _vp),
+                ('ln_out', _vp), ('ln_ldy', _i32), ('ln_ldx', _i32), ('ln_ldo', _i32), ('ln_act', _i32), ('ln_eps', _f32),
+                ('wq_hi', _vp), ('wq_lo', _vp), ('ldwq', _i32), ('bq', _vp),
+                ('k', _vp), ('v', _vp), ('ldk', _i32), ('ldv', _i32), ('kv_batch_stride', _i64), ('key_mask', _vp),
+                ('attn', _vp), ('attn_row_stride', _i64),
+                ('wo_hi', _vp), ('wo_lo', _vp), ('ldwo', _i32), ('bo', _vp),
+                ('y', _vp), ('ldy', _i32), ('M', _i32), ('d', _i32), ('H', _i32), ('Lk', _i32),
+                ('ws', _vp), ('ws_bytes', _i64), ('counters', _vp), ('n_counters', _i32), ('q', _vp), ('ldq', _i32)]
 
 
 class ProgOp(C.Structure):
@@ -156,6 +167,7 @@ SIGNATURES = {
     'estts_expand': (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     'estts_conv2d_c1': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'estts_row_zero_mask': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
+    'estts_cross_attention_row': (_i32, [C.POINTER(CrossRowArgs), _vp]),
     'estts_masked_mae': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp]),
     'estts_wavernn_prep': (_i32, [C.POINTER(WavernnPrepArgs), _vp]),
     'estts_gru_gates': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),

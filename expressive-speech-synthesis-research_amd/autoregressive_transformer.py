@@ -137,6 +137,7 @@ class AutoregressiveTransformer:
         self.drop_n_heads = 0
         self.stop_prob_index = 2
         self.fuse_step_norms = True       # incremental decoding: row norms inside the one-row products that consume them
+        self.fuse_cross_attention = True  # ... and a position's whole cross-attention block in one launch (estts_cross_attention_row)
         self.decoder_prenet_dropout = 0.0
         # DecoderPrenet's dropout is active at inference too (layers.py:394-402).  Masks come from the counter-based
         # generator keyed by (seed, site, decoder position, channel); the seed advances once per decoder call.
@@ -412,6 +413,9 @@ class AutoregressiveTransformer:
         # launches per block off the step.  `pending` describes the normalisation whose result xc[:, :d] the next consumer
         # needs: None when the buffer already holds it.
         fuse = pr == 'bf16x3' and d % 8 == 0 and d <= 512 and self.fuse_step_norms
+        cross_row = [self.fuse_cross_attention and ops.can_cross_attention_row(ca.wq, ca.out, d, ca.heads, N, pr) for _, ca, _ in blocks]
+        # ... and a self-attention block's attention over its cache + output projection (the cache grows to S rows)
+        self_row = [self.fuse_cross_attention and ops.can_cross_attention_row(None, sa.out, d, sa.heads, S, pr) for sa, _, _ in blocks]
 
         def step(i):
             frame = frames[r - 1 + i * r:r + i * r]
@@ -424,18 +428,29 @@ class AutoregressiveTransformer:
                 row = qkv[b][i:i + 1]
                 ops.gemm(xc[:, :d], sa.qkv, row, precision=pr, ln=pending)
                 pending = None
-                ops.attention(row[:, :d], qkv[b][:i + 1, d:2 * d], qkv[b][:i + 1, 2 * d:], xc[:, d:], 1, sa.heads, 1, i + 1,
-                              d // sa.heads, key_mask=dec_mask[:, :i + 1], precision=pr)
-                ops.gemm(xc, sa.out, y, precision=pr)
-                if fuse:
-                    ops.gemm(xc2[:, :d], ca.wq, q, precision=pr,
-                             ln=dict(y=y, x=xc[:, :d], ln_a=sa.ln, ln_b=sa.last_ln, out=xc2[:, :d]))
+                if self_row[b]:
+                    ops.cross_attention_row(None, sa.out, qkv[b][:i + 1, d:2 * d], qkv[b][:i + 1, 2 * d:], y, sa.heads, x=xc[:, :d],
+                                            q=row[:, :d], key_mask=dec_mask[:, :i + 1])
                 else:
-                    ops.rownorm(y, xc2[:, :d], ln_a=sa.ln, residual=xc[:, :d], ln_b=sa.last_ln)
-                    ops.gemm(xc2[:, :d], ca.wq, q, precision=pr)
-                ops.attention(q, kv_enc[b][:, :d], kv_enc[b][:, d:], xc2[:, d:], 1, ca.heads, 1, N, d // ca.heads,
-                              key_mask=enc_mask, attn=attn[b][i, :ca.heads * N].view(1, ca.heads, 1, N), precision=pr)
-                ops.gemm(xc2, ca.out, y, precision=pr)
+                    ops.attention(row[:, :d], qkv[b][:i + 1, d:2 * d], qkv[b][:i + 1, 2 * d:], xc[:, d:], 1, sa.heads, 1, i + 1,
+                                  d // sa.heads, key_mask=dec_mask[:, :i + 1], precision=pr)
+                    ops.gemm(xc, sa.out, y, precision=pr)
+                if fuse and cross_row[b]:
+                    # the whole cross-attention block of this position in one launch: the pending LN(LN(y) + x), the query
+                    # projection, attention over the encoder's keys / values and the output projection (y is read, then written)
+                    ops.cross_attention_row(ca.wq, ca.out, kv_enc[b][:, :d], kv_enc[b][:, d:], y, ca.heads,
+                                            ln=dict(y=y, x=xc[:, :d], ln_a=sa.ln, ln_b=sa.last_ln, out=xc2[:, :d]),
+                                            key_mask=enc_mask, attn=attn[b][i:i + 1, :ca.heads * N])
+                else:
+                    if fuse:
+                        ops.gemm(xc2[:, :d], ca.wq, q, precision=pr,
+                                 ln=dict(y=y, x=xc[:, :d], ln_a=sa.ln, ln_b=sa.last_ln, out=xc2[:, :d]))
+                    else:
+                        ops.rownorm(y, xc2[:, :d], ln_a=sa.ln, residual=xc[:, :d], ln_b=sa.last_ln)
+                        ops.gemm(xc2[:, :d], ca.wq, q, precision=pr)
+                    ops.attention(q, kv_enc[b][:, :d], kv_enc[b][:, d:], xc2[:, d:], 1, ca.heads, 1, N, d // ca.heads,
+                                  key_mask=enc_mask, attn=attn[b][i, :ca.heads * N].view(1, ca.heads, 1, N), precision=pr)
+                    ops.gemm(xc2, ca.out, y, precision=pr)
                 if isinstance(ff, FFNLayer):
                     first = ff.d12 if ff.fold else ff.d1
                     if fuse:

@@ -465,12 +465,13 @@ extern "C" int estts_run_program(const estts_prog_op* ops, int32_t n_ops, int32_
         estts_attention_args a;
         estts_rownorm_args r;
         estts_rowmask_args m;
+        estts_cross_row_args c;
     } blk;
-    static const size_t sizes[4] = {sizeof(estts_gemm_args), sizeof(estts_attention_args), sizeof(estts_rownorm_args),
-                                    sizeof(estts_rowmask_args)};
+    static const size_t sizes[5] = {sizeof(estts_gemm_args), sizeof(estts_attention_args), sizeof(estts_rownorm_args),
+                                    sizeof(estts_rowmask_args), sizeof(estts_cross_row_args)};
     for (int i = 0; i < n_ops; ++i) {
         const estts_prog_op& op = ops[i];
-        ESTTS_CHECK_ARG(op.kind >= 0 && op.kind < 4 && op.args && op.n_patch >= 0 && op.n_patch <= ESTTS_PROG_MAX_PATCH,
+        ESTTS_CHECK_ARG(op.kind >= 0 && op.kind < 5 && op.args && op.n_patch >= 0 && op.n_patch <= ESTTS_PROG_MAX_PATCH,
                         "estts_run_program: op %d is malformed", i);
         memcpy(&blk, op.args, sizes[op.kind]);
         char* base = reinterpret_cast<char*>(&blk);
@@ -494,6 +495,7 @@ extern "C" int estts_run_program(const estts_prog_op* ops, int32_t n_ops, int32_
             case 0: rc = estts_gemm(&blk.g, stream); break;
             case 1: rc = estts_attention(&blk.a, stream); break;
             case 2: rc = estts_rownorm(&blk.r, stream); break;
+            case 4: rc = estts_cross_attention_row(&blk.c, stream); break;
             default: rc = estts_row_zero_mask(blk.m.x, blk.m.ldx, blk.m.mask, blk.m.M, blk.m.D, stream); break;
         }
         if (rc != 0) return rc;

@@ -97,7 +97,7 @@ class StepProgram:
     (estts_run_program).  Built by recording the same Python code for step 0 and step 1: every argument field that
     differs between the two recordings becomes a patch `field += step * (value1 - value0)`."""
 
-    KINDS = {'gemm': 0, 'attention': 1, 'rownorm': 2, 'row_zero_mask': 3}
+    KINDS = {'gemm': 0, 'attention': 1, 'rownorm': 2, 'row_zero_mask': 3, 'cross_attention_row': 4}
 
     def __init__(self, record_step):
         """record_step(i): issues the launches of step i through this module's op functions."""
@@ -413,6 +413,74 @@ def attention(q, k, v, ctx, B, H, Lq, Lk, depth, key_mask=None, causal=False, at
                           'bytes': 4.0 * B * H * depth * (2 * Lq + 2 * Lk) + (4.0 * B * H * Lq * Lk if attn is not None else 0)},
             _lib.load().estts_attention, a, keep=(q, k, v, ctx, attn, key_mask))
     return ctx
+
+
+def can_cross_attention_row(wq, wo, d, heads, Lk, precision='bf16x3', site=None):
+    """True when cross_attention_row() can take the block: width 256, heads of depth 64, at most 256 keys (Lk = the most there
+    will be), split operands, plain dense projections (bias only).  wq None: the query rows are given."""
+    plain = all(l.taps == 1 and l.act == 0 and l.s1 is None and l.s2 is None for l in (wq, wo) if l is not None)
+    return (precision_at(precision, site) == 'bf16x3' and d == 256 and heads * 64 == d and 0 < Lk <= 256 and plain and
+            (wq is None or (wq.N == d and wq.K == d)) and wo.N == d and wo.K == 2 * d)
+
+
+def cross_attention_row(wq, wo, k, v, y, heads, x=None, ln=None, key_mask=None, attn=None, M=None, q=None):
+    """One decoder position per row through q projection, attention over the encoder's keys / values and the output projection
+    over [x | ctx] in one launch (estts_cross_attention_row; see can_cross_attention_row).  x: [M, d] rows, or ln = dict(y=,
+    x= or None, ln_a=, ln_b=, act=, out=, eps=1e-6) as in gemm(ln=...): the rows are that normalisation, also written to
+    ln['out'].  k / v: [Lk, >= d] views shared by all rows (M = 1 in the incremental decoder); attn: [M, heads, Lk] view or None;
+    y: [M, d] output (may be the buffer ln['y'] points to).  q: [M, d] query rows instead of wq (attention + output projection
+    only: a self-attention block after the product that wrote its q | k | v row)."""
+    a = _lib.CrossRowArgs()
+    src = ln['y'] if ln is not None else x
+    M = src.shape[0] if M is None else M
+    d = wo.N
+    if ln is not None:
+        yy, xr, lo = ln['y'], ln.get('x'), ln.get('out')
+        _check_f32(yy, 'ln.y')
+        a.ln_y, a.ln_ldy = yy.data_ptr(), yy.stride(0)
+        if xr is not None:
+            _check_f32(xr, 'ln.x')
+            a.ln_x, a.ln_ldx = xr.data_ptr(), xr.stride(0)
+        if lo is not None:
+            _check_f32(lo, 'ln.out')
+            a.ln_out, a.ln_ldo = lo.data_ptr(), lo.stride(0)
+        if ln.get('ln_a') is not None:
+            a.ln_ga, a.ln_ba = ln['ln_a'][0].data_ptr(), ln['ln_a'][1].data_ptr()
+        if ln.get('ln_b') is not None:
+            a.ln_gb, a.ln_bb = ln['ln_b'][0].data_ptr(), ln['ln_b'][1].data_ptr()
+        a.ln_act, a.ln_eps = ACT[ln.get('act')], ln.get('eps', 1e-6)
+    else:
+        _check_f32(x, 'x')
+        a.x, a.ldx = x.data_ptr(), x.stride(0)
+    for t, n in ((k, 'k'), (v, 'v'), (y, 'y')):
+        _check_f32(t, n)
+    if q is not None:
+        _check_f32(q, 'q')
+        a.q, a.ldq = q.data_ptr(), q.stride(0)
+    else:
+        a.wq_hi, a.wq_lo, a.ldwq, a.bq = wq.w_hi.data_ptr(), wq.w_lo.data_ptr(), wq.ldw, _ptr(wq.b1)
+    a.wo_hi, a.wo_lo, a.ldwo, a.bo = wo.w_hi.data_ptr(), wo.w_lo.data_ptr(), wo.ldw, _ptr(wo.b1)
+    a.k, a.v, a.ldk, a.ldv, a.kv_batch_stride = k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0), 0
+    a.key_mask = _ptr(key_mask)
+    Lk = k.shape[0]
+    if attn is not None:
+        _check_f32(attn, 'attn')
+        a.attn, a.attn_row_stride = attn.data_ptr(), attn.stride(0)
+    a.y, a.ldy = y.data_ptr(), y.stride(0)
+    a.M, a.d, a.H, a.Lk = M, d, heads, Lk
+    ws, cnt = _ws_override if _ws_override is not None else gemm_workspace(y.device)   # the heads' shares of y meet here
+    a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
+    a._keep = (x, ln, k, v, y, key_mask, attn, wq, wo, ws, cnt, q)
+    if _program is not None:
+        _program.append(('cross_attention_row', a, a._keep))
+        return y
+    check(_lib.load().estts_cross_attention_row(a, _stream()), 'estts_cross_attention_row')
+    nw = 2 if q is not None else 3     # d x d weight panels read
+    _record('cross_attention_row', {'M': M, 'd': d, 'H': heads, 'Lk': Lk, 'projected': q is None,
+                                    'flops': 2.0 * M * (nw * d * d + 2 * Lk * d),
+                                    'bytes': 4.0 * (nw * d * d + 2 * Lk * d) + 4.0 * M * (3 * d + heads * Lk)},
+            _lib.load().estts_cross_attention_row, a, keep=a._keep)
+    return y
 
 
 def rownorm_args(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=None, D=None,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 33
+#define ESTTS_ABI_VERSION 34
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -777,13 +777,52 @@ int estts_mol_loss(const float* y_hat, int32_t ld, const float* y, float* loss, 
                    int32_t nr_mix, int32_t num_classes, float log_scale_min, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * One decoder position through a CrossAttentionResnorm block in one launch, for incremental decoding
+ * (TransformerTTS/model/layers.py:258-274 with transformer_utils.py:24-44 for a single query row; the reference re-runs the
+ * whole decoder per step, model/AutoregressiveTransformer.py:279-296).  Per row m < M:
+ *   x   = ln_y ? LNb(act_ln(LNa(ln_y[m])) + ln_x[m]) : x[m]       (the ln_* fields as in estts_gemm's LayerNorm prologue; the
+ *                                                                  normalised row is also written to ln_out[m] when given)
+ *   q   = x Wq + bq;   p[h, j] = softmax_j(q_h . k[j, h] / sqrt(depth) - 1e9 key_mask[m, j]);   ctx_h = sum_j p[h, j] v[j, h]
+ *   y[m] = [x | ctx] Wo + bo
+ * Wq ([d, d]) and Wo ([d, 2 d]) in the packed bf16 hi + lo layout of estts_gemm (ldw = K rounded up to 64), k / v float32
+ * [Lk, >= d] rows of row m at k / v + m * kv_batch_stride (floats; 0 = shared), attn (may be NULL) receives p as [H, Lk] at
+ * attn + m * attn_row_stride.  This kernel takes d = 256 with heads of depth 64 and Lk <= 256; y may be the buffer ln_y points
+ * to (a row is read before it is written).  With q given the kernel is attention + output projection only: a self-attention
+ * block's step after the product that wrote the position's q | k | v row (k / v = the cache up to and including it, Lk = the
+ * position + 1; TransformerTTS/model/layers.py:217-233).  A row is four workgroups (one per head) whose shares of y meet in ws; launches
+ * that share ws / counters must be ordered on one stream, as with estts_gemm's.  Same products as estts_gemm + estts_attention + estts_gemm on one row, summed in
+ * float32 on hi + lo: equal to 1e-5 of the largest value, not bit for bit.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct estts_cross_row_args {
+    const float* x; int32_t ldx;
+    const float* ln_y; const float* ln_x;
+    const float* ln_ga; const float* ln_ba; const float* ln_gb; const float* ln_bb;
+    float* ln_out;
+    int32_t ln_ldy, ln_ldx, ln_ldo, ln_act;
+    float ln_eps;
+    const uint16_t* wq_hi; const uint16_t* wq_lo; int32_t ldwq; const float* bq;
+    const float* k; const float* v; int32_t ldk, ldv; int64_t kv_batch_stride;
+    const float* key_mask;
+    float* attn; int64_t attn_row_stride;
+    const uint16_t* wo_hi; const uint16_t* wo_lo; int32_t ldwo; const float* bo;
+    float* y; int32_t ldy;
+    int32_t M, d, H, Lk;
+    float* ws; int64_t ws_bytes;             /* slab for the heads' shares of y: M * 4 * 256 floats */
+    int32_t* counters; int32_t n_counters;   /* >= M, zero before the first launch; every launch leaves them at zero */
+    const float* q; int32_t ldq;             /* given: the query rows themselves (bias included); wq_hi / wq_lo / bq are not read */
+} estts_cross_row_args;
+
+int estts_cross_attention_row(const estts_cross_row_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Step programs: a fixed sequence of launches whose arguments depend affinely on a step index (an incremental decoder:
  * row i of a cache, a key range of i + 1, ...).  Each op carries the argument block of step 0 and a patch list; at step s
  * the field at byte `offset` of a copy of the block is advanced by s * stride (a pointer, in bytes, or an int32), then the
  * op's entry point is called.  This issues a whole decoder step from one host call, without rebuilding argument blocks
  * in the host language.  No counterpart in the reference (its loop, model/AutoregressiveTransformer.py:279-296, re-runs
  * the whole Keras decoder every step).
- * kind: 0 estts_gemm, 1 estts_attention, 2 estts_rownorm, 3 estts_row_zero_mask (args = estts_rowmask_args).
+ * kind: 0 estts_gemm, 1 estts_attention, 2 estts_rownorm, 3 estts_row_zero_mask (args = estts_rowmask_args),
+ * 4 estts_cross_attention_row.
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_rowmask_args {
     const float* x; int32_t ldx;

@@ -688,3 +688,81 @@ def test_gemm_batched_products_in_one_launch():
         assert np.abs(out[z].cpu().numpy() - ref).max() < 3e-5 * np.abs(ref).max()
     with pytest.raises(Exception):
         ops.gemm(xd[0], lin, out[0], split=False, tune=4, batch=(2, M * K, N * lin.ldw, M * N, N))
+
+
+@pytest.mark.parametrize('Lk,mode', [(100, 'sa'), (100, 'plain'), (37, 'ffn'), (256, 'single'), (1, 'sa')])
+def test_cross_attention_row_is_projection_attention_projection(Lk, mode):
+    # estts_cross_attention_row: one decoder position through q projection, attention over the encoder's keys / values and the
+    # output projection over [x | ctx] in one launch (layers.py:258-274 for a single query row), against the three launches it
+    # replaces -- gemm(ln=...) + attention + gemm -- with the pending normalisations an incremental decoder hands over (the
+    # self-attention block's LN(LN(y) + x), a closing FFN norm with ReLU, a single norm, none), a key mask, and several rows
+    d, H = 256, 4
+    for M in (1, 3):
+        g = 61000 + Lk + 7 * M
+        wq = PackedLinear(_rand(d, d, seed=g, scale=1 / 16).numpy(), bias=_rand(d, seed=g + 1).numpy(), device=DEV)
+        wo = PackedLinear(_rand(d, 2 * d, seed=g + 2, scale=1 / 23).numpy(), bias=_rand(d, seed=g + 3).numpy(), device=DEV)
+        kv = _rand(Lk, 2 * d, seed=g + 4).to(DEV)
+        mask = (torch.rand(M, Lk, generator=torch.Generator().manual_seed(g + 5)) < 0.2).float().to(DEV) if M == 1 else None
+        if mask is not None and Lk > 1:
+            mask[0, 0] = 0.0
+        yin, xin = _rand(M, d, seed=g + 6).to(DEV), _rand(M, d, seed=g + 7).to(DEV)
+        vec = lambda s: ((_rand(d, seed=s).abs() + 0.5).to(DEV), _rand(d, seed=s + 1).to(DEV))
+        ln = {'sa': dict(ln_a=vec(g + 8), ln_b=vec(g + 10), x=xin), 'ffn': dict(ln_a=vec(g + 8), act='relu', ln_b=vec(g + 10), x=xin),
+              'single': dict(ln_b=vec(g + 10), x=xin), 'plain': None}[mode]
+        assert ops.can_cross_attention_row(wq, wo, d, H, Lk)
+        # the three launches
+        xc = torch.zeros(M, 2 * d, device=DEV)
+        q, y_ref, attn_ref = torch.empty(M, d, device=DEV), torch.empty(M, d, device=DEV), torch.empty(M, H, 1, Lk, device=DEV)
+        if ln is None:
+            xc[:, :d] = yin
+            ops.gemm(xc[:, :d], wq, q)
+        else:
+            ops.rownorm(yin, xc[:, :d], ln_a=ln.get('ln_a'), act=ln.get('act'), residual=ln['x'], ln_b=ln.get('ln_b'))
+            ops.gemm(xc[:, :d], wq, q)
+        kk, vv = (kv[:, :d], kv[:, d:])
+        for m in range(M):      # the keys / values are shared by the rows: one launch per row of the reference form
+            ops.attention(q[m:m + 1], kk, vv, xc[m:m + 1, d:], 1, H, 1, Lk, d // H, key_mask=None if mask is None else mask[m:m + 1],
+                          attn=attn_ref[m:m + 1])
+        ops.gemm(xc, wo, y_ref)
+        # one launch
+        y = torch.full((M + 1, d + 4), float('nan'), device=DEV)
+        attn = torch.full((M, H * Lk + 3), float('nan'), device=DEV)
+        lo = torch.full((M, d), float('nan'), device=DEV)
+        if ln is None:
+            ops.cross_attention_row(wq, wo, kk, vv, y[:M, :d], H, x=yin, key_mask=mask, attn=attn)
+        else:
+            ops.cross_attention_row(wq, wo, kk, vv, y[:M, :d], H, ln=dict(y=yin, out=lo, **ln), key_mask=mask, attn=attn)
+            assert (lo - xc[:, :d]).abs().max().item() < 2e-6 * xc[:, :d].abs().max().item()
+        assert torch.isnan(y[M:]).all() and torch.isnan(y[:, d:]).all() and torch.isnan(attn[:, H * Lk:]).all()
+        assert torch.isfinite(y_ref).all()
+        err = (y[:M, :d] - y_ref).abs().max().item() / y_ref.abs().max().item()
+        aerr = (attn[:, :H * Lk].view(M, H, 1, Lk) - attn_ref).abs().max().item()
+        assert err < 2e-5 and aerr < 2e-5, (Lk, mode, M, err, aerr)
+
+
+@pytest.mark.parametrize('Lk', [1, 2, 60, 64, 65, 128, 129, 256])
+def test_cross_attention_row_with_given_queries_is_attention_then_projection(Lk):
+    # the same entry point with the query rows given (a self-attention block of an incremental decoder, layers.py:217-233, after
+    # the product that wrote the position's q | k | v row): attention over the cache + output projection over [x | ctx], against
+    # the two launches it replaces; the key counts straddle the kernel's register variants (64 / 128 / 256 keys)
+    d, H = 256, 4
+    g = 62000 + Lk
+    wo = PackedLinear(_rand(d, 2 * d, seed=g + 2, scale=1 / 23).numpy(), bias=_rand(d, seed=g + 3).numpy(), device=DEV)
+    qkv = _rand(Lk, 3 * d, seed=g + 4).to(DEV)
+    mask = (torch.rand(1, Lk, generator=torch.Generator().manual_seed(g + 5)) < 0.2).float().to(DEV)
+    mask[0, 0] = 0.0
+    assert ops.can_cross_attention_row(None, wo, d, H, Lk) and not ops.can_cross_attention_row(None, wo, d, H, 257)
+    xc = torch.zeros(1, 2 * d, device=DEV)
+    xc[:, :d] = _rand(1, d, seed=g + 6).to(DEV)
+    row = qkv[Lk - 1:Lk]
+    y_ref = torch.empty(1, d, device=DEV)
+    ops.attention(row[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], xc[:, d:], 1, H, 1, Lk, d // H, key_mask=mask)
+    ops.gemm(xc, wo, y_ref)
+    for _ in range(2):      # (twice: the row's arrival counter must be back at zero)
+        y = torch.full((2, d), float('nan'), device=DEV)
+        ops.cross_attention_row(None, wo, qkv[:, d:2 * d], qkv[:, 2 * d:], y[:1], H, x=xc[:, :d], q=row[:, :d], key_mask=mask)
+        assert torch.isnan(y[1:]).all()
+        err = (y[:1] - y_ref).abs().max().item() / y_ref.abs().max().item()
+        assert err < 2e-5, (Lk, err)
+    with pytest.raises(Exception):
+        ops.cross_attention_row(None, wo, qkv[:, d + 1:2 * d + 1], qkv[:, 2 * d:], y[:1], H, x=xc[:, :d], q=row[:, :d])   # misaligned keys
