@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 34
+ABI_VERSION = 35
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -92,6 +92,23 @@ class CrossRowArgs(C.Structure):
                 ('ws', _vp), ('ws_bytes', _i64), ('counters', _vp), ('n_counters', _i32), ('q', _vp), ('ldq', _i32)]
 
 
+class DecoderBlockArgs(C.Structure):
+    _fields_ = [('x', _vp), ('ldx', _i32), ('ln_y', _vp), ('ln_x', _vp), ('ln_ga', _vp), ('ln_ba', _vp), ('ln_gb', _vp), ('ln_bb', _vp),
+                ('ln_ldy', _i32), ('ln_ldx', _i32), ('ln_act', _i32), ('ln_eps', _f32),
+                ('wqkv_hi', _vp), ('wqkv_lo', _vp), ('ldwqkv', _i32), ('bqkv', _vp),
+                ('qkv', _vp), ('ldqkv', _i32), ('qkv_batch_stride', _i64), ('pos', _i32),
+                ('self_mask', _vp), ('self_mask_stride', _i64),
+                ('wos_hi', _vp), ('wos_lo', _vp), ('ldwos', _i32), ('bos', _vp),
+                ('sa_ga', _vp), ('sa_ba', _vp), ('sa_gb', _vp), ('sa_bb', _vp),
+                ('wqc_hi', _vp), ('wqc_lo', _vp), ('ldwqc', _i32), ('bqc', _vp),
+                ('k', _vp), ('v', _vp), ('ldk', _i32), ('ldv', _i32), ('kv_batch_stride', _i64), ('Lk', _i32), ('key_mask', _vp),
+                ('attn', _vp), ('attn_row_stride', _i64),
+                ('woc_hi', _vp), ('woc_lo', _vp), ('ldwoc', _i32), ('boc', _vp), ('ca_g', _vp), ('ca_b', _vp),
+                ('wff_hi', _vp), ('wff_lo', _vp), ('ldwff', _i32), ('bff', _vp),
+                ('y2', _vp), ('ldy2', _i32), ('x2', _vp), ('ldx2', _i32),
+                ('ws', _vp), ('ws_bytes', _i64), ('counters', _vp), ('n_counters', _i32), ('M', _i32), ('d', _i32), ('H', _i32)]
+
+
 class ProgOp(C.Structure):
     _fields_ = [('kind', _i32), ('n_patch', _i32), ('args', _vp), ('patch_offset', _i32 * PROG_MAX_PATCH),
                 ('patch_is_ptr', _i32 * PROG_MAX_PATCH), ('patch_stride', _i64 * PROG_MAX_PATCH)]
@@ -168,6 +185,7 @@ SIGNATURES = {
     'estts_conv2d_c1': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'estts_row_zero_mask': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
     'estts_cross_attention_row': (_i32, [C.POINTER(CrossRowArgs), _vp]),
+    'estts_decoder_block_row': (_i32, [C.POINTER(DecoderBlockArgs), _vp]),
     'estts_masked_mae': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp]),
     'estts_wavernn_prep': (_i32, [C.POINTER(WavernnPrepArgs), _vp]),
     'estts_gru_gates': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),

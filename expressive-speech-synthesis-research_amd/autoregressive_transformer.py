@@ -137,6 +137,7 @@ class AutoregressiveTransformer:
         self.drop_n_heads = 0
         self.stop_prob_index = 2
         self.fuse_step_norms = True       # incremental decoding: row norms inside the one-row products that consume them
+        self.fuse_decoder_block = True    # ... and a position's whole decoder block in one launch (estts_decoder_block_row)
         self.fuse_cross_attention = True  # ... and a position's whole cross-attention block in one launch (estts_cross_attention_row)
         self.decoder_prenet_dropout = 0.0
         # DecoderPrenet's dropout is active at inference too (layers.py:394-402).  Masks come from the counter-based
@@ -408,6 +409,7 @@ class AutoregressiveTransformer:
         sqrt_d = math.sqrt(np.float32(d))
 
         y2 = torch.empty(1, d, **f32)
+        y2s, x2s = [torch.empty(1, d, **f32) for _ in range(2)], [torch.empty(1, d, **f32) for _ in range(2)]   # (a block reads one pair, writes the other)
         # A row-wise normalisation is folded into the one-row product that consumes it (gemm(ln=...): every column tile
         # recomputes the norm of the single row and tile 0 writes it out for the later residual uses), which takes three
         # launches per block off the step.  `pending` describes the normalisation whose result xc[:, :d] the next consumer
@@ -417,6 +419,11 @@ class AutoregressiveTransformer:
         # ... and a self-attention block's attention over its cache + output projection (the cache grows to S rows)
         self_row = [self.fuse_cross_attention and ops.can_cross_attention_row(None, sa.out, d, sa.heads, S, pr) for sa, _, _ in blocks]
 
+        # ... or the whole block (self-attention, cross-attention, folded feed-forward product): four workgroups per position
+        # that meet at barriers of their own inside the kernel
+        block_row = [fuse and self.fuse_decoder_block and isinstance(ff, FFNLayer) and ff.fold and sa.heads == ca.heads and
+                     ops.can_decoder_block_row(sa.qkv, sa.out, ca.wq, ca.out, ff.d12, d, sa.heads, S, N, pr) for sa, ca, ff in blocks]
+
         def step(i):
             frame = frames[r - 1 + i * r:r + i * r]
             ops.row_zero_mask(frame, dec_mask[0, i:i + 1])
@@ -425,6 +432,13 @@ class AutoregressiveTransformer:
                      dropout=(rate, seed, 1, i))
             pending = None
             for b, (sa, ca, ff) in enumerate(blocks):
+                if block_row[b]:
+                    ops.decoder_block_row(sa.qkv, sa.out, sa.ln, sa.last_ln, ca.wq, ca.out, ca.ln, ff.d12, qkv[b], i,
+                                          kv_enc[b][:, :d], kv_enc[b][:, d:], y2s[b & 1], x2s[b & 1],
+                                          x=None if pending is not None else xc[:, :d], ln=pending, self_mask=dec_mask,
+                                          key_mask=enc_mask, attn=attn[b][i:i + 1, :ca.heads * N])
+                    pending = dict(y=y2s[b & 1], x=x2s[b & 1], ln_a=ff.ln, act='relu', ln_b=ff.last_ln, out=xc[:, :d])
+                    continue
                 row = qkv[b][i:i + 1]
                 ops.gemm(xc[:, :d], sa.qkv, row, precision=pr, ln=pending)
                 pending = None

@@ -97,7 +97,7 @@ class StepProgram:
     (estts_run_program).  Built by recording the same Python code for step 0 and step 1: every argument field that
     differs between the two recordings becomes a patch `field += step * (value1 - value0)`."""
 
-    KINDS = {'gemm': 0, 'attention': 1, 'rownorm': 2, 'row_zero_mask': 3, 'cross_attention_row': 4}
+    KINDS = {'gemm': 0, 'attention': 1, 'rownorm': 2, 'row_zero_mask': 3, 'cross_attention_row': 4, 'decoder_block_row': 5}
 
     def __init__(self, record_step):
         """record_step(i): issues the launches of step i through this module's op functions."""
@@ -481,6 +481,87 @@ def cross_attention_row(wq, wo, k, v, y, heads, x=None, ln=None, key_mask=None, 
                                     'bytes': 4.0 * (nw * d * d + 2 * Lk * d) + 4.0 * M * (3 * d + heads * Lk)},
             _lib.load().estts_cross_attention_row, a, keep=a._keep)
     return y
+
+
+_block_counters = {}
+
+
+def _decoder_block_counters(device):
+    """The barrier counters of decoder_block_row (per device; zero at allocation, every launch leaves them ready for the next)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    c = _block_counters.get(key)
+    if c is None:
+        c = _block_counters[key] = torch.zeros(128, dtype=torch.int32, device=torch.device('cuda', key))
+    return c
+
+
+def can_decoder_block_row(wqkv, wos, wqc, woc, wff, d, heads, max_pos, Lk, precision='bf16x3'):
+    """True when decoder_block_row() can take the block: width 256, 4 heads, at most 256 decoder and encoder positions, split
+    operands everywhere (also at the feed-forward site), plain dense layers (bias only), the feed-forward pair folded into wff."""
+    lins = (wqkv, wos, wqc, woc, wff)
+    plain = all(l is not None and l.taps == 1 and l.act == 0 and l.s1 is None and l.s2 is None for l in lins)
+    return (plain and precision_at(precision, None) == 'bf16x3' and precision_at(precision, 'ffn') == 'bf16x3' and d == 256 and heads == 4 and
+            0 < max_pos <= 256 and 0 < Lk <= 256 and (wqkv.N, wqkv.K) == (3 * d, d) and (wos.N, wos.K) == (d, 2 * d) and
+            (wqc.N, wqc.K) == (d, d) and (woc.N, woc.K) == (d, 2 * d) and (wff.N, wff.K) == (d, d))
+
+
+def decoder_block_row(wqkv, wos, sa_ln, sa_last_ln, wqc, woc, ca_ln, wff, cache, pos, k, v, y2, x2, x=None, ln=None, self_mask=None,
+                      key_mask=None, attn=None, eps=1e-6):
+    """One decoder position (row 0 of x, or of the pending normalisation ln = dict(y=, x=, ln_a=, act=, ln_b=) as in gemm(ln=...))
+    through self-attention, cross-attention and the folded feed-forward product of a block in one launch
+    (estts_decoder_block_row; see can_decoder_block_row).  cache: [S, 3 d] rows q | k | v of the decoder positions, row `pos`
+    is written; k / v: [Lk, >= d] encoder keys / values; self_mask: [1, > pos], key_mask: [1, Lk], attn: [1, heads * Lk] view or
+    None.  Writes y2 (the product) and x2 (its residual): the block's output is LN(relu(LN(y2)) + x2), left to the consumer."""
+    a = _lib.DecoderBlockArgs()
+    d = wos.N
+    if ln is not None:
+        yy, xr = ln['y'], ln.get('x')
+        _check_f32(yy, 'ln.y')
+        a.ln_y, a.ln_ldy = yy.data_ptr(), yy.stride(0)
+        if xr is not None:
+            _check_f32(xr, 'ln.x')
+            a.ln_x, a.ln_ldx = xr.data_ptr(), xr.stride(0)
+        if ln.get('ln_a') is not None:
+            a.ln_ga, a.ln_ba = ln['ln_a'][0].data_ptr(), ln['ln_a'][1].data_ptr()
+        if ln.get('ln_b') is not None:
+            a.ln_gb, a.ln_bb = ln['ln_b'][0].data_ptr(), ln['ln_b'][1].data_ptr()
+        a.ln_act = ACT[ln.get('act')]
+    else:
+        _check_f32(x, 'x')
+        a.x, a.ldx = x.data_ptr(), x.stride(0)
+    a.ln_eps = eps
+    for t, n in ((cache, 'cache'), (k, 'k'), (v, 'v'), (y2, 'y2'), (x2, 'x2')):
+        _check_f32(t, n)
+    a.wqkv_hi, a.wqkv_lo, a.ldwqkv, a.bqkv = wqkv.w_hi.data_ptr(), wqkv.w_lo.data_ptr(), wqkv.ldw, _ptr(wqkv.b1)
+    a.qkv, a.ldqkv, a.qkv_batch_stride, a.pos = cache.data_ptr(), cache.stride(0), 0, pos
+    if self_mask is not None:
+        a.self_mask, a.self_mask_stride = self_mask.data_ptr(), self_mask.stride(0)
+    a.wos_hi, a.wos_lo, a.ldwos, a.bos = wos.w_hi.data_ptr(), wos.w_lo.data_ptr(), wos.ldw, _ptr(wos.b1)
+    a.sa_ga, a.sa_ba, a.sa_gb, a.sa_bb = (sa_ln[0].data_ptr(), sa_ln[1].data_ptr(), sa_last_ln[0].data_ptr(), sa_last_ln[1].data_ptr())
+    a.wqc_hi, a.wqc_lo, a.ldwqc, a.bqc = wqc.w_hi.data_ptr(), wqc.w_lo.data_ptr(), wqc.ldw, _ptr(wqc.b1)
+    a.k, a.v, a.ldk, a.ldv, a.kv_batch_stride, a.Lk = k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0), 0, k.shape[0]
+    a.key_mask = _ptr(key_mask)
+    if attn is not None:
+        _check_f32(attn, 'attn')
+        a.attn, a.attn_row_stride = attn.data_ptr(), attn.stride(0)
+    a.woc_hi, a.woc_lo, a.ldwoc, a.boc = woc.w_hi.data_ptr(), woc.w_lo.data_ptr(), woc.ldw, _ptr(woc.b1)
+    a.ca_g, a.ca_b = ca_ln[0].data_ptr(), ca_ln[1].data_ptr()
+    a.wff_hi, a.wff_lo, a.ldwff, a.bff = wff.w_hi.data_ptr(), wff.w_lo.data_ptr(), wff.ldw, _ptr(wff.b1)
+    a.y2, a.ldy2, a.x2, a.ldx2 = y2.data_ptr(), y2.stride(0), x2.data_ptr(), x2.stride(0)
+    ws = (_ws_override if _ws_override is not None else gemm_workspace(y2.device))[0]
+    cnt = _decoder_block_counters(y2.device)
+    a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
+    a.M, a.d, a.H = 1, d, 4
+    a._keep = (x, ln, cache, k, v, y2, x2, self_mask, key_mask, attn, wqkv, wos, sa_ln, sa_last_ln, wqc, woc, ca_ln, wff, ws, cnt)
+    if _program is not None:
+        _program.append(('decoder_block_row', a, a._keep))
+        return y2
+    check(_lib.load().estts_decoder_block_row(a, _stream()), 'estts_decoder_block_row')
+    Lk = k.shape[0]
+    _record('decoder_block_row', {'M': 1, 'd': d, 'H': 4, 'Lk': Lk, 'pos': pos, 'flops': 2.0 * (8 * d * d + 2 * (Lk + pos + 1) * d),
+                                  'bytes': 4.0 * (8 * d * d + 2 * (Lk + pos + 1) * d) + 4.0 * (6 * d + 4 * Lk)},
+            _lib.load().estts_decoder_block_row, a, keep=a._keep)
+    return y2
 
 
 def rownorm_args(y, out, ln_a=None, act=None, residual=None, ln_b=None, eps=1e-6, M=None, D=None,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 34
+#define ESTTS_ABI_VERSION 35
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -813,6 +813,50 @@ typedef struct estts_cross_row_args {
 } estts_cross_row_args;
 
 int estts_cross_attention_row(const estts_cross_row_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One decoder position through a whole decoder block in one launch: SelfAttentionResNorm, CrossAttentionResnorm and the dense
+ * product of FFNResNorm (TransformerTTS/model/layers.py:217-233, 258-274, 104-124; the block, layers.py:277-297), for
+ * incremental decoding.  Per row m < M, with LN(v; g, b) the LayerNormalization over the 256 columns:
+ *   x    = ln_y ? LNb(act_ln(LNa(ln_y[m])) + ln_x[m]) : x[m]                     (as in estts_gemm's LayerNorm prologue)
+ *   q | k | v = x Wqkv + bqkv  -> row `pos` of the cache qkv ([rows, >= 768] per m);  ctx = attention of q over cache rows
+ *          0 .. pos (keys at columns 256.., values at 512..; -1e9 self_mask[m, j] added to the scores)
+ *   y_s  = [x | ctx] Wo_s + bos;        x'  = LN(LN(y_s; sa_ga, sa_ba) + x; sa_gb, sa_bb)
+ *   q'   = x' Wq_c + bqc;  ctx' = attention of q' over k / v (Lk rows, key_mask) -> weights to attn ([H, Lk] at
+ *          attn + m * attn_row_stride, may be NULL);     y_c = [x' | ctx'] Wo_c + boc
+ *   x2[m] = LN(y_c + x'; ca_g, ca_b);   y2[m] = x2 W_ff + bff
+ * W_ff is the block's two dense layers folded into one 256 x 256 product (the reference applies no activation between them,
+ * layers.py:116-119); the block's closing LN(relu(LN(y2)) + x2) is left to the consumer of (y2, x2), which is the next block's
+ * ln_y / ln_x or estts_gemm's prologue.  All weights in the packed bf16 hi + lo layout of estts_gemm.  Width 256, 4 heads,
+ * pos < 256, Lk <= 256, M <= 64.  ws: M * 2 * 4 * 256 floats of scratch; counters: 2 M int32 that belong to this entry point
+ * alone, zero at allocation (a launch leaves them ready for the next one; they are not the zero-after-use counters of
+ * estts_gemm).  The four workgroups of a row wait for one another inside the kernel: launches that share ws / counters must be
+ * ordered on one stream.  Same sums as the separate launches up to float32 summation order (1e-5 of the largest value).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct estts_decoder_block_args {
+    const float* x; int32_t ldx;
+    const float* ln_y; const float* ln_x;
+    const float* ln_ga; const float* ln_ba; const float* ln_gb; const float* ln_bb;
+    int32_t ln_ldy, ln_ldx, ln_act;
+    float ln_eps;                              /* epsilon of every LayerNormalization of the block */
+    const uint16_t* wqkv_hi; const uint16_t* wqkv_lo; int32_t ldwqkv; const float* bqkv;
+    float* qkv; int32_t ldqkv; int64_t qkv_batch_stride; int32_t pos;
+    const float* self_mask; int64_t self_mask_stride;
+    const uint16_t* wos_hi; const uint16_t* wos_lo; int32_t ldwos; const float* bos;
+    const float* sa_ga; const float* sa_ba; const float* sa_gb; const float* sa_bb;
+    const uint16_t* wqc_hi; const uint16_t* wqc_lo; int32_t ldwqc; const float* bqc;
+    const float* k; const float* v; int32_t ldk, ldv; int64_t kv_batch_stride; int32_t Lk;
+    const float* key_mask;
+    float* attn; int64_t attn_row_stride;
+    const uint16_t* woc_hi; const uint16_t* woc_lo; int32_t ldwoc; const float* boc;
+    const float* ca_g; const float* ca_b;
+    const uint16_t* wff_hi; const uint16_t* wff_lo; int32_t ldwff; const float* bff;
+    float* y2; int32_t ldy2; float* x2; int32_t ldx2;
+    float* ws; int64_t ws_bytes; int32_t* counters; int32_t n_counters;
+    int32_t M, d, H;
+} estts_decoder_block_args;
+
+int estts_decoder_block_row(const estts_decoder_block_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Step programs: a fixed sequence of launches whose arguments depend affinely on a step index (an incremental decoder:

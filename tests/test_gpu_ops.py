@@ -766,3 +766,84 @@ def test_cross_attention_row_with_given_queries_is_attention_then_projection(Lk)
         assert err < 2e-5, (Lk, err)
     with pytest.raises(Exception):
         ops.cross_attention_row(None, wo, qkv[:, d + 1:2 * d + 1], qkv[:, 2 * d:], y[:1], H, x=xc[:, :d], q=row[:, :d])   # misaligned keys
+
+
+@pytest.mark.parametrize('Lk,positions,pending', [(100, (0, 1, 2, 7), 'ffn'), (100, (62, 63, 64, 65), None), (37, (127, 128, 129), 'single'),
+                                                  (200, (0, 3), 'ffn'), (256, (254, 255), None)])
+def test_decoder_block_row_is_the_block_of_the_reference_for_one_position(Lk, positions, pending):
+    # estts_decoder_block_row: self-attention over the cache, cross-attention over the encoder and the folded feed-forward product
+    # of a decoder block for one position in one launch (layers.py:277-297 with 217-233, 258-274, 104-124), against the same
+    # block written out in float64 from the unpacked weights.  The positions straddle the kernel's register variants (64 / 128
+    # cache rows, 128 / 256 encoder rows); successive launches on one cache also exercise the counters that the four workgroups
+    # of a row leave for the next launch.
+    d, H = 256, 4
+    g = 63000 + Lk
+    W = lambda n, k, s: _rand(n, k, seed=s, scale=1 / np.sqrt(k))
+    w = dict(qkv=W(3 * d, d, g), os=W(d, 2 * d, g + 1), qc=W(d, d, g + 2), oc=W(d, 2 * d, g + 3), ff=W(d, d, g + 4))
+    bias = {n: _rand(w[n].shape[0], seed=g + 10 + i) * 0.3 for i, n in enumerate(w)}
+    lin = {n: PackedLinear(w[n].numpy(), bias=bias[n].numpy(), device=DEV) for n in w}
+    vec = lambda s: (_rand(d, seed=s).abs() + 0.5, _rand(d, seed=s + 1) * 0.3)
+    lns = dict(sa=vec(g + 20), sa_last=vec(g + 22), ca=vec(g + 24), pa=vec(g + 26), pb=vec(g + 28))
+    dev = lambda t: tuple(x.to(DEV) for x in t)
+    S = max(positions) + 1
+    cache = _rand(S, 3 * d, seed=g + 30)
+    enc = _rand(Lk, 2 * d, seed=g + 31)
+    smask = (torch.rand(1, S, generator=torch.Generator().manual_seed(g + 32)) < 0.15).float()
+    emask = (torch.rand(1, Lk, generator=torch.Generator().manual_seed(g + 33)) < 0.2).float()
+    emask[0, 0] = 0.0
+    assert ops.can_decoder_block_row(lin['qkv'], lin['os'], lin['qc'], lin['oc'], lin['ff'], d, H, S, Lk)
+    cache_d, enc_d = cache.to(DEV).clone(), enc.to(DEV)
+    f64 = lambda t: t.double()
+
+    def LN(v, gb):
+        m = v.mean(-1, keepdim=True)
+        return (v - m) / torch.sqrt(((v - m) ** 2).mean(-1, keepdim=True) + 1e-6) * f64(gb[0]) + f64(gb[1])
+
+    def attend(q, K, V, mask):
+        out, ws = [], []
+        for h in range(H):
+            sl = slice(64 * h, 64 * h + 64)
+            sc = (K[:, sl] @ q[0, sl]) / 8.0 + f64(mask[0, :K.shape[0]]) * -1e9
+            p = torch.softmax(sc, 0)
+            ws.append(p)
+            out.append(p @ V[:, sl])
+        return torch.cat(out)[None], torch.stack(ws)
+
+    for pos in positions:
+        yin, xin = _rand(1, d, seed=g + 40 + pos), _rand(1, d, seed=g + 41 + pos)
+        # float64 block
+        if pending == 'ffn':
+            x = LN(torch.relu(LN(f64(yin), lns['pa'])) + f64(xin), lns['pb'])
+            ln = dict(y=yin.to(DEV), x=xin.to(DEV), ln_a=dev(lns['pa']), act='relu', ln_b=dev(lns['pb']))
+        elif pending == 'single':
+            x = LN(f64(yin) + f64(xin), lns['pb'])
+            ln = dict(y=yin.to(DEV), x=xin.to(DEV), ln_b=dev(lns['pb']))
+        else:
+            x, ln = f64(yin), None
+        row = x @ f64(w['qkv']).T + f64(bias['qkv'])
+        cache[pos] = row[0].float()
+        C = f64(cache[:pos + 1])
+        C[pos] = row[0]
+        ctx, _ = attend(row[:, :d], C[:, d:2 * d], C[:, 2 * d:], smask)
+        ys = torch.cat([x, ctx], 1) @ f64(w['os']).T + f64(bias['os'])
+        x1 = LN(LN(ys, lns['sa']) + x, lns['sa_last'])
+        qc = x1 @ f64(w['qc']).T + f64(bias['qc'])
+        ctx2, aw = attend(qc, f64(enc[:, :d]), f64(enc[:, d:]), emask)
+        yc = torch.cat([x1, ctx2], 1) @ f64(w['oc']).T + f64(bias['oc'])
+        x2_ref = LN(yc + x1, lns['ca'])
+        y2_ref = x2_ref @ f64(w['ff']).T + f64(bias['ff'])
+        # one launch
+        y2 = torch.full((2, d), float('nan'), device=DEV)
+        x2 = torch.full((2, d), float('nan'), device=DEV)
+        attn = torch.full((1, H * Lk + 4), float('nan'), device=DEV)
+        ops.decoder_block_row(lin['qkv'], lin['os'], dev(lns['sa']), dev(lns['sa_last']), lin['qc'], lin['oc'], dev(lns['ca']), lin['ff'],
+                              cache_d, pos, enc_d[:, :d], enc_d[:, d:], y2[:1], x2[:1], x=None if ln is not None else yin.to(DEV), ln=ln,
+                              self_mask=smask.to(DEV), key_mask=emask.to(DEV), attn=attn[:, :H * Lk])
+        assert torch.isnan(y2[1:]).all() and torch.isnan(x2[1:]).all() and torch.isnan(attn[:, H * Lk:]).all()
+        rel = lambda a, b: (a.double().cpu() - b).abs().max().item() / b.abs().max().item()
+        assert rel(cache_d[pos:pos + 1], row) < 2e-5, (pos, 'cache row')
+        assert (attn[0, :H * Lk].view(H, Lk).double().cpu() - aw).abs().max().item() < 2e-5, (pos, 'weights')
+        assert rel(x2[:1], x2_ref) < 5e-5, (pos, 'x2', rel(x2[:1], x2_ref))
+        assert rel(y2[:1], y2_ref) < 5e-5, (pos, 'y2', rel(y2[:1], y2_ref))
+        cache_d[pos] = cache[pos].to(DEV)      # both sides go on from the same cache
+    assert not torch.equal(cache_d[:1], torch.zeros_like(cache_d[:1]))

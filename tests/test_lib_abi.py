@@ -45,7 +45,7 @@ def test_struct_sizes_match_header_layout(tmp_path):
              'estts_wavernn_sample_args': _lib.WavernnSampleArgs, 'estts_wavernn_unfold_args': _lib.WavernnUnfoldArgs, 'estts_wavernn_layer_args': _lib.WavernnLayerArgs, 'estts_wavernn_cond_args': _lib.WavernnCondArgs, 'estts_wgrad_args': _lib.WgradArgs,
              'estts_attention_bwd_args': _lib.AttentionBwdArgs, 'estts_rownorm_bwd_args': _lib.RownormBwdArgs,
              'estts_colreduce_args': _lib.ColreduceArgs, 'estts_wavernn_prep_bwd_args': _lib.WavernnPrepBwdArgs, 'estts_rowmask_args': _lib.RowmaskArgs,
-             'estts_prog_op': _lib.ProgOp, 'estts_pack_job': _lib.PackJob, 'estts_cross_row_args': _lib.CrossRowArgs}
+             'estts_prog_op': _lib.ProgOp, 'estts_pack_job': _lib.PackJob, 'estts_cross_row_args': _lib.CrossRowArgs, 'estts_decoder_block_args': _lib.DecoderBlockArgs}
     src = tmp_path / 'sizes.c'
     src.write_text('#include <stdio.h>\n#include "estts.h"\nint main(void) {\n' +
                    ''.join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + '  return 0;\n}\n')
@@ -90,17 +90,18 @@ def test_deferred_sum_arguments_are_validated_before_any_launch():
     assert lib.estts_gemm(g, None) != 0 and 'stat_slots' in err()
 
 
-def test_cross_row_field_offsets_match_header_layout(tmp_path):
-    """Every field of the ctypes mirror of estts_cross_row_args sits where the C compiler puts it (a step program patches this
-    block by byte offset)."""
+@pytest.mark.parametrize('cname,cls', [('estts_cross_row_args', _lib.CrossRowArgs), ('estts_decoder_block_args', _lib.DecoderBlockArgs)])
+def test_row_kernel_field_offsets_match_header_layout(tmp_path, cname, cls):
+    """Every field of the ctypes mirrors of the decoder-row argument blocks sits where the C compiler puts it (a step program
+    patches these blocks by byte offset)."""
     import subprocess
-    names = [n for n, _ in _lib.CrossRowArgs._fields_]
+    names = [n for n, _ in cls._fields_]
     src = tmp_path / 'offsets.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "estts.h"\nint main(void) {\n' +
-                   ''.join(f'  printf("{n} %zu\\n", offsetof(estts_cross_row_args, {n}));\n' for n in names) + '  return 0;\n}\n')
+                   ''.join(f'  printf("{n} %zu\\n", offsetof({cname}, {n}));\n' for n in names) + '  return 0;\n}\n')
     exe = tmp_path / 'offsets'
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     offsets = dict(line.split() for line in out.strip().splitlines())
     for n in names:
-        assert getattr(_lib.CrossRowArgs, n).offset == int(offsets[n]), n
+        assert getattr(cls, n).offset == int(offsets[n]), n
