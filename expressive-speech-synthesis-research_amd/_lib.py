@@ -10,7 +10,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libestts.so')
 
-ABI_VERSION = 35
+ABI_VERSION = 36
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 ACT = {None: ACT_NONE, 'linear': ACT_NONE, 'none': ACT_NONE, 'relu': ACT_RELU, 'tanh': ACT_TANH}
 
@@ -109,6 +109,15 @@ class DecoderBlockArgs(C.Structure):
                 ('ws', _vp), ('ws_bytes', _i64), ('counters', _vp), ('n_counters', _i32), ('M', _i32), ('d', _i32), ('H', _i32)]
 
 
+class PrenetRowArgs(C.Structure):
+    _fields_ = [('x', _vp), ('ldx', _i32), ('C', _i32), ('mask', _vp),
+                ('w1_hi', _vp), ('w1_lo', _vp), ('ldw1', _i32), ('b1', _vp), ('N1', _i32),
+                ('w2_hi', _vp), ('w2_lo', _vp), ('ldw2', _i32), ('b2', _vp), ('N2', _i32),
+                ('alpha', _f32), ('R', _vp), ('ldr', _i32),
+                ('drop_rate', _f32), ('drop_seed', _u32), ('drop_site1', _u32), ('drop_site2', _u32), ('drop_row0', _i32),
+                ('out', _vp), ('ldo', _i32), ('M', _i32)]
+
+
 class ProgOp(C.Structure):
     _fields_ = [('kind', _i32), ('n_patch', _i32), ('args', _vp), ('patch_offset', _i32 * PROG_MAX_PATCH),
                 ('patch_is_ptr', _i32 * PROG_MAX_PATCH), ('patch_stride', _i64 * PROG_MAX_PATCH)]
@@ -186,6 +195,7 @@ SIGNATURES = {
     'estts_row_zero_mask': (_i32, [_vp, _i32, _vp, _i32, _i32, _vp]),
     'estts_cross_attention_row': (_i32, [C.POINTER(CrossRowArgs), _vp]),
     'estts_decoder_block_row': (_i32, [C.POINTER(DecoderBlockArgs), _vp]),
+    'estts_prenet_row': (_i32, [C.POINTER(PrenetRowArgs), _vp]),
     'estts_masked_mae': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp]),
     'estts_wavernn_prep': (_i32, [C.POINTER(WavernnPrepArgs), _vp]),
     'estts_gru_gates': (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp]),

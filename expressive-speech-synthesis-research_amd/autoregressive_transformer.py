@@ -424,12 +424,18 @@ class AutoregressiveTransformer:
         block_row = [fuse and self.fuse_decoder_block and isinstance(ff, FFNLayer) and ff.fold and sa.heads == ca.heads and
                      ops.can_decoder_block_row(sa.qkv, sa.out, ca.wq, ca.out, ff.d12, d, sa.heads, S, N, pr) for sa, ca, ff in blocks]
 
+        prenet_row = fuse and self.fuse_decoder_block and d == 256 and ops.can_prenet_row(self.prenet1, self.prenet2, C, pr)
+
         def step(i):
             frame = frames[r - 1 + i * r:r + i * r]
-            ops.row_zero_mask(frame, dec_mask[0, i:i + 1])
-            ops.gemm(frame, self.prenet1, p1, precision=pr, dropout=(rate, seed, 0, i))
-            ops.gemm(p1, self.prenet2, xc[:, :d], alpha=sqrt_d, residual=self.pe_dec[i * r:i * r + 1], precision=pr,
-                     dropout=(rate, seed, 1, i))
+            if prenet_row:
+                ops.prenet_row(frame, dec_mask[0, i:i + 1], self.prenet1, self.prenet2, xc[:, :d], alpha=sqrt_d,
+                               residual=self.pe_dec[i * r:i * r + 1], dropout=(rate, seed, 0, 1, i))
+            else:
+                ops.row_zero_mask(frame, dec_mask[0, i:i + 1])
+                ops.gemm(frame, self.prenet1, p1, precision=pr, dropout=(rate, seed, 0, i))
+                ops.gemm(p1, self.prenet2, xc[:, :d], alpha=sqrt_d, residual=self.pe_dec[i * r:i * r + 1], precision=pr,
+                         dropout=(rate, seed, 1, i))
             pending = None
             for b, (sa, ca, ff) in enumerate(blocks):
                 if block_row[b]:

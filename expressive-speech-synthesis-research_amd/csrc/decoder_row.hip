@@ -644,6 +644,87 @@ __global__ __launch_bounds__(1024) void decoder_block_row_kernel(const estts_dec
     DB_STAMP(11);
 }
 
+
+// ======================================================================================================
+// The decoder's pre-net for one position in one launch (estts_prenet_row)
+// ======================================================================================================
+// mask = (the frame is all zeros);  p1 = drop(relu(frame W1 + b1));  out = alpha drop(relu(p1 W2 + b2)) + R
+// (TransformerTTS/model/layers.py:394-402, the padding mask of model/transformer_utils.py:47-50, and the positional encoding
+// added by the caller in AutoregressiveTransformer._call_decoder).  Three launches of one row each in an incremental decoder.
+// Four workgroups per row; each computes all 256 units of the first layer (82 KB of weights at 80 mel channels) and its own 64
+// columns of the second (64 KB), so they share nothing and need no barrier.  Operands requested up front, as above.
+__global__ __launch_bounds__(1024) void prenet_row_kernel(const estts_prenet_row_args p) {
+    __shared__ __attribute__((aligned(16))) float fr[128], b1s[CR_D], b2s[64], rs[64];
+    __shared__ __attribute__((aligned(16))) __bf16 xh[128], xl[128], ph[CR_D], pl[CR_D];
+    __shared__ float qp[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x, row = blockIdx.y;
+    const int nkb1 = p.ldw1 >> 5;      // <= 4
+    uint4 w1h[4], w1l[4];              // block row `wave` of W1
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        w1h[kb] = w1l[kb] = make_uint4(0u, 0u, 0u, 0u);
+        if (kb < nkb1) {
+            const long base = ((long)wave * nkb1 + kb) * 512 + lane * 8;
+            w1h[kb] = *reinterpret_cast<const uint4*>(p.w1_hi + base);
+            w1l[kb] = *reinterpret_cast<const uint4*>(p.w1_lo + base);
+        }
+    }
+    const int qn = wave & 3, qk = wave >> 2;
+    uint4 w2h[2], w2l[2];              // W2: block row qn of this workgroup's 64 columns, quarter qk of p1
+    {
+        const long base = ((long)(4 * s + qn) * (p.ldw2 >> 5) + 2 * qk) * 512 + lane * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            w2h[i] = *reinterpret_cast<const uint4*>(p.w2_hi + base + i * 512);
+            w2l[i] = *reinterpret_cast<const uint4*>(p.w2_lo + base + i * 512);
+        }
+    }
+    if (wave == 0) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 32 && 4 * lane < p.C) v = ld4g(p.x + (long)row * p.ldx + 4 * lane);
+        if (lane < 32) *reinterpret_cast<float4*>(fr + 4 * lane) = v;
+    } else if (wave == 1) {
+        *reinterpret_cast<float4*>(b1s + 4 * lane) = p.b1 ? ld4g(p.b1 + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (wave == 2) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 16) { if (p.b2) v = ld4g(p.b2 + 64 * s + 4 * lane); *reinterpret_cast<float4*>(b2s + 4 * lane) = v; }
+        else if (lane < 32) { if (p.R) v = ld4g(p.R + (long)row * p.ldr + 64 * s + 4 * (lane - 16)); *reinterpret_cast<float4*>(rs + 4 * (lane - 16)) = v; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < 32) v = *reinterpret_cast<const float4*>(fr + 4 * lane);
+        const float a = wave_sum(fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w));
+        if (p.mask && s == 0 && lane == 0) p.mask[row] = a == 0.0f ? 1.0f : 0.0f;
+        if (lane < 32) put_split4(v, xh, xl, lane);
+    }
+    __syncthreads();
+    const float keep_scale = p.drop_rate > 0.0f ? 1.0f / (1.0f - p.drop_rate) : 1.0f;
+    {
+        const float a = dot16<4>(w1h, w1l, xh, xl, lane);
+        if (lane < 16) {
+            const int col = 16 * wave + lane;
+            float v = fmaxf(a + b1s[col], 0.0f);
+            if (p.drop_rate > 0.0f) v = dropout_keep(p.drop_seed, p.drop_site1, (uint32_t)(p.drop_row0 + row), (uint32_t)col, p.drop_rate) ? v / (1.0f - p.drop_rate) : 0.0f;
+            put_split(v, ph, pl, col);
+        }
+    }
+    (void)keep_scale;
+    __syncthreads();
+    {
+        const float a = dot16<2>(w2h, w2l, ph + 64 * qk, pl + 64 * qk, lane);
+        if (lane < 16) qp[qk][16 * qn + lane] = a;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int col = 64 * s + tid;
+        float v = fmaxf(((qp[0][tid] + qp[1][tid]) + (qp[2][tid] + qp[3][tid])) + b2s[tid], 0.0f);
+        if (p.drop_rate > 0.0f) v = dropout_keep(p.drop_seed, p.drop_site2, (uint32_t)(p.drop_row0 + row), (uint32_t)col, p.drop_rate) ? v / (1.0f - p.drop_rate) : 0.0f;
+        p.out[(long)row * p.ldo + col] = v * p.alpha + rs[tid];
+    }
+}
+
 }  // namespace
 
 extern "C" int estts_cross_attention_row(const estts_cross_row_args* args, void* stream) {
@@ -718,5 +799,21 @@ extern "C" int estts_decoder_block_row(const estts_decoder_block_args* args, voi
     else if (enc2) ESTTS_LAUNCH((decoder_block_row_kernel<4, 2>), grid, dim3(1024), 0, st, a);
     else ESTTS_LAUNCH((decoder_block_row_kernel<4, 4>), grid, dim3(1024), 0, st, a);
     ESTTS_CHECK_LAUNCH("estts_decoder_block_row");
+    return 0;
+}
+
+extern "C" int estts_prenet_row(const estts_prenet_row_args* args, void* stream) {
+    ESTTS_CHECK_ARG(args != nullptr, "estts_prenet_row: null args");
+    const estts_prenet_row_args& a = *args;
+    ESTTS_CHECK_ARG(a.M > 0 && a.M <= 65535 && a.C > 0 && a.C <= 128 && (a.C & 3) == 0 && a.N1 == CR_D && a.N2 == CR_D,
+                    "estts_prenet_row: this kernel takes frames of at most 128 channels (a multiple of 4) and two layers of 256 units (got %d, %d, %d)", a.C, a.N1, a.N2);
+    ESTTS_CHECK_ARG(a.x && a.w1_hi && a.w1_lo && a.w2_hi && a.w2_lo && a.out, "estts_prenet_row: null operand");
+    ESTTS_CHECK_ARG(a.ldw1 >= a.C && (a.ldw1 & 63) == 0 && a.ldw1 <= 128 && a.ldw2 >= CR_D && (a.ldw2 & 63) == 0, "estts_prenet_row: ldw must be K rounded up to 64");
+    ESTTS_CHECK_ARG((((uintptr_t)a.x | (uintptr_t)a.w1_hi | (uintptr_t)a.w1_lo | (uintptr_t)a.w2_hi | (uintptr_t)a.w2_lo | (uintptr_t)a.b1 | (uintptr_t)a.b2 |
+                      (uintptr_t)a.R) & 15) == 0 && ((a.ldx | a.ldr) & 3) == 0 && a.ldx >= a.C && a.ldo >= CR_D && (!a.R || a.ldr >= CR_D),
+                    "estts_prenet_row: operands must be 16-byte aligned with row strides that are multiples of 4");
+    ESTTS_CHECK_ARG(a.drop_rate >= 0.0f && a.drop_rate < 1.0f, "estts_prenet_row: dropout rate must be in [0, 1)");
+    ESTTS_LAUNCH(prenet_row_kernel, dim3(4, a.M), dim3(1024), 0, (hipStream_t)stream, a);
+    ESTTS_CHECK_LAUNCH("estts_prenet_row");
     return 0;
 }

@@ -467,12 +467,14 @@ extern "C" int estts_run_program(const estts_prog_op* ops, int32_t n_ops, int32_
         estts_rowmask_args m;
         estts_cross_row_args c;
         estts_decoder_block_args d;
+        estts_prenet_row_args p;
     } blk;
-    static const size_t sizes[6] = {sizeof(estts_gemm_args), sizeof(estts_attention_args), sizeof(estts_rownorm_args),
-                                    sizeof(estts_rowmask_args), sizeof(estts_cross_row_args), sizeof(estts_decoder_block_args)};
+    static const size_t sizes[7] = {sizeof(estts_gemm_args), sizeof(estts_attention_args), sizeof(estts_rownorm_args),
+                                    sizeof(estts_rowmask_args), sizeof(estts_cross_row_args), sizeof(estts_decoder_block_args),
+                                    sizeof(estts_prenet_row_args)};
     for (int i = 0; i < n_ops; ++i) {
         const estts_prog_op& op = ops[i];
-        ESTTS_CHECK_ARG(op.kind >= 0 && op.kind < 6 && op.args && op.n_patch >= 0 && op.n_patch <= ESTTS_PROG_MAX_PATCH,
+        ESTTS_CHECK_ARG(op.kind >= 0 && op.kind < 7 && op.args && op.n_patch >= 0 && op.n_patch <= ESTTS_PROG_MAX_PATCH,
                         "estts_run_program: op %d is malformed", i);
         memcpy(&blk, op.args, sizes[op.kind]);
         char* base = reinterpret_cast<char*>(&blk);
@@ -498,6 +500,7 @@ extern "C" int estts_run_program(const estts_prog_op* ops, int32_t n_ops, int32_
             case 2: rc = estts_rownorm(&blk.r, stream); break;
             case 4: rc = estts_cross_attention_row(&blk.c, stream); break;
             case 5: rc = estts_decoder_block_row(&blk.d, stream); break;
+            case 6: rc = estts_prenet_row(&blk.p, stream); break;
             default: rc = estts_row_zero_mask(blk.m.x, blk.m.ldx, blk.m.mask, blk.m.M, blk.m.D, stream); break;
         }
         if (rc != 0) return rc;

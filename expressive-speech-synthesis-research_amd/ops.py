@@ -97,7 +97,7 @@ class StepProgram:
     (estts_run_program).  Built by recording the same Python code for step 0 and step 1: every argument field that
     differs between the two recordings becomes a patch `field += step * (value1 - value0)`."""
 
-    KINDS = {'gemm': 0, 'attention': 1, 'rownorm': 2, 'row_zero_mask': 3, 'cross_attention_row': 4, 'decoder_block_row': 5}
+    KINDS = {'gemm': 0, 'attention': 1, 'rownorm': 2, 'row_zero_mask': 3, 'cross_attention_row': 4, 'decoder_block_row': 5, 'prenet_row': 6}
 
     def __init__(self, record_step):
         """record_step(i): issues the launches of step i through this module's op functions."""
@@ -481,6 +481,42 @@ def cross_attention_row(wq, wo, k, v, y, heads, x=None, ln=None, key_mask=None, 
                                     'bytes': 4.0 * (nw * d * d + 2 * Lk * d) + 4.0 * M * (3 * d + heads * Lk)},
             _lib.load().estts_cross_attention_row, a, keep=a._keep)
     return y
+
+
+def can_prenet_row(lin1, lin2, C, precision='bf16x3'):
+    """True when prenet_row() can take the pre-net: at most 128 input channels, two plain dense layers of 256 units with ReLU,
+    split operands."""
+    plain = all(l.taps == 1 and l.act == ACT['relu'] and l.s1 is None and l.s2 is None for l in (lin1, lin2))
+    return (plain and precision_at(precision, None) == 'bf16x3' and C % 4 == 0 and 0 < C <= 128 and (lin1.N, lin1.K) == (256, C) and
+            (lin2.N, lin2.K) == (256, 256))
+
+
+def prenet_row(x, mask, lin1, lin2, out, alpha=1.0, residual=None, dropout=None):
+    """The decoder's pre-net for one position per row of x in one launch (estts_prenet_row; see can_prenet_row): mask[m] = the
+    frame is all zeros, out = alpha * drop(relu(drop(relu(x W1 + b1)) W2 + b2)) + residual.  dropout = (rate, seed, site of the
+    first layer, site of the second, row0) with the generator of gemm(dropout=...)."""
+    a = _lib.PrenetRowArgs()
+    _check_f32(x, 'x')
+    _check_f32(out, 'out')
+    a.x, a.ldx, a.C = x.data_ptr(), x.stride(0), x.shape[1]
+    a.mask = _ptr(mask)
+    a.w1_hi, a.w1_lo, a.ldw1, a.b1, a.N1 = lin1.w_hi.data_ptr(), lin1.w_lo.data_ptr(), lin1.ldw, _ptr(lin1.b1), lin1.N
+    a.w2_hi, a.w2_lo, a.ldw2, a.b2, a.N2 = lin2.w_hi.data_ptr(), lin2.w_lo.data_ptr(), lin2.ldw, _ptr(lin2.b1), lin2.N
+    a.alpha = alpha
+    if residual is not None:
+        _check_f32(residual, 'residual')
+        a.R, a.ldr = residual.data_ptr(), residual.stride(0)
+    if dropout is not None and dropout[0] > 0.0:
+        a.drop_rate, a.drop_seed, a.drop_site1, a.drop_site2, a.drop_row0 = dropout
+    a.out, a.ldo, a.M = out.data_ptr(), out.stride(0), x.shape[0]
+    a._keep = (x, mask, lin1, lin2, out, residual)
+    if _program is not None:
+        _program.append(('prenet_row', a, a._keep))
+        return out
+    check(_lib.load().estts_prenet_row(a, _stream()), 'estts_prenet_row')
+    _record('prenet_row', {'M': a.M, 'C': a.C, 'flops': 2.0 * a.M * 256 * (a.C + 256), 'bytes': 4.0 * 256 * (a.C + 256) + 4.0 * a.M * (a.C + 513)},
+            _lib.load().estts_prenet_row, a, keep=a._keep)
+    return out
 
 
 _block_counters = {}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ESTTS_ABI_VERSION 35
+#define ESTTS_ABI_VERSION 36
 
 /* activation codes for estts_gemm / estts_rownorm */
 #define ESTTS_ACT_NONE 0
@@ -859,6 +859,28 @@ typedef struct estts_decoder_block_args {
 int estts_decoder_block_row(const estts_decoder_block_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The decoder's pre-net for one position per row in one launch (TransformerTTS/model/layers.py:394-402 with the padding mask
+ * of model/transformer_utils.py:47-50), for incremental decoding.  Per row m < M:
+ *   mask[m] = all C channels of x[m] are zero ? 1 : 0                                  (mask may be NULL)
+ *   p1  = drop_1(relu(x[m] W1 + b1));      out[m] = alpha * drop_2(relu(p1 W2 + b2)) + R[m]        (R may be NULL)
+ * drop_s(v)[n] = keep(drop_seed, drop_site_s, drop_row0 + m, n) ? v[n] / (1 - drop_rate) : 0, the generator of estts_gemm, so
+ * the result is estts_row_zero_mask + two estts_gemm launches with the same dropout arguments, up to float32 summation order.
+ * W1 [256, C] and W2 [256, 256] in the packed bf16 hi + lo layout of estts_gemm; C <= 128, a multiple of 4.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct estts_prenet_row_args {
+    const float* x; int32_t ldx; int32_t C;
+    float* mask;
+    const uint16_t* w1_hi; const uint16_t* w1_lo; int32_t ldw1; const float* b1; int32_t N1;
+    const uint16_t* w2_hi; const uint16_t* w2_lo; int32_t ldw2; const float* b2; int32_t N2;
+    float alpha; const float* R; int32_t ldr;
+    float drop_rate; uint32_t drop_seed, drop_site1, drop_site2; int32_t drop_row0;
+    float* out; int32_t ldo;
+    int32_t M;
+} estts_prenet_row_args;
+
+int estts_prenet_row(const estts_prenet_row_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Step programs: a fixed sequence of launches whose arguments depend affinely on a step index (an incremental decoder:
  * row i of a cache, a key range of i + 1, ...).  Each op carries the argument block of step 0 and a patch list; at step s
  * the field at byte `offset` of a copy of the block is advanced by s * stride (a pointer, in bytes, or an int32), then the
@@ -866,7 +888,7 @@ int estts_decoder_block_row(const estts_decoder_block_args* args, void* stream);
  * in the host language.  No counterpart in the reference (its loop, model/AutoregressiveTransformer.py:279-296, re-runs
  * the whole Keras decoder every step).
  * kind: 0 estts_gemm, 1 estts_attention, 2 estts_rownorm, 3 estts_row_zero_mask (args = estts_rowmask_args),
- * 4 estts_cross_attention_row.
+ * 4 estts_cross_attention_row, 5 estts_decoder_block_row, 6 estts_prenet_row.
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_rowmask_args {
     const float* x; int32_t ldx;

@@ -847,3 +847,32 @@ def test_decoder_block_row_is_the_block_of_the_reference_for_one_position(Lk, po
         assert rel(y2[:1], y2_ref) < 5e-5, (pos, 'y2', rel(y2[:1], y2_ref))
         cache_d[pos] = cache[pos].to(DEV)      # both sides go on from the same cache
     assert not torch.equal(cache_d[:1], torch.zeros_like(cache_d[:1]))
+
+
+@pytest.mark.parametrize('C,rate', [(80, 0.0), (80, 0.5), (128, 0.3), (4, 0.0)])
+def test_prenet_row_is_mask_and_two_dense_layers(C, rate):
+    # estts_prenet_row: the decoder pre-net of one position (layers.py:394-402: Dense + ReLU + Dropout twice, dropout on at
+    # inference too) with the padding mask of the frame (transformer_utils.py:47-50), scaled and added to a positional row, in
+    # one launch, against estts_row_zero_mask + two estts_gemm launches with the same dropout generator arguments
+    d = 256
+    g = 64000 + C
+    l1 = PackedLinear(_rand(d, C, seed=g, scale=1 / np.sqrt(C)).numpy(), bias=_rand(d, seed=g + 1).numpy() * 0.2, device=DEV, act='relu')
+    l2 = PackedLinear(_rand(d, d, seed=g + 2, scale=1 / 16).numpy(), bias=_rand(d, seed=g + 3).numpy() * 0.2, device=DEV, act='relu')
+    assert ops.can_prenet_row(l1, l2, C) and not ops.can_prenet_row(l1, l2, C + 4)
+    frames = _rand(5, C, seed=g + 4).to(DEV)
+    frames[2] = 0.0
+    pe = _rand(5, d, seed=g + 5).to(DEV)
+    for i in range(5):
+        x = frames[i:i + 1]
+        mask_ref, p1, ref = torch.full((1,), -1.0, device=DEV), torch.empty(1, d, device=DEV), torch.empty(1, d, device=DEV)
+        ops.row_zero_mask(x, mask_ref)
+        ops.gemm(x, l1, p1, dropout=(rate, 1234, 0, i))
+        ops.gemm(p1, l2, ref, alpha=16.0, residual=pe[i:i + 1], dropout=(rate, 1234, 1, i))
+        mask, out = torch.full((2,), -1.0, device=DEV), torch.full((2, d + 4), float('nan'), device=DEV)
+        ops.prenet_row(x, mask[:1], l1, l2, out[:1, :d], alpha=16.0, residual=pe[i:i + 1], dropout=(rate, 1234, 0, 1, i))
+        assert mask[0].item() == mask_ref[0].item() == (1.0 if i == 2 else 0.0) and mask[1].item() == -1.0
+        assert torch.isnan(out[1:]).all() and torch.isnan(out[:, d:]).all()
+        err = (out[:1, :d] - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 3e-5, (C, rate, i, err)
+        if rate > 0:      # the same units were dropped
+            assert torch.equal(out[:1, :d] == pe[i:i + 1], ref == pe[i:i + 1])

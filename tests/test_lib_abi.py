@@ -45,7 +45,7 @@ def test_struct_sizes_match_header_layout(tmp_path):
              'estts_wavernn_sample_args': _lib.WavernnSampleArgs, 'estts_wavernn_unfold_args': _lib.WavernnUnfoldArgs, 'estts_wavernn_layer_args': _lib.WavernnLayerArgs, 'estts_wavernn_cond_args': _lib.WavernnCondArgs, 'estts_wgrad_args': _lib.WgradArgs,
              'estts_attention_bwd_args': _lib.AttentionBwdArgs, 'estts_rownorm_bwd_args': _lib.RownormBwdArgs,
              'estts_colreduce_args': _lib.ColreduceArgs, 'estts_wavernn_prep_bwd_args': _lib.WavernnPrepBwdArgs, 'estts_rowmask_args': _lib.RowmaskArgs,
-             'estts_prog_op': _lib.ProgOp, 'estts_pack_job': _lib.PackJob, 'estts_cross_row_args': _lib.CrossRowArgs, 'estts_decoder_block_args': _lib.DecoderBlockArgs}
+             'estts_prog_op': _lib.ProgOp, 'estts_pack_job': _lib.PackJob, 'estts_cross_row_args': _lib.CrossRowArgs, 'estts_decoder_block_args': _lib.DecoderBlockArgs, 'estts_prenet_row_args': _lib.PrenetRowArgs}
     src = tmp_path / 'sizes.c'
     src.write_text('#include <stdio.h>\n#include "estts.h"\nint main(void) {\n' +
                    ''.join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + '  return 0;\n}\n')
@@ -90,7 +90,8 @@ def test_deferred_sum_arguments_are_validated_before_any_launch():
     assert lib.estts_gemm(g, None) != 0 and 'stat_slots' in err()
 
 
-@pytest.mark.parametrize('cname,cls', [('estts_cross_row_args', _lib.CrossRowArgs), ('estts_decoder_block_args', _lib.DecoderBlockArgs)])
+@pytest.mark.parametrize('cname,cls', [('estts_cross_row_args', _lib.CrossRowArgs), ('estts_decoder_block_args', _lib.DecoderBlockArgs),
+                                       ('estts_prenet_row_args', _lib.PrenetRowArgs)])
 def test_row_kernel_field_offsets_match_header_layout(tmp_path, cname, cls):
     """Every field of the ctypes mirrors of the decoder-row argument blocks sits where the C compiler puts it (a step program
     patches these blocks by byte offset)."""
