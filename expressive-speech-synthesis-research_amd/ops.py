@@ -543,11 +543,12 @@ def can_decoder_block_row(wqkv, wos, wqc, woc, wff, d, heads, max_pos, Lk, preci
 
 def decoder_block_row(wqkv, wos, sa_ln, sa_last_ln, wqc, woc, ca_ln, wff, cache, pos, k, v, y2, x2, x=None, ln=None, self_mask=None,
                       key_mask=None, attn=None, eps=1e-6):
-    """One decoder position (row 0 of x, or of the pending normalisation ln = dict(y=, x=, ln_a=, act=, ln_b=) as in gemm(ln=...))
-    through self-attention, cross-attention and the folded feed-forward product of a block in one launch
-    (estts_decoder_block_row; see can_decoder_block_row).  cache: [S, 3 d] rows q | k | v of the decoder positions, row `pos`
-    is written; k / v: [Lk, >= d] encoder keys / values; self_mask: [1, > pos], key_mask: [1, Lk], attn: [1, heads * Lk] view or
-    None.  Writes y2 (the product) and x2 (its residual): the block's output is LN(relu(LN(y2)) + x2), left to the consumer."""
+    """One decoder position per utterance (the M rows of x, or of the pending normalisation ln = dict(y=, x=, ln_a=, act=, ln_b=)
+    as in gemm(ln=...)) through self-attention, cross-attention and the folded feed-forward product of a block in one launch
+    (estts_decoder_block_row; see can_decoder_block_row).  cache: [S, 3 d] rows q | k | v of the decoder positions ([M, S, 3 d]
+    for M > 1), row `pos` is written; k / v: [Lk, >= d] encoder keys / values ([M, Lk, >= d] views of one tensor for M > 1);
+    self_mask: [M, > pos], key_mask: [M, Lk] contiguous, attn: [M, heads * Lk] view or None.  Writes y2 (the product) and x2
+    (its residual), [M, d]: the block's output is LN(relu(LN(y2)) + x2), left to the consumer."""
     a = _lib.DecoderBlockArgs()
     d = wos.N
     if ln is not None:
@@ -569,13 +570,19 @@ def decoder_block_row(wqkv, wos, sa_ln, sa_last_ln, wqc, woc, ca_ln, wff, cache,
     for t, n in ((cache, 'cache'), (k, 'k'), (v, 'v'), (y2, 'y2'), (x2, 'x2')):
         _check_f32(t, n)
     a.wqkv_hi, a.wqkv_lo, a.ldwqkv, a.bqkv = wqkv.w_hi.data_ptr(), wqkv.w_lo.data_ptr(), wqkv.ldw, _ptr(wqkv.b1)
-    a.qkv, a.ldqkv, a.qkv_batch_stride, a.pos = cache.data_ptr(), cache.stride(0), 0, pos
+    M = y2.shape[0]
+    if M > 64 or (M > 1 and (cache.dim() != 3 or k.dim() != 3 or v.dim() != 3 or k.stride(0) != v.stride(0))):
+        raise ValueError('decoder_block_row: at most 64 rows; with more than one, cache / k / v carry a leading batch dimension')
+    a.qkv, a.ldqkv, a.qkv_batch_stride, a.pos = cache.data_ptr(), cache.stride(-2), cache.stride(0) if cache.dim() == 3 else 0, pos
     if self_mask is not None:
         a.self_mask, a.self_mask_stride = self_mask.data_ptr(), self_mask.stride(0)
     a.wos_hi, a.wos_lo, a.ldwos, a.bos = wos.w_hi.data_ptr(), wos.w_lo.data_ptr(), wos.ldw, _ptr(wos.b1)
     a.sa_ga, a.sa_ba, a.sa_gb, a.sa_bb = (sa_ln[0].data_ptr(), sa_ln[1].data_ptr(), sa_last_ln[0].data_ptr(), sa_last_ln[1].data_ptr())
     a.wqc_hi, a.wqc_lo, a.ldwqc, a.bqc = wqc.w_hi.data_ptr(), wqc.w_lo.data_ptr(), wqc.ldw, _ptr(wqc.b1)
-    a.k, a.v, a.ldk, a.ldv, a.kv_batch_stride, a.Lk = k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0), 0, k.shape[0]
+    a.k, a.v, a.ldk, a.ldv, a.kv_batch_stride, a.Lk = (k.data_ptr(), v.data_ptr(), k.stride(-2), v.stride(-2),
+                                                       k.stride(0) if k.dim() == 3 else 0, k.shape[-2])
+    if key_mask is not None and M > 1 and not (key_mask.is_contiguous() and tuple(key_mask.shape) == (M, k.shape[-2])):
+        raise ValueError('decoder_block_row: key_mask must be a contiguous [M, Lk] tensor')
     a.key_mask = _ptr(key_mask)
     if attn is not None:
         _check_f32(attn, 'attn')
@@ -587,14 +594,14 @@ def decoder_block_row(wqkv, wos, sa_ln, sa_last_ln, wqc, woc, ca_ln, wff, cache,
     ws = (_ws_override if _ws_override is not None else gemm_workspace(y2.device))[0]
     cnt = _decoder_block_counters(y2.device)
     a.ws, a.ws_bytes, a.counters, a.n_counters = ws.data_ptr(), ws.numel() * 4, cnt.data_ptr(), cnt.numel()
-    a.M, a.d, a.H = 1, d, 4
+    a.M, a.d, a.H = M, d, 4
     a._keep = (x, ln, cache, k, v, y2, x2, self_mask, key_mask, attn, wqkv, wos, sa_ln, sa_last_ln, wqc, woc, ca_ln, wff, ws, cnt)
     if _program is not None:
         _program.append(('decoder_block_row', a, a._keep))
         return y2
     check(_lib.load().estts_decoder_block_row(a, _stream()), 'estts_decoder_block_row')
-    Lk = k.shape[0]
-    _record('decoder_block_row', {'M': 1, 'd': d, 'H': 4, 'Lk': Lk, 'pos': pos, 'flops': 2.0 * (8 * d * d + 2 * (Lk + pos + 1) * d),
+    Lk = k.shape[-2]
+    _record('decoder_block_row', {'M': M, 'd': d, 'H': 4, 'Lk': Lk, 'pos': pos, 'flops': 2.0 * (8 * d * d + 2 * (Lk + pos + 1) * d),
                                   'bytes': 4.0 * (8 * d * d + 2 * (Lk + pos + 1) * d) + 4.0 * (6 * d + 4 * Lk)},
             _lib.load().estts_decoder_block_row, a, keep=a._keep)
     return y2

@@ -876,3 +876,34 @@ def test_prenet_row_is_mask_and_two_dense_layers(C, rate):
         assert err < 3e-5, (C, rate, i, err)
         if rate > 0:      # the same units were dropped
             assert torch.equal(out[:1, :d] == pe[i:i + 1], ref == pe[i:i + 1])
+
+
+def test_decoder_block_row_takes_several_utterances_at_once():
+    # M rows = one position of M utterances, each with its own cache, encoder keys / values and masks: the same numbers as M
+    # launches of one row (the workgroups of a row only ever meet each other), also when launched twice on the same counters
+    d, H, Lk, S, M, pos = 256, 4, 70, 9, 3, 5
+    g = 65000
+    W = lambda n, k, s: _rand(n, k, seed=s, scale=1 / np.sqrt(k))
+    lin = {n: PackedLinear(W(*sh, g + i).numpy(), bias=_rand(sh[0], seed=g + 10 + i).numpy() * 0.3, device=DEV)
+           for i, (n, sh) in enumerate(dict(qkv=(3 * d, d), os=(d, 2 * d), qc=(d, d), oc=(d, 2 * d), ff=(d, d)).items())}
+    vec = lambda s: ((_rand(d, seed=s).abs() + 0.5).to(DEV), (_rand(d, seed=s + 1) * 0.3).to(DEV))
+    l1, l2, l3 = vec(g + 20), vec(g + 22), vec(g + 24)
+    cache0 = _rand(M, S, 3 * d, seed=g + 30).to(DEV)
+    enc = _rand(M, Lk, 2 * d, seed=g + 31).to(DEV)
+    smask = (torch.rand(M, S, generator=torch.Generator().manual_seed(g + 32)) < 0.2).float().to(DEV)
+    emask = (torch.rand(M, Lk, generator=torch.Generator().manual_seed(g + 33)) < 0.2).float().to(DEV)
+    emask[:, 0] = 0.0
+    x = _rand(M, d, seed=g + 34).to(DEV)
+    run = lambda cache, k, v, y2, x2, xx, sm, em, at: ops.decoder_block_row(
+        lin['qkv'], lin['os'], l1, l2, lin['qc'], lin['oc'], l3, lin['ff'], cache, pos, k, v, y2, x2, x=xx, self_mask=sm, key_mask=em, attn=at)
+    ref = []
+    for m in range(M):
+        c, y2, x2, at = cache0[m].clone(), torch.empty(1, d, device=DEV), torch.empty(1, d, device=DEV), torch.empty(1, H * Lk, device=DEV)
+        run(c, enc[m, :, :d], enc[m, :, d:], y2, x2, x[m:m + 1], smask[m:m + 1], emask[m:m + 1], at)
+        ref.append((c, y2, x2, at))
+    for _ in range(2):
+        c, y2, x2, at = cache0.clone(), torch.empty(M, d, device=DEV), torch.empty(M, d, device=DEV), torch.empty(M, H * Lk, device=DEV)
+        run(c, enc[:, :, :d], enc[:, :, d:], y2, x2, x, smask, emask, at)
+        for m in range(M):
+            assert torch.equal(c[m], ref[m][0]) and torch.equal(y2[m:m + 1], ref[m][1]) and torch.equal(x2[m:m + 1], ref[m][2])
+            assert torch.equal(at[m:m + 1], ref[m][3])
