@@ -417,16 +417,22 @@ class AutoregressiveTransformer:
         fuse = pr == 'bf16x3' and d % 8 == 0 and d <= 512 and self.fuse_step_norms
         cross_row = [self.fuse_cross_attention and ops.can_cross_attention_row(ca.wq, ca.out, d, ca.heads, N, pr) for _, ca, _ in blocks]
         # ... and a self-attention block's attention over its cache + output projection (the cache grows to S rows)
-        self_row = [self.fuse_cross_attention and ops.can_cross_attention_row(None, sa.out, d, sa.heads, S, pr) for sa, _, _ in blocks]
+        # Both row kernels hold the cache in registers, up to S_head rows: a longer utterance decodes its first S_head positions
+        # with them and the rest with the launches per layer (two step programs over the same buffers).
+        S_head = min(S, 256)
+        self_row = [self.fuse_cross_attention and ops.can_cross_attention_row(None, sa.out, d, sa.heads, S_head, pr) for sa, _, _ in blocks]
 
         # ... or the whole block (self-attention, cross-attention, folded feed-forward product): four workgroups per position
         # that meet at barriers of their own inside the kernel
         block_row = [fuse and self.fuse_decoder_block and isinstance(ff, FFNLayer) and ff.fold and sa.heads == ca.heads and
-                     ops.can_decoder_block_row(sa.qkv, sa.out, ca.wq, ca.out, ff.d12, d, sa.heads, S, N, pr) for sa, ca, ff in blocks]
+                     ops.can_decoder_block_row(sa.qkv, sa.out, ca.wq, ca.out, ff.d12, d, sa.heads, S_head, N, pr) for sa, ca, ff in blocks]
+        head_kernels = (self_row, block_row)
+        tail_kernels = ([False] * len(blocks), [False] * len(blocks))
 
         prenet_row = fuse and self.fuse_decoder_block and d == 256 and ops.can_prenet_row(self.prenet1, self.prenet2, C, pr)
 
         def step(i):
+            self_row, block_row = head_kernels if in_head[0] else tail_kernels
             frame = frames[r - 1 + i * r:r + i * r]
             if prenet_row:
                 ops.prenet_row(frame, dec_mask[0, i:i + 1], self.prenet1, self.prenet2, xc[:, :d], alpha=sqrt_d,
@@ -505,7 +511,12 @@ class AutoregressiveTransformer:
                      final[i * r:(i + 1) * r], residual=mel_rows, precision=pr)
 
         # every launch argument is affine in i: record steps 0 and 1 once, then issue each step from one C call
+        in_head = [True]
         prog = ops.StepProgram(step) if program and S >= 2 else None
+        prog_tail = None
+        if S > S_head:
+            in_head[0] = False
+            prog_tail = ops.StepProgram(step) if program else None
         # The reference asks the host after every step whether the stop token won (AutoregressiveTransformer.py:289-293).  Here the
         # steps are issued in groups and the stop rows of a group are read back together: the answer is the same (the first
         # step whose stop class wins ends the utterance; what was decoded past it is dropped), with one device-to-host wait
@@ -515,8 +526,10 @@ class AutoregressiveTransformer:
         while i < S and not done:
             n = min(group, S - i)
             for j in range(i, i + n):
-                if prog is not None:
-                    prog.run(j)
+                in_head[0] = j < S_head
+                pj = prog if in_head[0] else prog_tail
+                if pj is not None:
+                    pj.run(j)
                 else:
                     step(j)
             rows = stop[(i + 1) * r - 1:(i + n) * r:r].cpu()               # the last frame's stop logits of every step of the group

@@ -252,6 +252,84 @@ def test_step_program_equals_eager_launches():
         assert torch.equal(a, outs[1]['decoder_attention'][name])
 
 
+def wide_decoder_cfg(system_type):
+    """A decoder of the shipped width (256, 4 heads of depth 64, 256-unit pre-net, dense blocks): the shapes that the one-launch
+    kernels of the incremental decoder take (estts_prenet_row, estts_decoder_block_row, estts_cross_attention_row)."""
+    return configs.autoregressive_config(
+        system_type=system_type, encoder_model_dimension=64, decoder_model_dimension=256, encoder_prenet_dimension=64,
+        decoder_prenet_dimension=256, encoder_num_heads=[2, 2], decoder_num_heads=[4, 4], encoder_dense_blocks=2,
+        decoder_dense_blocks=2, encoder_feed_forward_dimension=96, decoder_feed_forward_dimension=160,
+        encoder_attention_conv_filters=80, decoder_attention_conv_filters=80, ref_encoder_filters=[8, 8, 16],
+        ref_encoder_gru_cell_units=32, gst_style_embed_dim=64, gst_multi_num_heads=2, gst_heads=5, speaker_embed_dim=16,
+        mel_channels=80, max_r=3, postnet_conv_filters=32, postnet_conv_layers=3, vocab_size=30,
+        encoder_max_position_encoding=64, decoder_max_position_encoding=640)
+
+
+def _wide_model(w, cfg, r, rows):
+    model = AutoregressiveTransformer(w, cfg)
+    model.set_constants(reduction_factor=r)
+    model.fuse_decoder_block = model.fuse_cross_attention = rows
+    return model
+
+
+@pytest.mark.parametrize('system_type,r,rate', [('speaker_text', 2, 0.0), ('style_text', 3, 0.5), ('text', 1, 0.0)])
+def test_decoder_row_kernels_change_nothing_at_the_shipped_width(system_type, r, rate):
+    """Incremental decoding at decoder width 256 with a position's pre-net and each decoder block as one launch (the default)
+    against the same steps with a launch per layer, and against the full re-decode of the reference's loop
+    (AutoregressiveTransformer.py:265-296); with the pre-net dropout on, the two incremental forms draw the same masks."""
+    from estts import _lib
+    cfg = wide_decoder_cfg(system_type)
+    w = weights.init_autoregressive_transformer(cfg, seed=31)
+    w['decoder_postnet.stop_linear.bias'] = np.array([5.0, 0.0, -5.0], np.float32)        # the stop class never wins
+    rng = np.random.default_rng(12)
+    tokens = rng.integers(1, cfg['vocab_size'], size=14)
+    spk = rng.normal(size=(1, cfg['speaker_embed_dim'])).astype(np.float32) if 'speaker' in system_type else None
+    ref_mel = rng.normal(size=(40, 80)).astype(np.float32) if 'style' in system_type else None
+    lib = _lib.load()
+    outs, launches = [], []
+    for rows in (True, False):
+        model = _wide_model(w, cfg, r, rows)
+        model.decoder_prenet_dropout = rate
+        n0 = lib.estts_launch_count()
+        outs.append(model._predict_incremental(tokens, ref_mel, spk, 9 * r, False, False, dropout_seed=77))
+        launches.append(lib.estts_launch_count() - n0)
+    a, b = outs
+    assert a['mel'].shape == b['mel'].shape == (10 * r, 80)
+    assert torch.isfinite(a['mel']).all()
+    # the row kernels add up a product in another order than the tiled kernels (and the loop feeds every frame back): measured
+    # 2e-5 .. 1.2e-4 on frames of magnitude 2 after ten steps
+    err = np.abs(a['mel'].cpu().numpy() - b['mel'].cpu().numpy()).max()
+    print(f'{system_type} r={r}: max |mel difference| {err:.2e}')
+    assert err < 3e-4
+    for name in a['decoder_attention']:
+        assert np.abs(a['decoder_attention'][name].cpu().numpy() - b['decoder_attention'][name].cpu().numpy()).max() < 1e-4
+    # per step: the pre-net 3 -> 1 launches, each of the two dense blocks 7 -> 1 (q | k | v, attention, projection, query,
+    # attention, projection, feed-forward product with their norms folded in)
+    assert launches[1] - launches[0] == 10 * (2 + 2 * 6), launches
+    if rate == 0.0:
+        c = _wide_model(w, cfg, r, True).predict(tokens, ref_mel, spk, max_length=9 * r, encode=False, verbose=False, kv_cache=False)
+        assert np.abs(a['mel'].cpu().numpy() - c['mel'].cpu().numpy()).max() < 3e-4
+
+
+def test_decoder_row_kernels_hand_over_to_the_layer_launches_past_256_positions():
+    """The row kernels hold a decoder cache of at most 256 rows: a longer utterance takes them for its first 256 positions and
+    the launches per layer for the rest (two step programs over the same buffers).  Same utterance as with a launch per layer
+    throughout, to the rounding of the different summation orders."""
+    cfg = wide_decoder_cfg('text')
+    w = weights.init_autoregressive_transformer(cfg, seed=33)
+    w['decoder_postnet.stop_linear.bias'] = np.array([5.0, 0.0, -5.0], np.float32)
+    tokens = np.random.default_rng(13).integers(1, cfg['vocab_size'], size=10)
+    outs = [_wide_model(w, cfg, 1, rows).predict(tokens, None, None, max_length=270, encode=False, verbose=False) for rows in (True, False)]
+    a, b = (o['mel'].cpu().numpy() for o in outs)
+    assert a.shape == b.shape == (271, 80) and np.isfinite(a).all()
+    err = np.abs(a - b).max(axis=1)
+    print('max |difference| by position: first 32 %.2e, 224-256 %.2e, last 15 %.2e' % (err[:32].max(), err[224:256].max(), err[256:].max()))
+    assert err.max() < 3e-4          # (measured 1.2e-4 early, 5e-5 .. 6e-5 around and past the hand-over)
+    for name in outs[0]['decoder_attention']:
+        x, y = outs[0]['decoder_attention'][name].cpu().numpy(), outs[1]['decoder_attention'][name].cpu().numpy()
+        assert x.shape == y.shape and np.abs(x - y).max() < 3e-4
+
+
 def _prenet_masks(rate, seed, rows, widths):
     """The scaled keep masks the device generator draws for sites 0 and 1 (rows = b * Tq + t)."""
     from estts import train_ops
