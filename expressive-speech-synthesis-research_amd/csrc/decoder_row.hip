@@ -700,7 +700,6 @@ __global__ __launch_bounds__(1024) void prenet_row_kernel(const estts_prenet_row
         if (lane < 32) put_split4(v, xh, xl, lane);
     }
     __syncthreads();
-    const float keep_scale = p.drop_rate > 0.0f ? 1.0f / (1.0f - p.drop_rate) : 1.0f;
     {
         const float a = dot16<4>(w1h, w1l, xh, xl, lane);
         if (lane < 16) {
@@ -710,7 +709,6 @@ __global__ __launch_bounds__(1024) void prenet_row_kernel(const estts_prenet_row
             put_split(v, ph, pl, col);
         }
     }
-    (void)keep_scale;
     __syncthreads();
     {
         const float a = dot16<2>(w2h, w2l, ph + 64 * qk, pl + 64 * qk, lane);
