@@ -183,6 +183,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_kernel(const estts_gemm_
 // LNCH > 0: the staged rows are not read from A but computed as LNb(act(LNa(ln_y)) + ln_x) (see estts_gemm_args.ln_y): one
 // wave per source row, LNCH float4 per lane (c_per_tap <= 256 LNCH), every operand of the wave's rows requested before the
 // first reduction; the workgroups of column tile 0 also write their own rows (not the halo) to ln_out.
+#ifdef ESTTS_ONESHOT_STAMPS
+// Diagnostic build (-DESTTS_ONESHOT_STAMPS, tools/oneshot_stamps.py): lane 0 of wave 0 of every workgroup of the convolution
+// kernel leaves the 100 MHz clock at its phase boundaries.  The marks cost registers (122 -> 139 at 600 x 512 x 768 with the
+// LayerNorm prologue, i.e. one workgroup per CU instead of two), so the kernel under test is not quite the shipped one.
+__device__ unsigned long long oneshot_stamps[1024][8];
+#define OS_STAMP(i) do { if (threadIdx.x == 0) oneshot_stamps[(blockIdx.x + gridDim.x * blockIdx.y) & 1023][i] = wall_clock64(); } while (0)
+}  // namespace
+extern "C" int estts_debug_oneshot_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(oneshot_stamps), sizeof(oneshot_stamps)); }
+namespace {
+#else
+#define OS_STAMP(i) do { } while (0)
+#endif
+
 template <int NSPLIT, int T, int NW, int S, int LNCH, bool LNA>
 __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_gemm_args p, const int rows_staged, const int lda_s) {
     constexpr int NS = (NSPLIT > 1) ? 2 : 1;
@@ -196,6 +209,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    OS_STAMP(0);
     const int i16 = lane & 15;
     const int g = lane >> 4;
     // (LayerNorm prologue: every column tile of a row tile re-reads that tile's y and x rows, so an L2 should hold a block of
@@ -305,6 +319,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
         // every request above is issued before anything below is scheduled: left alone, the compiler sinks the rows' loads to
         // their uses to save registers, and the wave then pays one memory round trip per row instead of one in all
         __builtin_amdgcn_sched_barrier(0);
+        OS_STAMP(1);
         const float inv_c = 1.0f / (float)C;
         const float floor_v = p.ln_act == ESTTS_ACT_RELU ? 0.0f : -INFINITY;
         // the rows of a wave are independent: each phase runs over all of them so that their reductions interleave
@@ -377,7 +392,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
             }
         }
     }
+    OS_STAMP(2);
     __syncthreads();
+    OS_STAMP(3);
 
     int a_pos[T];
 #pragma unroll
@@ -432,6 +449,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
         }
     }
 
+    OS_STAMP(4);
     __syncthreads();   // every wave is done with the A planes: the partial tiles take their place
 #pragma unroll
     for (int i = 0; i < T; ++i)
@@ -440,6 +458,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[(wave * NF + (i * T + j) * 4 + r) * 64 + lane] = acc[i][j][r];
     __syncthreads();
+    OS_STAMP(5);
 #pragma unroll
     for (int o = 0; o < OUTS; ++o) {
         const int f = wave + o * NW;
@@ -459,6 +478,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_oneshot_conv_kernel(const estts_
             }
         }
     }
+    OS_STAMP(6);
 }
 
 // Dynamic LDS beyond 64 KiB has to be allowed per kernel and device before the first launch.
