@@ -573,6 +573,9 @@ def decoder_block_row(wqkv, wos, sa_ln, sa_last_ln, wqc, woc, ca_ln, wff, cache,
     M = y2.shape[0]
     if M > 64 or (M > 1 and (cache.dim() != 3 or k.dim() != 3 or v.dim() != 3 or k.stride(0) != v.stride(0))):
         raise ValueError('decoder_block_row: at most 64 rows; with more than one, cache / k / v carry a leading batch dimension')
+    if not 0 <= pos < cache.shape[-2] or cache.shape[-1] < 3 * d or (self_mask is not None and self_mask.shape[-1] <= pos):
+        raise ValueError(f'decoder_block_row: position {pos} needs a cache of more than {pos} rows of {3 * d} columns and a self_mask '
+                         f'of more than {pos} columns')
     a.qkv, a.ldqkv, a.qkv_batch_stride, a.pos = cache.data_ptr(), cache.stride(-2), cache.stride(0) if cache.dim() == 3 else 0, pos
     if self_mask is not None:
         a.self_mask, a.self_mask_stride = self_mask.data_ptr(), self_mask.stride(0)
