@@ -790,8 +790,9 @@ int estts_mol_loss(const float* y_hat, int32_t ld, const float* y, float* loss, 
  * to (a row is read before it is written).  With q given the kernel is attention + output projection only: a self-attention
  * block's step after the product that wrote the position's q | k | v row (k / v = the cache up to and including it, Lk = the
  * position + 1; TransformerTTS/model/layers.py:217-233).  A row is four workgroups (one per head) whose shares of y meet in ws; launches
- * that share ws / counters must be ordered on one stream, as with estts_gemm's.  Same products as estts_gemm + estts_attention + estts_gemm on one row, summed in
- * float32 on hi + lo: equal to 1e-5 of the largest value, not bit for bit.
+ * that share ws / counters must be ordered on one stream, as with estts_gemm's.  The projections use the split bf16 operands of estts_gemm
+ * (hi hi + hi lo + lo hi in float32) in another order of summation; attention in float32: equal to the three launches to 1e-5
+ * of the largest value, not bit for bit.
  * ------------------------------------------------------------------------------------------ */
 typedef struct estts_cross_row_args {
     const float* x; int32_t ldx;
