@@ -153,3 +153,32 @@ def test_oneshot_tile_of_48_columns_needs_its_block_row_clamped():
     for N in (500, 512, 1000, 1104):
         blocks, last = oneshot_w_blocks(N, 48, clamp=True)
         assert max(blocks) <= last
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# csrc/common.h xcd_tile_coord / csrc/gemm.hip region_tile_coord: every workgroup id of a grid names one tile, every tile once
+# ---------------------------------------------------------------------------------------------------------------------------
+def xcd_tile_coord(bx, by, bz, gx, gy, gz, y_first, remap=True, panel=0):
+    nwg = gx * gy * gz
+    i = bx + gx * (by + gy * bz)
+    if remap and nwg >= 16:
+        q, r, xcd = nwg >> 3, nwg & 7, i & 7
+        i = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + (i >> 3)
+    tz, tile = i % gz, i // gz
+    if panel > 0 and gz == 1:
+        per = panel * gy
+        pn, rem = tile // per, tile % per
+        w = min(panel, gx - pn * panel)
+        ty = rem // w
+        return pn * panel + (rem - ty * w), ty, tz
+    return (tile // gy, tile % gy, tz) if y_first else (tile % gx, tile // gx, tz)
+
+
+@pytest.mark.parametrize('gx,gy,gz', [(1, 1, 1), (16, 19, 1), (11, 19, 1), (3, 5, 1), (8, 2, 1), (24, 19, 1), (7, 7, 3), (16, 4, 8),
+                                      (5, 1, 1), (1, 300, 1), (13, 10, 2)])
+def test_xcd_tile_numbering_is_a_bijection(gx, gy, gz):
+    for y_first, remap, panel in itertools.product((False, True), (False, True), (0, 4)):
+        tiles = {xcd_tile_coord(bx, by, bz, gx, gy, gz, y_first, remap, panel)
+                 for bx in range(gx) for by in range(gy) for bz in range(gz)}
+        assert len(tiles) == gx * gy * gz, (y_first, remap, panel)
+        assert all(0 <= tx < gx and 0 <= ty < gy and 0 <= tz < gz for tx, ty, tz in tiles), (y_first, remap, panel)
